@@ -1,0 +1,395 @@
+// msm_engine.hip — Pippenger multi-scalar multiplication sum_i s_i * P_i on gfx950.
+//
+// What it replaces: ark-ec 0.3.0 VariableBaseMSM::multi_scalar_mul as called by the reference at
+// src/worker.rs:179-182 (varMsm), :117-123,405 (commit_polynomial / round1), src/dispatcher.rs:1052
+// and src/dispatcher2.rs:835-893.  Only the group element is contractual
+// (Appendix A.1), so the GPU algorithm is free to differ from the CPU one:
+//
+//   1. digits      every scalar is cut into W = ceil(bits/c) unsigned c-bit digits; a histogram of
+//                  (window, digit) pairs is built with HBM atomics            (msm_count_kernel)
+//   2. offsets     exclusive prefix sum over the W*2^c counters               (scan_* kernels)
+//   3. scatter     point indices are written to their bucket's segment        (msm_scatter_kernel)
+//   4. accumulate  one lane per bucket walks its segment and adds the (affine, 256-bit-limb loaded)
+//                  bases into an XYZZ accumulator held in VGPRs               (msm_accumulate_kernel)
+//   5. reduce      sum_d d*B_d per window: every lane does the running-sum trick on a chunk of K
+//                  buckets and fixes its offset with a small double-and-add   (msm_reduce_chunks_kernel)
+//                  followed by an LDS tree over the chunk sums                (msm_window_sum_kernel)
+//   6. fold        W window sums -> one point (W*c doublings), on the host; the result is returned as
+//                  a normalised Jacobian triple (x, y, 1) / (1, 1, 0).
+//
+// Zero scalars and digit 0 never touch a bucket (the reference filters zeros too); scalar 1 needs no
+// special case (digit 1 in window 0).  Infinity bases are skipped, P+P and P+(-P) are handled in
+// ec.cuh.  No MFMA: ~10 Fq Montgomery products per (point, window) dominate everything — the
+// kernel is v_mad_u64_u32 bound; algorithmic HBM bytes are n*(sizeof(affine)+32).
+#include <algorithm>
+#include <cstring>
+
+#include "constants.h"
+#include "ec.cuh"
+#include "plonk_internal.hpp"
+
+template <int NQ> static const FpParams<NQ>& fq_params(int curve);
+template <> const FpParams<8>& fq_params<8>(int) { return BN254_FQ_PARAMS; }
+template <> const FpParams<12>& fq_params<12>(int) { return BLS12_381_FQ_PARAMS; }
+
+// ---------------------------------------------------------------------------------------------- helpers
+template <typename T> __device__ __forceinline__ T load16(const T* p) {
+    static_assert(sizeof(T) % 16 == 0, "16-byte multiple");
+    T r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store16(T* p, const T& v) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+}
+
+__device__ __forceinline__ uint32_t scalar_digit(const uint32_t* s, int bit0, int c) {
+    const int limb = bit0 >> 5, off = bit0 & 31;
+    uint64_t v = s[limb];
+    if (limb + 1 < 8) v |= (uint64_t)s[limb + 1] << 32;
+    return (uint32_t)(v >> off) & ((1u << c) - 1);
+}
+
+// ---------------------------------------------------------------------------------------------- 1/3: histogram + scatter
+__global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
+                                                        uint32_t* __restrict__ counts) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t* s = scalars + 8 * i;
+        for (int w = 0; w < W; w++) {
+            const uint32_t d = scalar_digit(s, w * c, c);
+            if (d) atomicAdd(&counts[((uint64_t)w << c) + d], 1u);
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
+                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
+                                                          uint32_t* __restrict__ sorted) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t* s = scalars + 8 * i;
+        for (int w = 0; w < W; w++) {
+            const uint32_t d = scalar_digit(s, w * c, c);
+            if (d) {
+                const uint64_t b = ((uint64_t)w << c) + d;
+                const uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
+                sorted[pos] = (uint32_t)i;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 2: exclusive scan (u32)
+#define SCAN_ITEMS 16
+#define SCAN_THREADS 256
+#define SCAN_CHUNK (SCAN_ITEMS * SCAN_THREADS)
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ block_sums) {
+    __shared__ uint32_t red[SCAN_THREADS];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t s = 0;
+    for (int k = 0; k < SCAN_ITEMS; k++) if (base + k < n) s += in[base + k];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = SCAN_THREADS / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t* __restrict__ block_sums, uint64_t nblocks, uint32_t* __restrict__ total_out) {
+    __shared__ uint32_t buf[1024];
+    __shared__ uint32_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint64_t base = 0; base < nblocks; base += 1024) {
+        const uint64_t i = base + threadIdx.x;
+        const uint32_t v = i < nblocks ? block_sums[i] : 0;
+        buf[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+            __syncthreads();
+            buf[threadIdx.x] += t;
+            __syncthreads();
+        }
+        const uint32_t incl = buf[threadIdx.x];
+        if (i < nblocks) block_sums[i] = carry + incl - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __restrict__ block_offsets,
+                                                                  uint32_t* __restrict__ out) {
+    __shared__ uint32_t buf[SCAN_THREADS];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    uint32_t v[SCAN_ITEMS];
+    uint32_t s = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) { v[k] = (base + k < n) ? in[base + k] : 0; s += v[k]; }
+    buf[threadIdx.x] = s;
+    __syncthreads();
+    for (int d = 1; d < SCAN_THREADS; d <<= 1) {
+        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = block_offsets[blockIdx.x] + buf[threadIdx.x] - s;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+        if (base + k < n) out[base + k] = run;
+        run += v[k];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- 4: bucket accumulation
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffPt<NQ>* __restrict__ bases, const uint32_t* __restrict__ sorted,
+                                                             const uint32_t* __restrict__ offsets, uint64_t nbuckets,
+                                                             XyzzPt<NQ>* __restrict__ buckets, const FpParams<NQ> P) {
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nbuckets) return;
+    const uint32_t beg = offsets[b], end = offsets[b + 1];
+    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    for (uint32_t j = beg; j < end; j++) {
+        const AffPt<NQ> q = load16(bases + sorted[j]);
+        acc = xyzz_madd(acc, q, P);
+    }
+    store16(buckets + b, acc);
+}
+
+// ---------------------------------------------------------------------------------------------- 5: window reduction
+// chunk (w, ch) covers digits d in [ch*K, (ch+1)*K): out = sum_d d * B_d
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_reduce_chunks_kernel(const XyzzPt<NQ>* __restrict__ buckets, int c, int logk, uint64_t nchunks_total,
+                                                                XyzzPt<NQ>* __restrict__ chunk_out, const FpParams<NQ> P) {
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= nchunks_total) return;
+    const uint64_t nch = (uint64_t)1 << (c - logk);
+    const uint64_t w = id / nch, ch = id % nch;
+    const uint64_t K = (uint64_t)1 << logk;
+    const XyzzPt<NQ>* B = buckets + (w << c) + ch * K;
+    XyzzPt<NQ> running = xyzz_inf<NQ>(), acc = xyzz_inf<NQ>();
+    for (uint64_t d = K; d-- > 0;) {
+        acc = xyzz_add_cold(acc, running, P);
+        const XyzzPt<NQ> bd = load16(B + d);
+        running = xyzz_add_cold(running, bd, P);
+    }
+    // acc = sum (d - lo) B_d ; add lo * S, lo = ch*K
+    if (ch != 0 && !xyzz_is_inf(running)) {
+        XyzzPt<NQ> t = running;
+        // t = ch * S (MSB-first double-and-add over the c-logk bits of ch), then K doublings
+        XyzzPt<NQ> m = xyzz_inf<NQ>();
+        for (int i = c - logk - 1; i >= 0; i--) {
+            m = xyzz_dbl_cold(m, P);
+            if ((ch >> i) & 1) m = xyzz_add_cold(m, t, P);
+        }
+        for (int i = 0; i < logk; i++) m = xyzz_dbl_cold(m, P);
+        acc = xyzz_add_cold(acc, m, P);
+    }
+    store16(chunk_out + id, acc);
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XyzzPt<NQ>* __restrict__ chunks, uint64_t nch, XyzzPt<NQ>* __restrict__ wsum,
+                                                             const FpParams<NQ> P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XyzzPt<NQ>* sh = reinterpret_cast<XyzzPt<NQ>*>(smem_raw);
+    const uint64_t w = blockIdx.x;
+    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    for (uint64_t i = threadIdx.x; i < nch; i += blockDim.x) acc = xyzz_add_cold(acc, load16(chunks + w * nch + i), P);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = blockDim.x / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            XyzzPt<NQ> a = sh[threadIdx.x], b = sh[threadIdx.x + d];
+            sh[threadIdx.x] = xyzz_add_cold(a, b, P);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store16(wsum + w, sh[0]);
+}
+
+// ---------------------------------------------------------------------------------------------- ark layout -> compact
+// arkworks GroupAffine { x, y, infinity: bool } padded to 8 bytes: stride 16*Q64 + 8 bytes.
+template <int NQ>
+__global__ void __launch_bounds__(256) bases_convert_kernel(const uint32_t* __restrict__ raw, uint64_t n, AffPt<NQ>* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t* s = raw + i * (2 * NQ + 2);
+    AffPt<NQ> p;
+    const bool inf = (s[2 * NQ] & 0xff) != 0;
+#pragma unroll
+    for (int k = 0; k < NQ; k++) { p.x.l[k] = inf ? 0 : s[k]; p.y.l[k] = inf ? 0 : s[NQ + k]; }
+    store16(out + i, p);
+}
+
+int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (curve == PLONK_BN254)
+        hipLaunchKernelGGL(bases_convert_kernel<8>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<8>*)d_compact);
+    else
+        hipLaunchKernelGGL(bases_convert_kernel<12>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<12>*)d_compact);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "bases_convert launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- host orchestration
+static int choose_window(size_t n, int bits) {
+    double best = 1e300;
+    int bc = 4;
+    for (int c = 4; c <= 20; c++) {
+        const int W = (bits + c - 1) / c;
+        // madd ~10 field products per (point, window); chunked reduction ~2 full adds (14 products) per bucket
+        const double cost = (double)W * ((double)n * 10.0 + (double)((size_t)1 << c) * 2.5 * 14.0);
+        if (cost < best) { best = cost; bc = c; }
+    }
+    return bc;
+}
+
+static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
+    if (ws.bytes >= bytes) return PLONK_OK;
+    if (ws.d_buf) hipFree(ws.d_buf);
+    ws.d_buf = nullptr; ws.bytes = 0;
+    HIP_TRY(hipMalloc(&ws.d_buf, bytes));
+    ws.bytes = bytes;
+    return PLONK_OK;
+}
+
+static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+template <int NQ>
+static int msm_slice(int curve, const AffPt<NQ>* d_bases, const uint32_t* d_scalars, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
+                     int window_bits, hipStream_t stream) {
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    const int bits = fr_params(curve).bits;
+    const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 22) : choose_window(n, bits);
+    const int W = (bits + c - 1) / c;
+    const uint64_t nb = (uint64_t)1 << c, nbuckets = (uint64_t)W * nb;
+    const int logk = std::min(c, 4);
+    const uint64_t nch = nb >> logk, nchunks_total = (uint64_t)W * nch;
+    const uint64_t nscan_blocks = (nbuckets + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
+
+    size_t off = 0;
+    const size_t o_counts = off; off = align_up(off + nbuckets * 4, 256);
+    const size_t o_offsets = off; off = align_up(off + (nbuckets + 1) * 4, 256);
+    const size_t o_bsums = off; off = align_up(off + (nscan_blocks + 1) * 4, 256);
+    const size_t o_sorted = off; off = align_up(off + (size_t)n * W * 4, 256);
+    const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_chunks = off; off = align_up(off + nchunks_total * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_wsum = off; off = align_up(off + (size_t)W * sizeof(XyzzPt<NQ>), 256);
+    int rc = ensure_ws(ws, off);
+    if (rc) return rc;
+    char* base = (char*)ws.d_buf;
+    uint32_t* counts = (uint32_t*)(base + o_counts);
+    uint32_t* offsets = (uint32_t*)(base + o_offsets);
+    uint32_t* bsums = (uint32_t*)(base + o_bsums);
+    uint32_t* sorted = (uint32_t*)(base + o_sorted);
+    XyzzPt<NQ>* buckets = (XyzzPt<NQ>*)(base + o_buckets);
+    XyzzPt<NQ>* chunks = (XyzzPt<NQ>*)(base + o_chunks);
+    XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
+
+    const uint32_t sgrid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 32);
+    HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, stream));
+    { ProfScope ps("msm_count_kernel", stream);
+    hipLaunchKernelGGL(msm_count_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, counts); }
+    { ProfScope ps("msm_scan", stream);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, counts, nbuckets, bsums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsums, nscan_blocks, offsets + nbuckets);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, counts, nbuckets, bsums, offsets); }
+    HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, stream));
+    { ProfScope ps("msm_scatter_kernel", stream);
+    hipLaunchKernelGGL(msm_scatter_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, offsets, counts, sorted); }
+    { ProfScope ps("msm_accumulate_kernel", stream);
+    hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, nbuckets,
+                       buckets, P); }
+    { ProfScope ps("msm_reduce_chunks_kernel", stream);
+    hipLaunchKernelGGL(msm_reduce_chunks_kernel<NQ>, dim3((uint32_t)((nchunks_total + 255) / 256)), dim3(256), 0, stream, buckets, c, logk,
+                       nchunks_total, chunks, P); }
+    const uint32_t wthreads = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, nch));
+    // blockDim must be a power of two for the tree
+    uint32_t wt = 1;
+    while (wt * 2 <= wthreads) wt *= 2;
+    { ProfScope ps("msm_window_sum_kernel", stream);
+    hipLaunchKernelGGL(msm_window_sum_kernel<NQ>, dim3((uint32_t)W), dim3(wt), wt * sizeof(XyzzPt<NQ>), stream, chunks, nch, wsum, P); }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
+
+    std::vector<XyzzPt<NQ>> h(W);
+    HIP_TRY(hipMemcpyAsync(h.data(), wsum, (size_t)W * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    XyzzPt<NQ> total = xyzz_inf<NQ>();
+    for (int w = W - 1; w >= 0; w--) {
+        if (!xyzz_is_inf(total))
+            for (int k = 0; k < c; k++) total = xyzz_dbl(total, P);
+        total = xyzz_add(total, h[w], P);
+    }
+    *h_result = total;
+    return PLONK_OK;
+}
+
+template <int NQ>
+static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
+                     hipStream_t stream) {
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    XyzzPt<NQ> total = xyzz_inf<NQ>();
+    const size_t SLICE = (size_t)1 << 26;
+    for (size_t s = 0; s < n; s += SLICE) {
+        const size_t m = std::min(SLICE, n - s);
+        XyzzPt<NQ> part;
+        int rc = msm_slice<NQ>(curve, (const AffPt<NQ>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, stream);
+        if (rc) return rc;
+        total = xyzz_add(total, part, P);
+    }
+    JacPt<NQ> j = jac_from_xyzz_normalised(total, P);
+    memcpy(h_out_jac, &j, sizeof j);
+    return PLONK_OK;
+}
+
+int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
+            hipStream_t stream) {
+    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, stream);
+    return msm_run_t<12>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, stream);
+}
+
+template <int NQ> static void jac_add_host_t(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    JacPt<NQ> ja, jb;
+    memcpy(&ja, a, sizeof ja); memcpy(&jb, b, sizeof jb);
+    XyzzPt<NQ> s = xyzz_add(xyzz_from_jac(ja, P), xyzz_from_jac(jb, P), P);
+    JacPt<NQ> r = jac_from_xyzz_normalised(s, P);
+    memcpy(out, &r, sizeof r);
+}
+int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out) {
+    if (curve == PLONK_BN254) jac_add_host_t<8>(curve, a, b, out); else jac_add_host_t<12>(curve, a, b, out);
+    return PLONK_OK;
+}
+template <int NQ> static void jac_to_affine_host_t(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf) {
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    JacPt<NQ> j;
+    memcpy(&j, jac, sizeof j);
+    XyzzPt<NQ> x = xyzz_from_jac(j, P);
+    *is_inf = xyzz_is_inf(x) ? 1 : 0;
+    AffPt<NQ> a = xyzz_to_affine(x, P);
+    if (*is_inf) a.y = fp_one(P);          // arkworks' affine zero is (0, 1, infinity = true)
+    memcpy(out_xy, &a, sizeof a);
+}
+int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf) {
+    if (curve == PLONK_BN254) jac_to_affine_host_t<8>(curve, jac, out_xy, is_inf); else jac_to_affine_host_t<12>(curve, jac, out_xy, is_inf);
+    return PLONK_OK;
+}

@@ -1,0 +1,334 @@
+// ntt_engine.hip — host-side planner / launcher for the LDS-tiled NTT passes (ntt_kernels.cuh),
+// twiddle-table setup, and the Fr matrix transpose (transpose.rs:413 equivalent).
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "constants.h"
+#include "ntt_kernels.cuh"
+#include "plonk_internal.hpp"
+
+static int g_ntt_max_log_r = NTT_LOG_RMAX;
+void ntt_set_max_log_r(int v) { g_ntt_max_log_r = std::max(3, std::min(v, NTT_LOG_RMAX)); }
+
+const FrParams& fr_params(int curve) { return curve == PLONK_BN254 ? BN254_FR_PARAMS : BLS12_381_FR_PARAMS; }
+
+// ---------------------------------------------------------------------------------------------- tables
+static Fr host_pow2k(const Fr& a, int k, const FrParams& P) {   // a^(2^k)
+    Fr r = a;
+    for (int i = 0; i < k; i++) r = fp_sqr(r, P);
+    return r;
+}
+
+static int upload_powers(Fr** d_out, const Fr& base, size_t count, const Fr& first, const FrParams& P, hipStream_t stream) {
+    std::vector<Fr> h(count);
+    Fr acc = first;
+    for (size_t i = 0; i < count; i++) { h[i] = acc; acc = fp_mul(acc, base, P); }
+    HIP_TRY(hipMalloc((void**)d_out, count * sizeof(Fr)));
+    HIP_TRY(hipMemcpyAsync(*d_out, h.data(), count * sizeof(Fr), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PLONK_OK;
+}
+
+int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
+    T.curve = curve;
+    T.fp = fr_params(curve);
+    const FrParams& P = T.fp;
+    const uint32_t* root_l = curve == PLONK_BN254 ? BN254_FR_TWO_ADIC_ROOT_MONT : BLS12_381_FR_TWO_ADIC_ROOT_MONT;
+    const uint32_t* g_l = curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
+    const uint32_t* gi_l = curve == PLONK_BN254 ? BN254_FR_GENERATOR_INV_MONT : BLS12_381_FR_GENERATOR_INV_MONT;
+    T.two_adicity = curve == PLONK_BN254 ? BN254_FR_TWO_ADICITY : BLS12_381_FR_TWO_ADICITY;
+    T.lt = (T.two_adicity + 1) / 2;
+    const Fr one = fp_one(P);
+    Fr w[2];
+    w[0] = fp_from_limbs<8>(root_l);
+    w[1] = fp_inv(w[0], P);
+    T.h_root[0] = w[0];
+    T.h_root[1] = w[1];
+    Fr g[2] = {fp_from_limbs<8>(g_l), fp_from_limbs<8>(gi_l)};
+    const size_t nt = (size_t)1 << T.lt;
+    for (int d = 0; d < 2; d++) {
+        int rc;
+        // Nmax = 2^two_adicity (= 2^(2*lt) for both curves)
+        if ((rc = upload_powers(&T.tw_lo[d], w[d], nt, one, P, stream))) return rc;
+        if ((rc = upload_powers(&T.tw_hi[d], host_pow2k(w[d], T.lt, P), nt, one, P, stream))) return rc;
+        if ((rc = upload_powers(&T.tw_small[d], host_pow2k(w[d], T.two_adicity - NTT_LOG_RMAX, P),
+                                (size_t)1 << (NTT_LOG_RMAX - 1), one, P, stream))) return rc;
+        if ((rc = upload_powers(&T.g_lo[d], g[d], nt, one, P, stream))) return rc;
+        if ((rc = upload_powers(&T.g_hi[d], host_pow2k(g[d], T.lt, P), nt, one, P, stream))) return rc;
+    }
+    // 2^-k
+    Fr two = fp_add(one, one, P), half = fp_inv(two, P);
+    T.h_pow2_inv.resize(T.two_adicity + 1);
+    Fr acc = one;
+    for (int k = 0; k <= T.two_adicity; k++) { T.h_pow2_inv[k] = acc; acc = fp_mul(acc, half, P); }
+    return PLONK_OK;
+}
+
+void ntt_tables_destroy(NttTables& T) {
+    for (int d = 0; d < 2; d++) {
+        hipFree(T.tw_small[d]); hipFree(T.tw_lo[d]); hipFree(T.tw_hi[d]); hipFree(T.g_lo[d]); hipFree(T.g_hi[d]);
+        T.tw_small[d] = T.tw_lo[d] = T.tw_hi[d] = T.g_lo[d] = T.g_hi[d] = nullptr;
+    }
+    for (auto& kv : T.tw_lo_scaled) hipFree(kv.second);
+    T.tw_lo_scaled.clear();
+}
+
+// w^-e * 2^-log_m for e < 2^lt (inverse transforms of size 2^log_m fold their 1/M here)
+static int get_scaled_lo(NttTables& T, int log_m, Fr** out, hipStream_t stream) {
+    auto it = T.tw_lo_scaled.find(log_m);
+    if (it != T.tw_lo_scaled.end()) { *out = it->second; return PLONK_OK; }
+    Fr* d = nullptr;
+    int rc = upload_powers(&d, T.h_root[1], (size_t)1 << T.lt, T.h_pow2_inv[log_m], T.fp, stream);
+    if (rc) return rc;
+    T.tw_lo_scaled[log_m] = d;
+    *out = d;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- plan
+std::vector<int> ntt_plan_widths(int log_m) {
+    std::vector<int> w;
+    const int mx = g_ntt_max_log_r;
+    if (log_m <= mx) { w.push_back(log_m); return w; }
+    int P = (log_m + mx - 1) / mx;
+    int base = log_m / P, rem = log_m % P;
+    for (int i = 0; i < P; i++) w.push_back(base + (i < rem ? 1 : 0));
+    return w;
+}
+
+static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
+
+static int pref_log_t(int log_r) {
+    if (log_r >= 10) return 2;
+    if (log_r == 9) return 3;
+    if (log_r < 3) return 9;  // EPT = R there: one lane per column, at most 512 lanes
+    return 11 - log_r;        // 2048-element tiles (64 KiB)
+}
+
+bool ntt_single_pass_inplace_ok(const NttCall& c) {
+    return ntt_plan_widths(c.log_m).size() == 1 && c.layout == NTT_CONTIGUOUS && c.out_layout == NTT_CONTIGUOUS && c.split_log < 0;
+}
+
+static TwoLevelScale make_scale(const NttTables& T, const ScaleSpec& s, uint64_t q_offset) {
+    TwoLevelScale o;
+    memset(&o, 0, sizeof o);
+    if (s.kind == 0) return o;
+    o.enabled = 1;
+    o.lt = T.lt;
+    uint64_t aq = s.aq, a0 = s.a0 + s.aq * q_offset, bq = s.bq, b0 = s.b0 + s.bq * q_offset;
+    if (s.kind == 1 || s.kind == 2) {
+        o.lo = T.g_lo[s.kind - 1];
+        o.hi = T.g_hi[s.kind - 1];
+    } else {
+        const int d = s.kind - 3;
+        o.lo = T.tw_lo[d];
+        o.hi = T.tw_hi[d];
+        const int sh = T.two_adicity - s.log_order;
+        aq <<= sh; a0 <<= sh; bq <<= sh; b0 <<= sh;
+    }
+    o.aq = aq; o.a0 = a0; o.bq = bq; o.b0 = b0;
+    return o;
+}
+
+template <int LOG_R>
+static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(ntt_pass_kernel<LOG_R>, dim3((uint32_t)grid), dim3(threads), lds, stream, P);
+    return hipGetLastError();
+}
+
+static hipError_t launch_pass(int log_r, const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t s) {
+    switch (log_r) {
+        case 1: return launch_one<1>(P, grid, threads, lds, s);
+        case 2: return launch_one<2>(P, grid, threads, lds, s);
+        case 3: return launch_one<3>(P, grid, threads, lds, s);
+        case 4: return launch_one<4>(P, grid, threads, lds, s);
+        case 5: return launch_one<5>(P, grid, threads, lds, s);
+        case 6: return launch_one<6>(P, grid, threads, lds, s);
+        case 7: return launch_one<7>(P, grid, threads, lds, s);
+        case 8: return launch_one<8>(P, grid, threads, lds, s);
+        case 9: return launch_one<9>(P, grid, threads, lds, s);
+        case 10: return launch_one<10>(P, grid, threads, lds, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
+    const int L = c.log_m;
+    if (L < 1 || L > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "ntt_run: log size %d outside [1,%d]", L, T.two_adicity);
+    if (c.batch == 0 || (c.batch & (c.batch - 1))) return plonk_fail(PLONK_ERR_ARG, "ntt_run: batch must be a power of two");
+    const uint64_t M = (uint64_t)1 << L, Bt = c.batch;
+    const std::vector<int> widths = ntt_plan_widths(L);
+    const int NP = (int)widths.size();
+    if (NP > NTT_MAX_PASSES) return plonk_fail(PLONK_ERR_ARG, "ntt_run: too many passes");
+    const int dir = c.inverse ? 1 : 0;
+    const bool interleaved = c.layout == NTT_INTERLEAVED;
+    if (NP > 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: in == out needs a single pass");
+    if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(c))
+        return plonk_fail(PLONK_ERR_ARG, "ntt_run: in-place only for contiguous single pass");
+
+    uint64_t r_prev = M;
+    for (int p = 0; p < NP; p++) {
+        const int w = widths[p];
+        const uint64_t R = (uint64_t)1 << w;
+        const uint64_t r_p = r_prev >> w;
+        const bool last = (p == NP - 1);
+        NttPassParams P;
+        memset(&P, 0, sizeof P);
+        P.fp = T.fp;
+        P.tw_small = T.tw_small[dir];
+        P.tw_lo = T.tw_lo[dir];
+        P.tw_hi = T.tw_hi[dir];
+        P.tw_lt = T.lt;
+        P.split_log = -1;
+        P.is_last = last ? 1 : 0;
+        P.in = c.in;
+        uint64_t grid = 0, avail = 1;
+        if (!last) {
+            P.out = const_cast<Fr*>(c.in);
+            P.tw_shift = T.two_adicity - ilog2(r_prev);
+            if (p == 0 && c.inverse) {
+                Fr* scaled = nullptr;
+                int rc = get_scaled_lo(T, L, &scaled, stream);
+                if (rc) return rc;
+                P.tw_lo = scaled;
+            }
+            avail = interleaved ? Bt : r_p;
+            int lt = std::min(pref_log_t(w), ilog2(avail));
+            const uint64_t Tt = (uint64_t)1 << lt;
+            P.log_t = lt;
+            if (!interleaved) {
+                P.n0 = r_p / Tt; P.n1 = M / r_prev;
+                P.ls0 = Tt; P.ls1 = r_prev; P.ls2 = M; P.l_astride = r_p; P.l_tstride = 1;
+                P.bs0 = Tt; P.bs1 = 0; P.tb = 1;
+                P.qs0 = 0; P.qs1 = 0; P.qs2 = 1; P.tq = 0;
+                P.pa = r_p; P.ps0 = Tt; P.ps1 = 0; P.pt = 1;
+                grid = Bt * P.n1 * P.n0;
+            } else {
+                P.n0 = Bt / Tt; P.n1 = r_p;
+                P.ls0 = Tt; P.ls1 = Bt; P.ls2 = r_prev * Bt; P.l_astride = r_p * Bt; P.l_tstride = 1;
+                P.bs0 = 0; P.bs1 = 1; P.tb = 0;
+                P.qs0 = Tt; P.qs1 = 0; P.qs2 = 0; P.tq = 1;
+                P.pa = r_p; P.ps0 = 0; P.ps1 = 1; P.pt = 0;
+                grid = (M / r_prev) * P.n1 * P.n0;
+            }
+            P.ss0 = P.ls0; P.ss1 = P.ls1; P.ss2 = P.ls2; P.s_istride = P.l_astride; P.s_tstride = 1;
+            P.tile_pitch = (uint32_t)Tt;
+        } else {
+            P.out = c.out;
+            P.kstride = M >> w;
+            if (!interleaved && NP >= 2) {
+                const uint64_t R1 = (uint64_t)1 << widths[0], r1 = M >> widths[0];
+                avail = R1;
+                int lt = std::min(pref_log_t(w), ilog2(avail));
+                const uint64_t Tt = (uint64_t)1 << lt;
+                P.log_t = lt;
+                P.n0 = R1 / Tt; P.n1 = (M >> w) / R1;
+                P.ls0 = Tt * r1; P.ls1 = R; P.ls2 = M; P.l_astride = 1; P.l_tstride = r1; P.load_a_fast = 1;
+                P.qs2 = 1; P.tq = 0;
+                P.ms0 = Tt; P.tk = 1;
+                P.rev_ndig = NP - 2;
+                for (int d = 0; d < NP - 2; d++) P.rev_w[d] = widths[1 + d];
+                P.rev_shift0 = widths[0];
+                grid = Bt * P.n1 * P.n0;
+            } else if (!interleaved) {       // single pass, contiguous: tile over arrays
+                avail = Bt;
+                int lt = std::min(pref_log_t(w), ilog2(avail));
+                const uint64_t Tt = (uint64_t)1 << lt;
+                P.log_t = lt;
+                P.n0 = Bt / Tt; P.n1 = 1;
+                P.ls0 = Tt * M; P.l_astride = 1; P.l_tstride = M; P.load_a_fast = 1;
+                P.qs0 = Tt; P.tq = 1;
+                P.ms0 = 0; P.tk = 0; P.rev_ndig = 0;
+                P.pa = 1;
+                grid = P.n0;
+            } else {
+                avail = Bt;
+                int lt = std::min(pref_log_t(w), ilog2(avail));
+                const uint64_t Tt = (uint64_t)1 << lt;
+                P.log_t = lt;
+                P.n0 = Bt / Tt; P.n1 = M >> w;
+                P.ls0 = Tt; P.ls1 = R * Bt; P.l_astride = Bt; P.l_tstride = 1; P.load_a_fast = 0;
+                P.qs0 = Tt; P.tq = 1;
+                P.ms0 = 0; P.tk = 0;
+                P.rev_ndig = NP - 1;
+                for (int d = 0; d < NP - 1; d++) P.rev_w[d] = widths[d];
+                P.rev_shift0 = 0;
+                P.pa = 1;
+                grid = P.n0 * P.n1;
+            }
+            if (c.out_layout == NTT_CONTIGUOUS) { P.oq = M; P.ok = 1; } else { P.oq = 1; P.ok = Bt; }
+            P.split_log = c.split_log;
+            P.split_blk = c.split_blk;
+            if (c.inverse && NP == 1) { P.scale_const_enabled = 1; P.scale_const = T.h_pow2_inv[L]; }
+            P.epi = make_scale(T, c.epi, c.q_offset);
+            // LDS pitch: +1 word of padding when lanes walk `a` on load, if it fits
+            const uint64_t Tt = (uint64_t)1 << P.log_t;
+            P.tile_pitch = (uint32_t)Tt;
+            if (P.load_a_fast) {
+                size_t padded = 8 * R * (Tt + 1) * 4 + std::max<size_t>(R / 2, 1) * 32;
+                if (padded <= 150 * 1024) P.tile_pitch = (uint32_t)(Tt + 1);
+            }
+        }
+        if (p == 0) P.pro = make_scale(T, c.pro, c.q_offset);
+        const uint64_t Tt = (uint64_t)1 << P.log_t;
+        const uint32_t ept = (w >= 3) ? 8 : (uint32_t)R;
+        const uint32_t threads = (uint32_t)(R * Tt / ept);
+        const size_t lds = (size_t)8 * R * P.tile_pitch * 4 + std::max<size_t>(R / 2, 1) * 32;
+        if (grid == 0 || grid > 0x7fffffffull) return plonk_fail(PLONK_ERR_ARG, "ntt_run: grid %llu out of range", (unsigned long long)grid);
+        static const char* const kNames[11] = {"", "ntt_pass_kernel<1>", "ntt_pass_kernel<2>", "ntt_pass_kernel<3>", "ntt_pass_kernel<4>",
+                                               "ntt_pass_kernel<5>", "ntt_pass_kernel<6>", "ntt_pass_kernel<7>", "ntt_pass_kernel<8>",
+                                               "ntt_pass_kernel<9>", "ntt_pass_kernel<10>"};
+        hipError_t e;
+        {
+            ProfScope ps_all("ntt_pass_kernel", stream);
+            ProfScope ps_w(kNames[w], stream);
+            e = launch_pass(w, P, grid, threads, lds, stream);
+        }
+        if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "ntt pass launch (log_r=%d, grid=%llu, threads=%u, lds=%zu): %s", w,
+                                               (unsigned long long)grid, threads, lds, hipGetErrorString(e));
+        r_prev = r_p;
+    }
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- transpose
+// out[c][r] = in[r][c] for a rows x cols matrix of Fr.  16x16-element tiles staged through LDS so
+// that both the load and the store touch 512-byte contiguous pieces.
+__global__ void __launch_bounds__(256) transpose_fr_kernel(const Fr* __restrict__ in, Fr* __restrict__ out, uint64_t rows, uint64_t cols) {
+    __shared__ uint4 tile[16][16 * 2 + 1];
+    const uint64_t tiles_c = (cols + 15) / 16;
+    const uint64_t tr = blockIdx.x / tiles_c, tc = blockIdx.x % tiles_c;
+    const uint32_t ly = threadIdx.x / 16, lx = threadIdx.x % 16;
+    uint64_t r = tr * 16 + ly, cc = tc * 16 + lx;
+    if (r < rows && cc < cols) {
+        const uint4* src = reinterpret_cast<const uint4*>(in + r * cols + cc);
+        tile[ly][2 * lx] = src[0];
+        tile[ly][2 * lx + 1] = src[1];
+    }
+    __syncthreads();
+    uint64_t orow = tc * 16 + ly, ocol = tr * 16 + lx;     // out is cols x rows
+    if (orow < cols && ocol < rows) {
+        uint4* dst = reinterpret_cast<uint4*>(out + orow * rows + ocol);
+        dst[0] = tile[lx][2 * ly];
+        dst[1] = tile[lx][2 * ly + 1];
+    }
+}
+
+int transpose_fr(const Fr* in, Fr* out, uint64_t rows, uint64_t cols, hipStream_t stream) {
+    if (rows == 0 || cols == 0) return PLONK_OK;
+    if (in == out) return plonk_fail(PLONK_ERR_ARG, "transpose_fr: in == out");
+    const uint64_t grid = ((rows + 15) / 16) * ((cols + 15) / 16);
+    if (grid > 0x7fffffffull) return plonk_fail(PLONK_ERR_ARG, "transpose_fr: too large");
+    hipLaunchKernelGGL(transpose_fr_kernel, dim3((uint32_t)grid), dim3(256), 0, stream, in, out, rows, cols);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "transpose launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}

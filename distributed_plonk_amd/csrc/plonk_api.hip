@@ -1,0 +1,659 @@
+// plonk_api.hip — the C ABI of include/plonk_hip.h: worker state (reference `State`, worker.rs:42-59)
+// as an opaque per-GPU context, and one entry point per PlonkSlave / PlonkPeer method.
+#include <cstdarg>
+#include <cstring>
+#include <map>
+#include <memory>
+
+#include "ec.cuh"
+#include "plonk_internal.hpp"
+
+void ntt_set_max_log_r(int v);
+
+// ---------------------------------------------------------------------------------------------- errors
+static thread_local char g_err[512] = {0};
+char* plonk_last_error_buf() { return g_err; }
+int plonk_fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+extern "C" const char* plonk_last_error(void) { return g_err; }
+
+// ---------------------------------------------------------------------------------------------- per-kernel timing
+KernelProfiler& kernel_profiler() { static KernelProfiler p; return p; }
+void KernelProfiler::resolve() {
+    for (auto& r : pending) {
+        float ms = 0;
+        if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& t = totals[r.name];
+            t.first += ms; t.second += 1;
+        }
+        (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b);
+    }
+    pending.clear();
+}
+void KernelProfiler::reset() { resolve(); totals.clear(); }
+
+// ---------------------------------------------------------------------------------------------- context
+struct FftTask {          // reference FftTask, worker.rs:32-40
+    bool is_quot = false, is_inv = false, is_coset = false;
+    std::vector<plonk_fft_workload> wl;
+    size_t me = 0;
+    int log_n = 0;
+    uint64_t r = 0, c = 0, nrows = 0, ncols = 0;
+    Fr* d_rows = nullptr;      // [nrows][c]      (owned unless rows_external)
+    bool rows_external = false;
+    Fr* d_send = nullptr;      // S blocks of [nrows][ncols]
+    Fr* d_recv = nullptr;      // [r][ncols]
+    std::vector<uint8_t> row_present;
+    uint64_t rows_filled = 0;
+    bool prepared = false;
+};
+
+struct plonk_ctx {
+    int device = 0, curve = 0;
+    hipStream_t stream = nullptr;
+    NttTables tables;
+    // SRS (State.bases)
+    void* d_bases = nullptr;
+    size_t n_bases = 0;
+    bool bases_external = false;
+    // domains (State.domain / quot_domain and their r/c splits are derived on demand)
+    size_t domain_size = 0, quot_domain_size = 0;
+    std::map<uint64_t, FftTask> tasks;          // State.fft_tasks
+    Fr* d_wire = nullptr;                       // State.wire
+    size_t wire_len = 0;
+    // scratch
+    void* d_scratch = nullptr;
+    size_t scratch_bytes = 0;
+    void* d_scratch2 = nullptr;
+    size_t scratch2_bytes = 0;
+    MsmWorkspace msm_ws;
+    int msm_window = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+};
+
+static size_t aff_bytes(int curve) { return curve == PLONK_BN254 ? 64 : 96; }
+static size_t jac_bytes(int curve) { return curve == PLONK_BN254 ? 96 : 144; }
+static size_t ark_aff_bytes(int curve) { return curve == PLONK_BN254 ? 72 : 104; }
+
+static int ilog2_exact(size_t n) {
+    if (n == 0 || (n & (n - 1))) return -1;
+    int l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+static int ensure_scratch(plonk_ctx* ctx, size_t bytes) {
+    if (ctx->scratch_bytes >= bytes) return PLONK_OK;
+    if (ctx->d_scratch) hipFree(ctx->d_scratch);
+    ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->d_scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return PLONK_OK;
+}
+static int ensure_scratch2(plonk_ctx* ctx, size_t bytes) {
+    if (ctx->scratch2_bytes >= bytes) return PLONK_OK;
+    if (ctx->d_scratch2) hipFree(ctx->d_scratch2);
+    ctx->d_scratch2 = nullptr; ctx->scratch2_bytes = 0;
+    HIP_TRY(hipMalloc(&ctx->d_scratch2, bytes));
+    ctx->scratch2_bytes = bytes;
+    return PLONK_OK;
+}
+
+#define CHECK_CTX(ctx)                                                  \
+    do {                                                                \
+        if (!(ctx)) return plonk_fail(PLONK_ERR_ARG, "null context");   \
+        HIP_TRY(hipSetDevice((ctx)->device));                           \
+    } while (0)
+
+static void free_task(FftTask& t) {
+    if (t.d_rows && !t.rows_external) hipFree(t.d_rows);
+    if (t.d_send) hipFree(t.d_send);
+    if (t.d_recv && t.d_recv != t.d_send) hipFree(t.d_recv);
+    t.d_rows = t.d_send = t.d_recv = nullptr;
+}
+
+extern "C" int plonk_create(plonk_ctx** out, int device, int curve) {
+    if (!out) return plonk_fail(PLONK_ERR_ARG, "plonk_create: null out");
+    if (curve != PLONK_BN254 && curve != PLONK_BLS12_381) return plonk_fail(PLONK_ERR_ARG, "plonk_create: unknown curve %d", curve);
+    int ndev = 0;
+    HIP_TRY(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return plonk_fail(PLONK_ERR_HIP, "plonk_create: device %d not present (%d visible)", device, ndev);
+    HIP_TRY(hipSetDevice(device));
+    std::unique_ptr<plonk_ctx> ctx(new plonk_ctx());
+    ctx->device = device;
+    ctx->curve = curve;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    int rc = ntt_tables_create(ctx->tables, curve, ctx->stream);
+    if (rc) return rc;
+    *out = ctx.release();
+    return PLONK_OK;
+}
+
+extern "C" void plonk_destroy(plonk_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->tasks) free_task(kv.second);
+    ntt_tables_destroy(ctx->tables);
+    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
+    if (ctx->d_wire) hipFree(ctx->d_wire);
+    if (ctx->d_scratch) hipFree(ctx->d_scratch);
+    if (ctx->d_scratch2) hipFree(ctx->d_scratch2);
+    if (ctx->msm_ws.d_buf) hipFree(ctx->msm_ws.d_buf);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" void* plonk_stream(plonk_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+extern "C" int plonk_sync(plonk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) {
+    if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
+    if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
+    if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
+    return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);
+}
+
+extern "C" int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms) {
+    CHECK_CTX(ctx);
+    if (!out_ms || !ctx->ev_valid) return plonk_fail(PLONK_ERR_STATE, "no timed call yet");
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    *out_ms = ms;
+    return PLONK_OK;
+}
+
+static int check_domain(plonk_ctx* ctx, size_t size, const char* what) {
+    if (size == 0) return PLONK_OK;
+    int l = ilog2_exact(size);
+    if (l < 0) return plonk_fail(PLONK_ERR_DOMAIN, "%s %zu is not a power of two", what, size);
+    if (l > ctx->tables.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "%s 2^%d exceeds the field's two-adicity %d", what, l, ctx->tables.two_adicity);
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- init @0
+static int set_domains(plonk_ctx* ctx, size_t domain_size, size_t quot_domain_size) {
+    // Radix2EvaluationDomain::new rounds up to a power of two (worker.rs:143,150); fail like
+    // DomainCreationError when it does not exist.
+    auto round_up = [](size_t n) { size_t s = 1; while (s < n) s <<= 1; return n ? s : 0; };
+    domain_size = round_up(domain_size);
+    quot_domain_size = round_up(quot_domain_size);
+    int rc;
+    if ((rc = check_domain(ctx, domain_size, "domain_size"))) return rc;
+    if ((rc = check_domain(ctx, quot_domain_size, "quot_domain_size"))) return rc;
+    ctx->domain_size = domain_size;
+    ctx->quot_domain_size = quot_domain_size;
+    return PLONK_OK;
+}
+
+extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int base_layout, size_t domain_size, size_t quot_domain_size) {
+    CHECK_CTX(ctx);
+    if (n_bases && !bases) return plonk_fail(PLONK_ERR_ARG, "plonk_init: null bases");
+    if (base_layout != PLONK_BASES_XY && base_layout != PLONK_BASES_ARK) return plonk_fail(PLONK_ERR_ARG, "plonk_init: layout %d", base_layout);
+    int rc = set_domains(ctx, domain_size, quot_domain_size);
+    if (rc) return rc;
+    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
+    ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->bases_external = false;
+    if (n_bases) {
+        const size_t ab = aff_bytes(ctx->curve);
+        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * ab));
+        if (base_layout == PLONK_BASES_XY) {
+            HIP_TRY(hipMemcpyAsync(ctx->d_bases, bases, n_bases * ab, hipMemcpyHostToDevice, ctx->stream));
+        } else {
+            const size_t rb = ark_aff_bytes(ctx->curve) * n_bases;
+            if ((rc = ensure_scratch(ctx, rb))) return rc;
+            HIP_TRY(hipMemcpyAsync(ctx->d_scratch, bases, rb, hipMemcpyHostToDevice, ctx->stream));
+            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, ctx->d_bases, ctx->stream))) return rc;
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->n_bases = n_bases;
+    }
+    return PLONK_OK;
+}
+
+extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size, size_t quot_domain_size) {
+    CHECK_CTX(ctx);
+    int rc = set_domains(ctx, domain_size, quot_domain_size);
+    if (rc) return rc;
+    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
+    ctx->d_bases = const_cast<void*>(d_bases_xy);
+    ctx->n_bases = n_bases;
+    ctx->bases_external = true;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- varMsm @1
+static int msm_device(plonk_ctx* ctx, size_t start, size_t n, const uint32_t* d_scalars, uint64_t* out_jac) {
+    if (n == 0) {       // empty MSM = zero (1,1,0)
+        uint64_t a[18], b[18];
+        memset(a, 0, sizeof a); memset(b, 0, sizeof b);
+        return msm_jac_add_host(ctx->curve, (uint32_t*)a, (uint32_t*)b, (uint32_t*)out_jac);
+    }
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * aff_bytes(ctx->curve), d_scalars, n, (uint32_t*)out_jac, ctx->msm_ws,
+                     ctx->msm_window, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
+}
+
+extern "C" int plonk_var_msm(plonk_ctx* ctx, const plonk_msm_workload* wl, const uint64_t* scalars, size_t n_scalars, uint64_t* out_jacobian) {
+    CHECK_CTX(ctx);
+    if (!wl || !out_jacobian || (n_scalars && !scalars)) return plonk_fail(PLONK_ERR_ARG, "plonk_var_msm: null argument");
+    if (wl->start > wl->end || wl->end > ctx->n_bases)
+        return plonk_fail(PLONK_ERR_ARG, "plonk_var_msm: range [%llu,%llu) outside the %zu resident bases", (unsigned long long)wl->start,
+                          (unsigned long long)wl->end, ctx->n_bases);
+    const size_t n = std::min<size_t>(wl->end - wl->start, n_scalars);     // multi_scalar_mul takes min(len)
+    int rc = ensure_scratch(ctx, std::max<size_t>(n, 1) * 32);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->d_scratch, scalars, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return msm_device(ctx, wl->start, n, (const uint32_t*)ctx->d_scratch, out_jacobian);
+}
+
+extern "C" int plonk_msm_dev(plonk_ctx* ctx, size_t start, size_t end, const void* d_scalars, uint64_t* out_jacobian) {
+    CHECK_CTX(ctx);
+    if (!out_jacobian || (!d_scalars && end > start)) return plonk_fail(PLONK_ERR_ARG, "plonk_msm_dev: null argument");
+    if (start > end || end > ctx->n_bases) return plonk_fail(PLONK_ERR_ARG, "plonk_msm_dev: range outside the resident bases");
+    return msm_device(ctx, start, end - start, (const uint32_t*)d_scalars, out_jacobian);
+}
+
+// commit_polynomial: into_repr + zero-pad to the SRS length (zero scalars add nothing) + MSM
+extern "C" int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian) {
+    CHECK_CTX(ctx);
+    if (!out_jacobian || (n_coeffs && !d_coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_dev: null argument");
+    const size_t n = std::min(n_coeffs, ctx->n_bases);
+    int rc = ensure_scratch2(ctx, std::max<size_t>(n, 1) * 32);
+    if (rc) return rc;
+    if ((rc = fr_from_mont_dev(ctx->curve, (const Fr*)d_coeffs_mont, (Fr*)ctx->d_scratch2, n, ctx->stream))) return rc;
+    return msm_device(ctx, 0, n, (const uint32_t*)ctx->d_scratch2, out_jacobian);
+}
+
+extern "C" int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian) {
+    CHECK_CTX(ctx);
+    if (!out_jacobian || (n_coeffs && !coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit: null argument");
+    const size_t n = std::min(n_coeffs, ctx->n_bases);
+    int rc = ensure_scratch(ctx, std::max<size_t>(n, 1) * 32);
+    if (rc) return rc;
+    if (n) HIP_TRY(hipMemcpyAsync(ctx->d_scratch, coeffs_mont, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    return plonk_commit_dev(ctx, ctx->d_scratch, n, out_jacobian);
+}
+
+extern "C" int plonk_g1_add(int curve, const uint64_t* a, const uint64_t* b, uint64_t* out) {
+    if (!a || !b || !out) return plonk_fail(PLONK_ERR_ARG, "plonk_g1_add: null");
+    return msm_jac_add_host(curve, (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out);
+}
+extern "C" int plonk_g1_to_affine(int curve, const uint64_t* jac, uint64_t* out_xy, int* is_infinity) {
+    if (!jac || !out_xy || !is_infinity) return plonk_fail(PLONK_ERR_ARG, "plonk_g1_to_affine: null");
+    return msm_jac_to_affine_host(curve, (const uint32_t*)jac, (uint32_t*)out_xy, is_infinity);
+}
+
+// ---------------------------------------------------------------------------------------------- whole-vector NTT
+extern "C" int plonk_ntt_dev(plonk_ctx* ctx, void* d_in, void* d_out, size_t n, int is_inv, int is_coset) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_ntt_dev: null");
+    const int log_n = ilog2_exact(n);
+    if (log_n < 0) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_ntt_dev: size %zu is not a power of two", n);
+    if (log_n > ctx->tables.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_ntt_dev: 2^%d exceeds two-adicity", log_n);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    if (log_n == 0) {
+        if (d_in != d_out) HIP_TRY(hipMemcpyAsync(d_out, d_in, 32, hipMemcpyDeviceToDevice, ctx->stream));
+    } else {
+        NttCall c;
+        c.in = (const Fr*)d_in;
+        c.log_m = log_n;
+        c.batch = 1;
+        c.inverse = is_inv != 0;
+        if (is_coset && !is_inv) { c.pro.kind = 1; c.pro.b0 = 1; }      // x[n] * g^n
+        if (is_coset && is_inv) { c.epi.kind = 2; c.epi.b0 = 1; }       // X[k] * g^-k
+        Fr* out = (Fr*)d_out;
+        bool via_scratch = false;
+        if (d_in == d_out && !ntt_single_pass_inplace_ok(c)) {
+            int rc = ensure_scratch(ctx, n * 32);
+            if (rc) return rc;
+            out = (Fr*)ctx->d_scratch;
+            via_scratch = true;
+        }
+        c.out = out;
+        int rc = ntt_run(ctx->tables, c, ctx->stream);
+        if (rc) return rc;
+        if (via_scratch) HIP_TRY(hipMemcpyAsync(d_out, out, n * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return PLONK_OK;
+}
+
+extern "C" int plonk_ntt(plonk_ctx* ctx, uint64_t* v, size_t n, int is_inv, int is_coset) {
+    CHECK_CTX(ctx);
+    if (!v) return plonk_fail(PLONK_ERR_ARG, "plonk_ntt: null");
+    if (ilog2_exact(n) < 0) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_ntt: size %zu is not a power of two", n);
+    int rc = ensure_scratch2(ctx, 2 * n * 32);
+    if (rc) return rc;
+    Fr* a = (Fr*)ctx->d_scratch2;
+    Fr* b = a + n;
+    HIP_TRY(hipMemcpyAsync(a, v, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = plonk_ntt_dev(ctx, a, b, n, is_inv, is_coset))) return rc;
+    HIP_TRY(hipMemcpyAsync(v, b, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- transpose
+extern "C" int plonk_transpose_dev(plonk_ctx* ctx, const void* d_in, void* d_out, size_t rows, size_t cols) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_transpose_dev: null");
+    return transpose_fr((const Fr*)d_in, (Fr*)d_out, rows, cols, ctx->stream);
+}
+extern "C" int plonk_transpose(plonk_ctx* ctx, uint64_t* v, size_t rows, size_t cols) {
+    CHECK_CTX(ctx);
+    if (!v) return plonk_fail(PLONK_ERR_ARG, "plonk_transpose: null");
+    const size_t n = rows * cols;
+    if (n == 0) return PLONK_OK;
+    int rc = ensure_scratch2(ctx, 2 * n * 32);
+    if (rc) return rc;
+    Fr* a = (Fr*)ctx->d_scratch2;
+    Fr* b = a + n;
+    HIP_TRY(hipMemcpyAsync(a, v, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = transpose_fr(a, b, rows, cols, ctx->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(v, b, n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fftInit @2
+extern "C" int plonk_fft_init(plonk_ctx* ctx, uint64_t id, const plonk_fft_workload* wl, size_t n_wl, size_t me, int is_quot, int is_inv,
+                              int is_coset) {
+    CHECK_CTX(ctx);
+    if (!wl || n_wl == 0 || me >= n_wl) return plonk_fail(PLONK_ERR_ARG, "plonk_fft_init: bad workloads (n=%zu, me=%zu)", n_wl, me);
+    const size_t N = is_quot ? ctx->quot_domain_size : ctx->domain_size;
+    const int log_n = ilog2_exact(N);
+    if (N == 0 || log_n < 2) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_fft_init: %s domain of size %zu not initialised / too small", is_quot ? "quot" : "main", N);
+    FftTask t;
+    t.is_quot = is_quot; t.is_inv = is_inv; t.is_coset = is_coset;
+    t.wl.assign(wl, wl + n_wl);
+    t.me = me;
+    t.log_n = log_n;
+    t.r = (uint64_t)1 << (log_n >> 1);           // worker.rs:144
+    t.c = N / t.r;
+    t.nrows = wl[me].row_end - wl[me].row_start;
+    t.ncols = wl[me].col_end - wl[me].col_start;
+    // the all-to-all needs the reference's even contiguous partition (dispatcher2.rs:272-291)
+    for (size_t s = 0; s < n_wl; s++) {
+        if (wl[s].row_start != s * t.nrows || wl[s].row_end != (s + 1) * t.nrows || wl[s].col_start != s * t.ncols ||
+            wl[s].col_end != (s + 1) * t.ncols)
+            return plonk_fail(PLONK_ERR_ARG, "plonk_fft_init: workload %zu is not the even contiguous partition", s);
+    }
+    if (t.nrows * n_wl != t.r || t.ncols * n_wl != t.c || ilog2_exact(t.nrows) < 0 || ilog2_exact(t.ncols) < 0)
+        return plonk_fail(PLONK_ERR_ARG, "plonk_fft_init: %zu workers do not evenly split r=%llu, c=%llu", n_wl, (unsigned long long)t.r,
+                          (unsigned long long)t.c);
+    auto old = ctx->tasks.find(id);
+    if (old != ctx->tasks.end()) { free_task(old->second); ctx->tasks.erase(old); }   // HashMap::insert replaces
+    t.row_present.assign(t.nrows, 0);
+    ctx->tasks[id] = t;
+    return PLONK_OK;
+}
+
+static int get_task(plonk_ctx* ctx, uint64_t id, FftTask** out) {
+    auto it = ctx->tasks.find(id);
+    if (it == ctx->tasks.end()) return plonk_fail(PLONK_ERR_STATE, "unknown fft task id %llu", (unsigned long long)id);
+    *out = &it->second;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fft1 @3
+extern "C" int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_t* v, size_t len) {
+    CHECK_CTX(ctx);
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    if (!v || len != t->c) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1: row length %zu != c = %llu", len, (unsigned long long)t->c);
+    if (i >= t->nrows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1: local row %llu >= %llu", (unsigned long long)i, (unsigned long long)t->nrows);
+    if (t->prepared || t->rows_external) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1: rows already consumed");
+    if (!t->d_rows) HIP_TRY(hipMalloc((void**)&t->d_rows, t->nrows * t->c * 32));
+    HIP_TRY(hipMemcpyAsync(t->d_rows + i * t->c, v, t->c * 32, hipMemcpyHostToDevice, ctx->stream));
+    if (!t->row_present[i]) { t->row_present[i] = 1; t->rows_filled++; }
+    return PLONK_OK;
+}
+
+extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows) {
+    CHECK_CTX(ctx);
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    if (!d_rows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev: null");
+    if (t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1_dev: already prepared");
+    if (t->d_rows && !t->rows_external) hipFree(t->d_rows);
+    t->d_rows = (Fr*)const_cast<void*>(d_rows);
+    t->rows_external = true;
+    t->rows_filled = t->nrows;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fft2Prepare @4 (+ fftExchange)
+extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn exchange, void* user) {
+    CHECK_CTX(ctx);
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    if (t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft2_prepare: called twice");
+    if (t->rows_filled != t->nrows) return plonk_fail(PLONK_ERR_STATE, "plonk_fft2_prepare: %llu of %llu rows received", (unsigned long long)t->rows_filled,
+                                                      (unsigned long long)t->nrows);
+    const size_t S = t->wl.size();
+    if (S > 1 && !exchange) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu ranks need an exchange callback", S);
+    const size_t tile_bytes = t->nrows * t->c * 32;     // == r * ncols * 32
+    HIP_TRY(hipMalloc((void**)&t->d_send, tile_bytes));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    // row pass (fft1_helper, worker.rs:66-94) for all local rows, written straight into the
+    // per-peer blocks of the send buffer (the pack of worker.rs:327-330)
+    NttCall c;
+    c.in = t->d_rows;
+    c.out = t->d_send;
+    c.log_m = t->log_n - (t->log_n >> 1);
+    c.batch = t->nrows;
+    c.inverse = t->is_inv;
+    c.q_offset = t->wl[t->me].row_start;
+    if (t->is_coset && !t->is_inv) { c.pro.kind = 1; c.pro.aq = 1; c.pro.b0 = t->r; }   // g^(i + j*r)
+    c.epi.kind = t->is_inv ? 4 : 3;                                                      // w_N^(+-i*j)
+    c.epi.bq = 1;
+    c.epi.log_order = t->log_n;
+    c.split_log = ilog2_exact(t->ncols);
+    c.split_blk = t->nrows * t->ncols;
+    if ((rc = ntt_run(ctx->tables, c, ctx->stream))) return rc;
+    if (S > 1) {
+        HIP_TRY(hipMalloc((void**)&t->d_recv, tile_bytes));
+        const int xr = exchange(user, t->d_send, t->d_recv, t->nrows * t->ncols * 32, (int)S, (void*)ctx->stream);
+        if (xr) return plonk_fail(PLONK_ERR_EXCHANGE, "exchange callback returned %d", xr);
+    } else {
+        t->d_recv = t->d_send;
+    }
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    if (t->d_rows && !t->rows_external) { hipFree(t->d_rows); }     // task.rows = vec![] (worker.rs:341)
+    t->d_rows = nullptr;
+    t->prepared = true;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- fft2 @5
+static int fft2_common(plonk_ctx* ctx, uint64_t id, Fr* d_out, int layout) {
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    if (!t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft2: fft2_prepare has not run for this task");
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    // column pass (fft2_helper, worker.rs:96-115): the received blocks form an [r][ncols] matrix,
+    // so the scatter-transpose of worker.rs:432-435 is just a stride in the loads.
+    NttCall c;
+    c.in = t->d_recv;
+    c.out = d_out;
+    c.log_m = t->log_n >> 1;
+    c.batch = t->ncols;
+    c.layout = NTT_INTERLEAVED;
+    c.out_layout = layout == 0 ? NTT_CONTIGUOUS : NTT_INTERLEAVED;
+    c.inverse = t->is_inv;
+    c.q_offset = t->wl[t->me].col_start;
+    if (t->is_coset && t->is_inv) { c.epi.kind = 2; c.epi.aq = 1; c.epi.b0 = t->c; }     // g^-(i + j*c)
+    rc = ntt_run(ctx->tables, c, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
+}
+
+extern "C" int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layout) {
+    CHECK_CTX(ctx);
+    if (!d_out || (layout != 0 && layout != 1)) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_dev: bad argument");
+    int rc = fft2_common(ctx, id, (Fr*)d_out, layout);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto it = ctx->tasks.find(id);
+    free_task(it->second);
+    ctx->tasks.erase(it);                       // worker.rs:378
+    return PLONK_OK;
+}
+
+extern "C" int plonk_fft2(plonk_ctx* ctx, uint64_t id, uint64_t* out_cols) {
+    CHECK_CTX(ctx);
+    if (!out_cols) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2: null");
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    const size_t bytes = t->ncols * t->r * 32;
+    if ((rc = ensure_scratch2(ctx, bytes))) return rc;
+    if ((rc = fft2_common(ctx, id, (Fr*)ctx->d_scratch2, 0))) return rc;
+    HIP_TRY(hipMemcpyAsync(out_cols, ctx->d_scratch2, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    auto it = ctx->tasks.find(id);
+    free_task(it->second);
+    ctx->tasks.erase(it);
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- round1 @6
+extern "C" int plonk_round1(plonk_ctx* ctx, const uint64_t* evals, size_t n, const uint64_t* blinders, uint64_t* out_commit) {
+    CHECK_CTX(ctx);
+    if (!evals || !blinders || !out_commit) return plonk_fail(PLONK_ERR_ARG, "plonk_round1: null");
+    if (n != ctx->domain_size || n < 2) return plonk_fail(PLONK_ERR_ARG, "plonk_round1: %zu evaluations, domain is %zu", n, ctx->domain_size);
+    int rc = ensure_scratch2(ctx, (n + 2) * 32);
+    if (rc) return rc;
+    if (ctx->wire_len < n + 2) {
+        if (ctx->d_wire) hipFree(ctx->d_wire);
+        ctx->d_wire = nullptr; ctx->wire_len = 0;
+        HIP_TRY(hipMalloc((void**)&ctx->d_wire, (n + 2) * 32));
+        ctx->wire_len = n + 2;
+    }
+    Fr* tmp = (Fr*)ctx->d_scratch2;
+    Fr* d_bl = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_bl, 64));
+    HIP_TRY(hipMemcpyAsync(tmp, evals, n * 32, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_bl, blinders, 64, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_wire + n, 0, 64, ctx->stream));
+    {
+        NttCall c;
+        c.in = tmp; c.out = ctx->d_wire; c.log_m = ilog2_exact(n); c.batch = 1; c.inverse = true;     // worker.rs:398
+        rc = ntt_run(ctx->tables, c, ctx->stream);
+    }
+    if (!rc) rc = blind_add_dev(ctx->curve, ctx->d_wire, n, d_bl, ctx->stream);                        // worker.rs:400-401
+    if (!rc) rc = plonk_commit_dev(ctx, ctx->d_wire, n + 2, out_commit);                               // worker.rs:403-405
+    hipStreamSynchronize(ctx->stream);
+    hipFree(d_bl);
+    return rc;
+}
+
+extern "C" int plonk_get_wire(plonk_ctx* ctx, uint64_t* out, size_t n_coeffs) {
+    CHECK_CTX(ctx);
+    if (!out || n_coeffs > ctx->wire_len) return plonk_fail(PLONK_ERR_ARG, "plonk_get_wire: %zu > resident %zu", n_coeffs, ctx->wire_len);
+    HIP_TRY(hipMemcpyAsync(out, ctx->d_wire, n_coeffs * 32, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- memory / synth / debug
+extern "C" int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out) {
+    CHECK_CTX(ctx);
+    if (!out) return plonk_fail(PLONK_ERR_ARG, "plonk_dev_alloc: null");
+    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    return PLONK_OK;
+}
+extern "C" int plonk_dev_free(plonk_ctx* ctx, void* p) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(p));
+    return PLONK_OK;
+}
+extern "C" int plonk_memcpy_h2d(plonk_ctx* ctx, void* d, const void* h, size_t bytes) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+extern "C" int plonk_memcpy_d2h(plonk_ctx* ctx, void* h, const void* d, size_t bytes) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+extern "C" int plonk_memcpy_d2d(plonk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+extern "C" int plonk_profile_enable(plonk_ctx* ctx, int on) {
+    CHECK_CTX(ctx);
+    kernel_profiler().enabled = on != 0;
+    return PLONK_OK;
+}
+extern "C" int plonk_profile_reset(plonk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    kernel_profiler().reset();
+    return PLONK_OK;
+}
+extern "C" int plonk_profile_get(plonk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches) {
+    CHECK_CTX(ctx);
+    if (!name || !total_ms || !launches) return plonk_fail(PLONK_ERR_ARG, "plonk_profile_get: null");
+    kernel_profiler().resolve();
+    auto it = kernel_profiler().totals.find(name);
+    *total_ms = it == kernel_profiler().totals.end() ? 0.0 : it->second.first;
+    *launches = it == kernel_profiler().totals.end() ? 0 : it->second.second;
+    return PLONK_OK;
+}
+extern "C" int plonk_synth_fr(plonk_ctx* ctx, uint64_t seed, void* d_out, size_t n) {
+    CHECK_CTX(ctx);
+    if (!d_out && n) return plonk_fail(PLONK_ERR_ARG, "plonk_synth_fr: null");
+    return synth_fr_dev(ctx->curve, seed, (Fr*)d_out, n, ctx->stream);
+}
+extern "C" int plonk_synth_bases(plonk_ctx* ctx, uint64_t seed, size_t unique, size_t n, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_out && n) return plonk_fail(PLONK_ERR_ARG, "plonk_synth_bases: null");
+    if (unique == 0) return synth_bases_distinct_dev(ctx->curve, seed, n, d_out, ctx->stream);
+    return synth_bases_dev(ctx->curve, seed, unique, n, d_out, ctx->stream);
+}
+extern "C" int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    CHECK_CTX(ctx);
+    if (!a || !out) return plonk_fail(PLONK_ERR_ARG, "plonk_debug_field_op: null");
+    const size_t eb = (field == 1 && ctx->curve == PLONK_BLS12_381) ? 48 : 32;
+    int rc = ensure_scratch2(ctx, 3 * n * eb + 48);
+    if (rc) return rc;
+    char* base = (char*)ctx->d_scratch2;
+    HIP_TRY(hipMemcpyAsync(base, a, n * eb, hipMemcpyHostToDevice, ctx->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(base + n * eb, b, n * eb, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = field_op_dev(ctx->curve, field, op, base, b ? base + n * eb : nullptr, base + 2 * n * eb, n, ctx->stream))) return rc;
+    HIP_TRY(hipMemcpyAsync(out, base + 2 * n * eb, n * eb, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}

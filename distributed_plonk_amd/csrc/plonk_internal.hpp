@@ -1,0 +1,123 @@
+// plonk_internal.hpp — internal C++ interfaces behind the C ABI of include/plonk_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "fp.cuh"
+#include "../../include/plonk_hip.h"
+
+typedef Fp<8> Fr;
+typedef FpParams<8> FrParams;
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            snprintf(plonk_last_error_buf(), 512, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, \
+                     hipGetErrorString(_e));                                                   \
+            return PLONK_ERR_HIP;                                                              \
+        }                                                                                      \
+    } while (0)
+
+char* plonk_last_error_buf();
+int plonk_fail(int code, const char* fmt, ...);
+
+// ----------------------------------------------------------------------------------------------- per-kernel timing
+// HIP-event timing of individual kernel launches on the stream they are launched on (bench.py's
+// roofline leg).  Disabled by default (no events are created).
+struct KernelProfiler {
+    bool enabled = false;
+    struct Rec { const char* name; hipEvent_t a, b; };
+    std::vector<Rec> pending;
+    std::unordered_map<std::string, std::pair<double, uint64_t>> totals;   // name -> (ms, launches)
+    void resolve();
+    void reset();
+};
+KernelProfiler& kernel_profiler();
+struct ProfScope {       // RAII: brackets the launches issued in its lifetime
+    const char* name; hipStream_t stream; hipEvent_t a = nullptr, b = nullptr; bool on;
+    ProfScope(const char* n, hipStream_t s) : name(n), stream(s), on(kernel_profiler().enabled) {
+        if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, stream); }
+    }
+    ~ProfScope() {
+        if (on) { (void)hipEventRecord(b, stream); kernel_profiler().pending.push_back({name, a, b}); }
+    }
+};
+
+// ----------------------------------------------------------------------------------------------- NTT
+struct NttTables {
+    int curve = 0;
+    FrParams fp;
+    int two_adicity = 0;
+    int lt = 0;                       // two-level table split: 2^lt entries per level, 2*lt >= two_adicity
+    Fr* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
+    Fr* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
+    Fr* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
+    Fr* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e
+    Fr* g_hi[2] = {nullptr, nullptr};       // [0] g^(e<<lt) ...
+    std::unordered_map<int, Fr*> tw_lo_scaled;   // key = log_m (inverse only): w^-e * 2^-log_m
+    std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
+    Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
+};
+
+enum NttLayout { NTT_CONTIGUOUS = 0, NTT_INTERLEAVED = 1 };
+
+struct ScaleSpec {          // exponent = idx*(bq*q + b0) + (aq*q + a0)
+    int kind = 0;           // 0 none, 1 powers of g (coset), 2 powers of g^-1, 3 powers of w_N (fwd dir), 4 powers of w_N^-1
+    uint64_t aq = 0, a0 = 0, bq = 0, b0 = 0;
+    int log_order = 0;      // for kind 3/4: N = 2^log_order (exponent is scaled to the Nmax table)
+};
+
+struct NttCall {
+    const Fr* in = nullptr;   // destroyed when passes > 1
+    Fr* out = nullptr;        // must differ from `in` unless a single contiguous pass is used
+    int log_m = 0;            // transform size per array
+    uint64_t batch = 1;       // number of arrays
+    NttLayout layout = NTT_CONTIGUOUS;   // element (q,pos): contiguous q*M+pos ; interleaved pos*batch+q
+    bool inverse = false;     // w^-1 and 1/M scaling
+    ScaleSpec pro;            // applied to inputs (idx = position in array)
+    ScaleSpec epi;            // applied to outputs (idx = natural-order output index)
+    uint64_t q_offset = 0;    // added to q in both scale specs
+    int split_log = -1;       // output re-blocking for the all-to-all send buffer (see ntt_kernels.cuh)
+    uint64_t split_blk = 0;
+    NttLayout out_layout = NTT_CONTIGUOUS;
+};
+
+int ntt_tables_create(NttTables& T, int curve, hipStream_t stream);
+void ntt_tables_destroy(NttTables& T);
+int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream);
+bool ntt_single_pass_inplace_ok(const NttCall& c);
+std::vector<int> ntt_plan_widths(int log_m);
+
+int transpose_fr(const Fr* in, Fr* out, uint64_t rows, uint64_t cols, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- MSM
+struct MsmWorkspace {
+    void* d_buf = nullptr;
+    size_t bytes = 0;
+};
+struct MsmConfig {
+    int curve;
+    int window_bits;     // 0 = auto
+};
+// bases: device, compact x||y Montgomery (2*Q u32-limb field elements), infinity encoded as all-zero.
+// scalars: device, canonical 8xu32.  out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
+int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac,
+            MsmWorkspace& ws, int window_bits, hipStream_t stream);
+int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);
+int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf);
+int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream);
+
+// elementwise helpers (device pointers)
+int fr_from_mont_dev(int curve, const Fr* in, Fr* out, size_t n, hipStream_t stream);
+int field_op_dev(int curve, int field, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream);
+int synth_fr_dev(int curve, uint64_t seed, Fr* out, size_t n, hipStream_t stream);
+int synth_bases_dev(int curve, uint64_t seed, size_t unique, size_t n, void* d_out, hipStream_t stream);
+int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hipStream_t stream);
+int blind_add_dev(int curve, Fr* poly, size_t n, const Fr* d_blind2, hipStream_t stream);
+
+const FrParams& fr_params(int curve);

@@ -1,0 +1,219 @@
+// synth.hip — small element-wise device kernels around the hot path:
+//   * into_repr over a coefficient vector (commit_polynomial, worker.rs:118)
+//   * blinding add (worker.rs:400-401)
+//   * element-wise field ops for pinning the arithmetic layer against the oracle
+//   * seeded synthetic inputs (the reference draws from thread_rng: dispatcher.rs:187-200):
+//     uniform Fr, and SRS-like G1 bases (k_j*G tiled, or pairwise-distinct sums A_i + B_j)
+#include "constants.h"
+#include "ec.cuh"
+#include "plonk_internal.hpp"
+
+template <int N> static const FpParams<N>& field_params(int curve, int field);
+template <> const FpParams<8>& field_params<8>(int curve, int field) {
+    if (field == 0) return curve == PLONK_BN254 ? BN254_FR_PARAMS : BLS12_381_FR_PARAMS;
+    return BN254_FQ_PARAMS;
+}
+template <> const FpParams<12>& field_params<12>(int, int) { return BLS12_381_FQ_PARAMS; }
+
+template <typename T> __device__ __forceinline__ T ld16(const T* p) {
+    T r;
+    const uint4* s = reinterpret_cast<const uint4*>(p);
+    uint4* d = reinterpret_cast<uint4*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+    return r;
+}
+template <typename T> __device__ __forceinline__ void st16(T* p, const T& v) {
+    uint4* d = reinterpret_cast<uint4*>(p);
+    const uint4* s = reinterpret_cast<const uint4*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
+}
+
+// ---------------------------------------------------------------------------------------------- field ops
+template <int N>
+__global__ void __launch_bounds__(256) field_op_kernel(int op, const Fp<N>* __restrict__ a, const Fp<N>* __restrict__ b, Fp<N>* __restrict__ out,
+                                                       uint64_t n, const FpParams<N> P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Fp<N> x = ld16(a + i), y = b ? ld16(b + i) : x, r;
+    switch (op) {
+        case 0: r = fp_mul(x, y, P); break;
+        case 1: r = fp_add(x, y, P); break;
+        case 2: r = fp_sub(x, y, P); break;
+        case 3: r = fp_to_mont(x, P); break;
+        case 4: r = fp_from_mont(x, P); break;
+        case 5: r = fp_inv(x, P); break;
+        default: r = fp_sqr(x, P); break;
+    }
+    st16(out + i, r);
+}
+
+int field_op_dev(int curve, int field, int op, const void* a, const void* b, void* out, size_t n, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    if (op < 0 || op > 6) return plonk_fail(PLONK_ERR_ARG, "field op %d", op);
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (field == 1 && curve == PLONK_BLS12_381)
+        hipLaunchKernelGGL(field_op_kernel<12>, dim3(grid), dim3(256), 0, stream, op, (const Fp<12>*)a, (const Fp<12>*)b, (Fp<12>*)out, (uint64_t)n,
+                           field_params<12>(curve, field));
+    else
+        hipLaunchKernelGGL(field_op_kernel<8>, dim3(grid), dim3(256), 0, stream, op, (const Fp<8>*)a, (const Fp<8>*)b, (Fp<8>*)out, (uint64_t)n,
+                           field_params<8>(curve, field));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "field_op launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+int fr_from_mont_dev(int curve, const Fr* in, Fr* out, size_t n, hipStream_t stream) {
+    return field_op_dev(curve, 0, 4, in, nullptr, out, n, stream);
+}
+
+// poly[0..1] -= b ; poly[n..n+1] += b   ((b0 + b1 X)(X^n - 1) + poly), worker.rs:400-401
+__global__ void blind_add_kernel(Fr* poly, uint64_t n, const Fr* blind2, const FrParams P) {
+    const int i = threadIdx.x;
+    if (i < 2) {
+        Fr b = ld16(blind2 + i);
+        st16(poly + i, fp_sub(ld16(poly + i), b, P));
+        st16(poly + n + i, fp_add(ld16(poly + n + i), b, P));
+    }
+}
+int blind_add_dev(int curve, Fr* poly, size_t n, const Fr* d_blind2, hipStream_t stream) {
+    hipLaunchKernelGGL(blind_add_kernel, dim3(1), dim3(64), 0, stream, poly, (uint64_t)n, d_blind2, fr_params(curve));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "blind_add launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- synthetic Fr
+__device__ __forceinline__ uint64_t splitmix64(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Fp::rand of ark-ff 0.3.0: draw limbs, mask the top REPR_SHAVE_BITS, accept if < p; the accepted
+// raw limbs are the Montgomery representation.  Element i has its own stream (seed, i).
+__device__ __forceinline__ Fr rand_fr_elem(uint64_t seed, uint64_t i, const FrParams& P) {
+    uint64_t s = seed ^ (0xD1B54A32D192ED03ull * (i + 1));
+    const int shave = 256 - P.bits;
+    Fr r;
+    for (;;) {
+        uint64_t l[4];
+        for (int k = 0; k < 4; k++) l[k] = splitmix64(s);
+        l[3] &= (~0ull) >> shave;
+#pragma unroll
+        for (int k = 0; k < 4; k++) { r.l[2 * k] = (uint32_t)l[k]; r.l[2 * k + 1] = (uint32_t)(l[k] >> 32); }
+        // accept if r < p
+        uint64_t br = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { uint64_t t = (uint64_t)r.l[k] - P.p[k] - br; br = (t >> 32) & 1; }
+        if (br) break;
+    }
+    return r;
+}
+
+__global__ void __launch_bounds__(256) synth_fr_kernel(uint64_t seed, Fr* __restrict__ out, uint64_t n, const FrParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st16(out + i, rand_fr_elem(seed, i, P));
+}
+
+int synth_fr_dev(int curve, uint64_t seed, Fr* out, size_t n, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    hipLaunchKernelGGL(synth_fr_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, seed, out, (uint64_t)n, fr_params(curve));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_fr launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- synthetic bases
+// P_j = k_j * G with k_j = the raw limbs of rand_fr(seed)[j] (same rule as oracle orc_gen_bases)
+template <int NQ>
+__global__ void __launch_bounds__(64) synth_points_kernel(uint64_t seed, uint64_t count, AffPt<NQ>* __restrict__ out, const AffPt<NQ> G,
+                                                          const FrParams FR, const FpParams<NQ> P) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= count) return;
+    const Fr k = rand_fr_elem(seed, j, FR);
+    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    for (int i = 255; i >= 0; i--) {
+        acc = xyzz_dbl_cold(acc, P);
+        if ((k.l[i >> 5] >> (i & 31)) & 1) acc = xyzz_madd_cold(acc, G, P);
+    }
+    st16(out + j, xyzz_to_affine(acc, P));
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) synth_tile_kernel(AffPt<NQ>* __restrict__ pts, uint64_t unique, uint64_t n) {
+    const uint64_t i = unique + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    st16(pts + i, ld16(pts + (i % unique)));
+}
+
+// P_i = A[i % na] + B[i / na]
+template <int NQ>
+__global__ void __launch_bounds__(128) synth_sum_kernel(const AffPt<NQ>* __restrict__ A, uint64_t na, const AffPt<NQ>* __restrict__ B,
+                                                        AffPt<NQ>* __restrict__ out, uint64_t n, const FpParams<NQ> P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    XyzzPt<NQ> a = xyzz_from_affine(ld16(A + (i % na)), P);
+    a = xyzz_madd_cold(a, ld16(B + (i / na)), P);
+    st16(out + i, xyzz_to_affine(a, P));
+}
+
+template <int NQ> static AffPt<NQ> generator_affine(int curve);
+template <> AffPt<8> generator_affine<8>(int) {
+    AffPt<8> g;
+    g.x = fp_from_limbs<8>(BN254_G1_GX_MONT); g.y = fp_from_limbs<8>(BN254_G1_GY_MONT);
+    return g;
+}
+template <> AffPt<12> generator_affine<12>(int) {
+    AffPt<12> g;
+    g.x = fp_from_limbs<12>(BLS12_381_G1_GX_MONT); g.y = fp_from_limbs<12>(BLS12_381_G1_GY_MONT);
+    return g;
+}
+
+template <int NQ>
+static int synth_bases_t(int curve, uint64_t seed, size_t unique, size_t n, void* d_out, hipStream_t stream) {
+    const FpParams<NQ>& P = field_params<NQ>(curve, 1);
+    AffPt<NQ>* out = (AffPt<NQ>*)d_out;
+    if (unique > n) unique = n;
+    hipLaunchKernelGGL(synth_points_kernel<NQ>, dim3((uint32_t)((unique + 63) / 64)), dim3(64), 0, stream, seed, (uint64_t)unique, out,
+                       generator_affine<NQ>(curve), fr_params(curve), P);
+    if (n > unique)
+        hipLaunchKernelGGL(synth_tile_kernel<NQ>, dim3((uint32_t)((n - unique + 255) / 256)), dim3(256), 0, stream, out, (uint64_t)unique, (uint64_t)n);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_bases launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+int synth_bases_dev(int curve, uint64_t seed, size_t unique, size_t n, void* d_out, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    if (curve == PLONK_BN254) return synth_bases_t<8>(curve, seed, unique, n, d_out, stream);
+    return synth_bases_t<12>(curve, seed, unique, n, d_out, stream);
+}
+
+template <int NQ>
+static int synth_distinct_t(int curve, uint64_t seed, size_t n, void* d_out, hipStream_t stream) {
+    const FpParams<NQ>& P = field_params<NQ>(curve, 1);
+    const size_t na = 4096, nbb = (n + na - 1) / na;
+    AffPt<NQ>* tmp = nullptr;
+    HIP_TRY(hipMalloc((void**)&tmp, (na + nbb) * sizeof(AffPt<NQ>)));
+    int rc = synth_bases_t<NQ>(curve, seed, na, na, tmp, stream);
+    if (!rc) rc = synth_bases_t<NQ>(curve, seed + 1, nbb, nbb, tmp + na, stream);
+    if (!rc) {
+        hipLaunchKernelGGL(synth_sum_kernel<NQ>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, stream, tmp, (uint64_t)na, tmp + na,
+                           (AffPt<NQ>*)d_out, (uint64_t)n, P);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) rc = plonk_fail(PLONK_ERR_HIP, "synth_sum launch: %s", hipGetErrorString(e));
+    }
+    hipStreamSynchronize(stream);
+    hipFree(tmp);
+    return rc;
+}
+
+int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    if (curve == PLONK_BN254) return synth_distinct_t<8>(curve, seed, n, d_out, stream);
+    return synth_distinct_t<12>(curve, seed, n, d_out, stream);
+}

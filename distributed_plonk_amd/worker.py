@@ -1,0 +1,249 @@
+"""Host-side mirror of the reference worker (`impl plonk_slave::Server for PlonkImpl`,
+/root/reference/src/worker.rs:125-439) on top of the C ABI: same method names, argument meaning and
+call order as the Cap'n Proto interface (src/hello_world.capnp:16-24,49-50); the work runs in
+libplonk_hip.so on one MI355X.  numpy arrays are uint64 limbs in the reference's raw layouts
+(src/utils.rs:27-43).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, Optional, Sequence
+
+import numpy as np
+
+from . import _ffi
+from ._ffi import FftWorkload, MsmWorkload, PlonkError, check  # noqa: F401
+
+
+def _u64(a) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+def _ptr(a: Optional[np.ndarray]):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class DeviceBuffer:
+    """A piece of HBM owned through the C ABI (plonk_dev_alloc)."""
+
+    def __init__(self, worker: "PlonkWorker", nbytes: int):
+        self.worker, self.nbytes = worker, nbytes
+        p = C.c_void_p()
+        check(worker.lib.plonk_dev_alloc(worker.ctx, nbytes, C.byref(p)))
+        self.ptr = p.value
+
+    def offset(self, nbytes: int) -> int:
+        return self.ptr + nbytes
+
+    def upload(self, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        assert arr.nbytes <= self.nbytes
+        check(self.worker.lib.plonk_memcpy_h2d(self.worker.ctx, self.ptr, _ptr(arr), arr.nbytes))
+        return self
+
+    def download(self, shape, dtype=np.uint64, byte_offset: int = 0) -> np.ndarray:
+        out = np.empty(shape, dtype=dtype)
+        check(self.worker.lib.plonk_memcpy_d2h(self.worker.ctx, _ptr(out), self.ptr + byte_offset, out.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            check(self.worker.lib.plonk_dev_free(self.worker.ctx, self.ptr))
+            self.ptr = None
+
+    def __cuda_array_interface_for__(self, nbytes=None):
+        return {"shape": ((nbytes or self.nbytes) // 8,), "typestr": "<i8", "data": (self.ptr, False), "version": 2}
+
+
+class PlonkWorker:
+    """One worker = one GPU context (reference `State`, worker.rs:42-59)."""
+
+    def __init__(self, me: int = 0, device: int = 0, curve: str = "bn254"):
+        self.lib = _ffi.lib()
+        self.me = me
+        self.curve_name = curve
+        self.curve = _ffi.CURVES[curve]
+        self.q64 = _ffi.FQ_LIMBS64[self.curve]
+        ctx = C.c_void_p()
+        check(self.lib.plonk_create(C.byref(ctx), device, self.curve))
+        self.ctx = ctx
+        self._tasks = {}
+        self._keepalive = []
+
+    def close(self):
+        if self.ctx:
+            self.lib.plonk_destroy(self.ctx)
+            self.ctx = None
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ PlonkSlave @0
+    def init(self, bases: Optional[np.ndarray], domain_size: int, quot_domain_size: int, layout=_ffi.PLONK_BASES_XY):
+        """worker.rs:126-157.  bases: (n, 2*Q) x||y Montgomery limbs, or raw ark bytes for PLONK_BASES_ARK."""
+        if bases is None or len(bases) == 0:
+            check(self.lib.plonk_init(self.ctx, None, 0, layout, domain_size, quot_domain_size))
+            return
+        if layout == _ffi.PLONK_BASES_XY:
+            b = _u64(bases)
+            n = b.shape[0]
+        else:
+            b = np.ascontiguousarray(bases, dtype=np.uint8)
+            n = b.size // (16 * self.q64 + 8)
+        check(self.lib.plonk_init(self.ctx, _ptr(b), n, layout, domain_size, quot_domain_size))
+
+    def init_dev(self, d_bases_ptr: int, n_bases: int, domain_size: int, quot_domain_size: int):
+        check(self.lib.plonk_init_dev(self.ctx, d_bases_ptr, n_bases, domain_size, quot_domain_size))
+
+    # ------------------------------------------------------------------ PlonkSlave @1
+    def var_msm(self, workload: MsmWorkload, scalars: np.ndarray) -> np.ndarray:
+        """worker.rs:159-185 -> raw Jacobian (3*Q u64)."""
+        s = _u64(scalars)
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_var_msm(self.ctx, C.byref(workload), _ptr(s), s.shape[0], _ptr(out)))
+        return out
+
+    def msm_dev(self, start: int, end: int, d_scalars_ptr: int) -> np.ndarray:
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_msm_dev(self.ctx, start, end, d_scalars_ptr, _ptr(out)))
+        return out
+
+    def commit(self, coeffs_mont: np.ndarray) -> np.ndarray:
+        """commit_polynomial, worker.rs:117-123."""
+        c = _u64(coeffs_mont)
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_commit(self.ctx, _ptr(c), c.shape[0], _ptr(out)))
+        return out
+
+    def commit_dev(self, d_coeffs_ptr: int, n_coeffs: int) -> np.ndarray:
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_commit_dev(self.ctx, d_coeffs_ptr, n_coeffs, _ptr(out)))
+        return out
+
+    # ------------------------------------------------------------------ PlonkSlave @2..@5
+    def fft_init(self, id: int, workloads: Sequence[FftWorkload], is_quot: bool, is_inv: bool, is_coset: bool):
+        arr = (FftWorkload * len(workloads))(*workloads)
+        check(self.lib.plonk_fft_init(self.ctx, id, arr, len(workloads), self.me, int(is_quot), int(is_inv), int(is_coset)))
+        self._tasks[id] = (workloads[self.me].num_rows(), workloads[self.me].num_cols(), is_quot)
+
+    def fft1(self, id: int, i: int, v: np.ndarray):
+        v = _u64(v)
+        check(self.lib.plonk_fft1(self.ctx, id, i, _ptr(v), v.shape[0]))
+
+    def fft1_dev(self, id: int, d_rows_ptr: int):
+        check(self.lib.plonk_fft1_dev(self.ctx, id, d_rows_ptr))
+
+    def fft2_prepare(self, id: int, exchange: Optional[Callable] = None):
+        """exchange(send_ptr, recv_ptr, bytes_per_peer, n_ranks, stream_ptr) -> int (0 = ok)."""
+        if exchange is None:
+            cb = C.cast(None, _ffi.EXCHANGE_FN)
+        else:
+            def _tramp(user, send, recv, nbytes, n_ranks, stream):
+                try:
+                    return int(exchange(send, recv, nbytes, n_ranks, stream) or 0)
+                except Exception as e:  # never unwind through C
+                    self._last_exchange_error = e
+                    return 1
+            cb = _ffi.EXCHANGE_FN(_tramp)
+            self._keepalive.append(cb)
+        try:
+            check(self.lib.plonk_fft2_prepare(self.ctx, id, cb, None))
+        finally:
+            self._keepalive.clear()
+
+    def fft2(self, id: int, r: int) -> np.ndarray:
+        """-> (num_cols, r, 4): the reply of worker.rs:366-376."""
+        _, ncols, _ = self._tasks.pop(id)
+        out = np.empty((ncols, r, 4), dtype=np.uint64)
+        check(self.lib.plonk_fft2(self.ctx, id, _ptr(out)))
+        return out
+
+    def fft2_dev(self, id: int, d_out_ptr: int, layout: int = 1):
+        self._tasks.pop(id, None)
+        check(self.lib.plonk_fft2_dev(self.ctx, id, d_out_ptr, layout))
+
+    # ------------------------------------------------------------------ PlonkSlave @6
+    def round1(self, evals: np.ndarray, blinders: np.ndarray) -> np.ndarray:
+        e, b = _u64(evals), _u64(blinders)
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_round1(self.ctx, _ptr(e), e.shape[0], _ptr(b), _ptr(out)))
+        return out
+
+    def get_wire(self, n_coeffs: int) -> np.ndarray:
+        out = np.empty((n_coeffs, 4), dtype=np.uint64)
+        check(self.lib.plonk_get_wire(self.ctx, _ptr(out), n_coeffs))
+        return out
+
+    # ------------------------------------------------------------------ operator boundary
+    def ntt(self, v: np.ndarray, is_inv=False, is_coset=False) -> np.ndarray:
+        """Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place on a host vector."""
+        v = _u64(v).copy()
+        check(self.lib.plonk_ntt(self.ctx, _ptr(v), v.shape[0], int(is_inv), int(is_coset)))
+        return v
+
+    def ntt_dev(self, d_in: int, d_out: int, n: int, is_inv=False, is_coset=False):
+        check(self.lib.plonk_ntt_dev(self.ctx, d_in, d_out, n, int(is_inv), int(is_coset)))
+
+    def transpose(self, v: np.ndarray, rows: int, cols: int) -> np.ndarray:
+        v = _u64(v).copy()
+        check(self.lib.plonk_transpose(self.ctx, _ptr(v), rows, cols))
+        return v
+
+    def g1_add(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_g1_add(self.curve, _ptr(_u64(a)), _ptr(_u64(b)), _ptr(out)))
+        return out
+
+    def g1_to_affine(self, jac: np.ndarray):
+        out = np.zeros(2 * self.q64, dtype=np.uint64)
+        inf = C.c_int(0)
+        check(self.lib.plonk_g1_to_affine(self.curve, _ptr(_u64(jac)), _ptr(out), C.byref(inf)))
+        return out, bool(inf.value)
+
+    # ------------------------------------------------------------------ device memory, synthetic inputs, debug
+    def alloc(self, nbytes: int) -> DeviceBuffer:
+        return DeviceBuffer(self, nbytes)
+
+    def memcpy_d2d(self, dst: int, src: int, nbytes: int):
+        check(self.lib.plonk_memcpy_d2d(self.ctx, dst, src, nbytes))
+
+    def synth_fr(self, seed: int, d_out: int, n: int):
+        check(self.lib.plonk_synth_fr(self.ctx, seed, d_out, n))
+
+    def synth_bases(self, seed: int, unique: int, n: int, d_out: int):
+        check(self.lib.plonk_synth_bases(self.ctx, seed, unique, n, d_out))
+
+    def field_op(self, field: int, op: int, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
+        a = _u64(a)
+        b = _u64(b) if b is not None else None
+        out = np.empty_like(a)
+        check(self.lib.plonk_debug_field_op(self.ctx, field, op, _ptr(a), _ptr(b), _ptr(out), a.shape[0]))
+        return out
+
+    def set_option(self, key: str, value: int):
+        check(self.lib.plonk_set_option(self.ctx, key.encode(), value))
+
+    def sync(self):
+        check(self.lib.plonk_sync(self.ctx))
+
+    def stream_ptr(self) -> int:
+        return self.lib.plonk_stream(self.ctx)
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double(0)
+        check(self.lib.plonk_last_kernel_ms(self.ctx, C.byref(ms)))
+        return ms.value
+
+    def profile_enable(self, on: bool):
+        check(self.lib.plonk_profile_enable(self.ctx, int(on)))
+
+    def profile_reset(self):
+        check(self.lib.plonk_profile_reset(self.ctx))
+
+    def profile_get(self, name: str):
+        ms, n = C.c_double(0), C.c_uint64(0)
+        check(self.lib.plonk_profile_get(self.ctx, name.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value

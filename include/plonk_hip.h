@@ -1,0 +1,166 @@
+/* plonk_hip.h — C ABI of the MI355X-native MSM + NTT hot path (libplonk_hip.so).
+ *
+ * Drop-in boundary for MengLing-L/distributed_plonk's worker: one entry point per Cap'n Proto method
+ * of `interface PlonkSlave` @0..@6 and `interface PlonkPeer` @0 (reference
+ * src/hello_world.capnp:16-24,49-50; server src/worker.rs:125-439; clients src/dispatcher.rs:50-175,
+ * src/dispatcher2.rs:961-1086), plus the three third-party operator calls the worker makes
+ * (VariableBaseMSM::multi_scalar_mul, Radix2EvaluationDomain::{fft,ifft}_in_place, Fr::pow loops).
+ * Plain pointers and sizes only; the caller owns every host buffer; the library owns device memory
+ * inside the context.  INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
+ *
+ * Byte layouts are the reference's raw memory layouts (src/utils.rs:27-43):
+ *   Fr            4 x u64 little-endian, Montgomery form (R = 2^256), fully reduced
+ *   MSM scalar    4 x u64 little-endian, canonical (`into_repr()`)
+ *   Fq            4 x u64 (BN254) / 6 x u64 (BLS12-381), Montgomery
+ *   G1 projective X || Y || Z (Jacobian, Montgomery), infinity = Z == 0
+ *   G1 affine     PLONK_BASES_XY: x || y, infinity encoded as x = y = 0 (not on either curve)
+ *                 PLONK_BASES_ARK: arkworks' in-memory `GroupAffine {x, y, infinity: bool}` with the
+ *                 struct padded to 8 bytes (72 B BN254 / 104 B BLS12-381) — what `init` puts on the wire
+ *
+ * Every function returns 0 (PLONK_OK) or a negative error code; nothing throws across the boundary.
+ * The reference panics (`.unwrap()`) on malformed input (worker.rs:131,253,303); here ranges, sizes
+ * and domain two-adicity are validated and reported.  A context is bound to one GPU and is not
+ * thread-safe (the reference worker is a single-threaded tokio LocalSet, worker.rs:441-448).
+ */
+#ifndef PLONK_HIP_H
+#define PLONK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct plonk_ctx plonk_ctx;
+
+enum { PLONK_BN254 = 0, PLONK_BLS12_381 = 1 };
+enum { PLONK_BASES_XY = 0, PLONK_BASES_ARK = 1 };
+enum {
+    PLONK_OK = 0,
+    PLONK_ERR_ARG = -1,       /* bad argument (range, size, null) */
+    PLONK_ERR_DOMAIN = -2,    /* DomainCreationError: log2(size) > two-adicity, or not a power of two */
+    PLONK_ERR_HIP = -3,       /* HIP runtime error (no device, out of memory, launch failure) */
+    PLONK_ERR_STATE = -4,     /* call order violated (unknown task id, rows missing, ...) */
+    PLONK_ERR_EXCHANGE = -5   /* the exchange callback failed */
+};
+
+/* src/utils.rs:3-8 / hello_world.capnp:8-13 */
+typedef struct { uint64_t row_start, row_end, col_start, col_end; } plonk_fft_workload;
+/* src/utils.rs:21-25 / hello_world.capnp:3-6 */
+typedef struct { uint64_t start, end; } plonk_msm_workload;
+
+/* Worker<->worker transport for fft2Prepare (replaces the per-exchange TCP + Cap'n Proto
+ * connections of worker.rs:303-338).  Called once per fft2_prepare with device pointers:
+ * `send` holds n_ranks blocks of `bytes_per_peer` bytes (block p goes to rank p), `recv` receives
+ * n_ranks blocks (block p came from rank p).  `stream` is the hipStream_t the buffers are ordered on.
+ * An RCCL all-to-all (ncclSend/ncclRecv group, or torch.distributed.all_to_all_single) implements it.
+ * Return 0 on success. */
+typedef int (*plonk_exchange_fn)(void* user, const void* send, void* recv, size_t bytes_per_peer,
+                                 int n_ranks, void* stream);
+
+/* ---- lifetime ------------------------------------------------------------------------------- */
+/* State::new, worker.rs:455-472. */
+int plonk_create(plonk_ctx** out, int device, int curve);
+void plonk_destroy(plonk_ctx* ctx);
+const char* plonk_last_error(void);
+/* HIP stream all work of this context is ordered on (for callers that share device buffers). */
+void* plonk_stream(plonk_ctx* ctx);
+int plonk_sync(plonk_ctx* ctx);
+
+/* ---- PlonkSlave @0 init — worker.rs:126-157, client dispatcher.rs:50-68 ----------------------
+ * Stores the SRS bases on the device and fixes the two evaluation domains (n and the quotient
+ * domain m); either size may be 0 (dispatcher.rs:215 passes 0,0 for the MSM test). */
+int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int base_layout,
+               size_t domain_size, size_t quot_domain_size);
+
+/* ---- PlonkSlave @1 varMsm — worker.rs:159-185, client dispatcher.rs:70-92 --------------------
+ * out_jacobian = sum_i scalars[i] * bases[start + i], i < min(end - start, n_scalars). */
+int plonk_var_msm(plonk_ctx* ctx, const plonk_msm_workload* workload, const uint64_t* scalars,
+                  size_t n_scalars, uint64_t* out_jacobian);
+
+/* ---- PlonkSlave @2 fftInit — worker.rs:187-233 ----------------------------------------------- */
+int plonk_fft_init(plonk_ctx* ctx, uint64_t id, const plonk_fft_workload* workloads, size_t n_workloads,
+                   size_t me, int is_quot, int is_inv, int is_coset);
+/* ---- PlonkSlave @3 fft1 — worker.rs:235-278 (helper :66-94).  One decimated row of c elements;
+ * i is the LOCAL row index (global row = i + workloads[me].row_start, worker.rs:267). */
+int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_t* v, size_t len);
+/* ---- PlonkSlave @4 fft2Prepare + PlonkPeer @0 fftExchange — worker.rs:280-345, 412-438 --------
+ * Row pass on every local row, then the all-to-all block transpose.  Collective: every rank calls
+ * it for the same id.  exchange may be NULL when n_workloads == 1. */
+int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn exchange, void* user);
+/* ---- PlonkSlave @5 fft2 — worker.rs:347-381 (helper :96-115).  out_cols receives num_cols
+ * columns of r elements each (column-major blobs, as the reply of worker.rs:366-376); the task is
+ * removed (worker.rs:378). */
+int plonk_fft2(plonk_ctx* ctx, uint64_t id, uint64_t* out_cols);
+/* ---- PlonkSlave @6 round1 — worker.rs:383-408.  evals: n = domain_size Fr; blinders: the two
+ * coefficients (b0, b1) of the degree-1 blinding polynomial the reference draws from thread_rng
+ * (worker.rs:400), supplied explicitly so results are reproducible.  The blinded polynomial
+ * (n + 2 coefficients) stays resident (`state.wire`, worker.rs:58); its commitment is returned. */
+int plonk_round1(plonk_ctx* ctx, const uint64_t* evals, size_t n, const uint64_t* blinders,
+                 uint64_t* out_commit_jacobian);
+int plonk_get_wire(plonk_ctx* ctx, uint64_t* out_coeffs, size_t n_coeffs);
+
+/* ---- third-party operator boundary (ark-poly / ark-ec calls the worker makes) ----------------
+ * Whole-vector transform, dispatcher.rs:594,632,667 / dispatcher2.rs:507: host buffer of n = 2^k
+ * Fr transformed in place ({fft,ifft,coset_fft,coset_ifft}_in_place). */
+int plonk_ntt(plonk_ctx* ctx, uint64_t* v, size_t n, int is_inv, int is_coset);
+/* commit_polynomial, worker.rs:117-123 / dispatcher2.rs:835-893: Montgomery coefficients ->
+ * into_repr -> zero-pad to the SRS -> MSM.  Host buffers. */
+int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian);
+/* G1Projective addition / normalisation used by the dispatcher's reduce (dispatcher.rs:236-238) and
+ * `Commitment(commitment.into())` (dispatcher2.rs:892).  Host-side, tiny. */
+int plonk_g1_add(int curve, const uint64_t* a_jac, const uint64_t* b_jac, uint64_t* out_jac);
+int plonk_g1_to_affine(int curve, const uint64_t* jac, uint64_t* out_xy, int* is_infinity);
+/* ip_transpose, transpose.rs:413 (rows x cols -> cols x rows of Fr), host buffer. */
+int plonk_transpose(plonk_ctx* ctx, uint64_t* v, size_t rows, size_t cols);
+
+/* ---- device-resident variants (no host staging; pointers are HBM addresses on ctx's device) ---
+ * d_in is used as workspace and destroyed unless d_in == d_out (then an internal scratch is used). */
+int plonk_ntt_dev(plonk_ctx* ctx, void* d_in, void* d_out, size_t n, int is_inv, int is_coset);
+int plonk_msm_dev(plonk_ctx* ctx, size_t start, size_t end, const void* d_scalars, uint64_t* out_jacobian);
+int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian);
+/* All local rows at once, row-major [num_rows][c] in HBM (replaces num_rows fft1 calls). */
+int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows);
+/* Result of fft2 left in HBM.  layout 0: [num_cols][r] (the reference's reply); layout 1:
+ * [r][num_cols] (natural order restricted to this rank's columns: element (j, i) = X[(i + col_start) + j*c]). */
+int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layout);
+int plonk_transpose_dev(plonk_ctx* ctx, const void* d_in, void* d_out, size_t rows, size_t cols);
+
+/* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
+int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
+int plonk_dev_free(plonk_ctx* ctx, void* p);
+int plonk_memcpy_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int plonk_memcpy_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+int plonk_memcpy_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+/* n uniform Fr (Montgomery limbs drawn like ark-ff's Fp::rand: mask + rejection), element i from
+ * stream (seed, i). */
+int plonk_synth_fr(plonk_ctx* ctx, uint64_t seed, void* d_out, size_t n);
+/* SRS-like bases in PLONK_BASES_XY layout.  unique > 0: `unique` points k_j*G tiled to n (the
+ * distribution of dispatcher.rs:190-196); unique == 0: n pairwise-distinct points A[i%4096] + B[i/4096]. */
+int plonk_synth_bases(plonk_ctx* ctx, uint64_t seed, size_t unique, size_t n, void* d_out);
+/* Use n_bases points already in HBM (PLONK_BASES_XY) as the SRS without a host round trip. */
+int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size,
+                   size_t quot_domain_size);
+/* element-wise field ops on the device, for pinning the arithmetic layer.
+ * field: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont, 5 inverse, 6 square.  Host buffers. */
+int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
+                         uint64_t* out, size_t n);
+/* tuning knobs: key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 10). */
+int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
+/* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP
+ * events on the context's stream (milliseconds). */
+int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms);
+
+/* Per-kernel timing with HIP events recorded on the context's stream around every kernel launch
+ * (off by default).  Names: "ntt_pass_kernel", "ntt_pass_kernel<9>" (per in-LDS size),
+ * "msm_count_kernel", "msm_scan", "msm_scatter_kernel", "msm_accumulate_kernel",
+ * "msm_reduce_chunks_kernel", "msm_window_sum_kernel".  total_ms / launches accumulate until reset. */
+int plonk_profile_enable(plonk_ctx* ctx, int on);
+int plonk_profile_reset(plonk_ctx* ctx);
+int plonk_profile_get(plonk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLONK_HIP_H */

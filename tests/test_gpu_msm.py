@@ -1,0 +1,109 @@
+"""MSM (varMsm / commit_polynomial / round1) vs the oracle, compared in affine form
+(a Jacobian triple is not unique — SURVEY fact 7)."""
+import numpy as np
+import pytest
+
+from distributed_plonk_amd._ffi import MsmWorkload
+
+pytestmark = pytest.mark.gpu
+
+
+def _affine_eq(w, oracle, cid, got_jac, want_jac):
+    g, gi = w.g1_to_affine(got_jac)
+    o, oi = oracle.jac_to_affine(cid, want_jac)
+    return gi == oi and np.array_equal(g, o)
+
+
+def _bases_with_inf(oracle, cid, bases, inf_idx):
+    b = bases.copy()
+    inf = np.zeros(len(b), dtype=np.uint8)
+    for i in inf_idx:
+        b[i] = 0
+        inf[i] = 1
+    return b, inf
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("n", [1, 5, 40, 1000, 1 << 14])
+def test_msm_matches_oracle(gpu_workers, oracle, curve, cid, n):
+    w = gpu_workers(curve)
+    uniq = min(n, 64)                                   # duplicated bases => P+P in buckets (dispatcher.rs:194-196)
+    bases = oracle.gen_bases(cid, 9, uniq, n)
+    b, inf = _bases_with_inf(oracle, cid, bases, [3] if n > 3 else [])     # infinity base (dispatcher2.rs:1101)
+    sc = oracle.from_mont(cid, oracle.rand_fr(cid, 21, n))
+    sc[0] = 0
+    if n > 2:
+        sc[1] = [1, 0, 0, 0]
+        sc[2] = oracle.field_const(cid, 0, 0) - np.array([1, 0, 0, 0], dtype=np.uint64)    # p - 1
+    w.init(b, 0, 0)
+    got = w.var_msm(MsmWorkload(0, n), sc)
+    want = oracle.msm(cid, bases, sc, inf, threads=4)
+    assert _affine_eq(w, oracle, cid, got, want)
+    if n <= 40:
+        assert _affine_eq(w, oracle, cid, got, oracle.msm_naive(cid, bases, sc, inf))
+
+
+def test_msm_sharded_like_test_msm(gpu_workers, oracle):
+    """dispatcher.rs:177-244: S contiguous shards, reduce(a+b) == monolithic MSM."""
+    w = gpu_workers("bn254")
+    n, S = 1 << 16, 4
+    bases = oracle.gen_bases(0, 3, 1 << 11, n)
+    sc = oracle.from_mont(0, oracle.rand_fr(0, 4, n))
+    w.init(bases, 0, 0)
+    acc = None
+    for i in range(S):
+        lo, hi = i * n // S, (i + 1) * n // S
+        part = w.var_msm(MsmWorkload(lo, hi), sc[lo:hi])
+        acc = part if acc is None else w.g1_add(acc, part)
+    assert _affine_eq(w, oracle, 0, acc, oracle.msm(0, bases, sc, threads=8))
+    assert _affine_eq(w, oracle, 0, acc, w.var_msm(MsmWorkload(0, n), sc))
+
+
+def test_msm_cancellation_and_zero(gpu_workers, oracle):
+    w = gpu_workers("bn254")
+    bases = oracle.gen_bases(0, 1, 1, 2)               # P, P
+    p = oracle.field_const(0, 0, 0)
+    s = np.array([[5, 0, 0, 0]], dtype=np.uint64)
+    neg = (p - np.array([5, 0, 0, 0], dtype=np.uint64)).reshape(1, 4)   # -5 mod r (no borrow: low limb > 5)
+    w.init(bases, 0, 0)
+    out = w.var_msm(MsmWorkload(0, 2), np.vstack([s, neg]))
+    assert w.g1_to_affine(out)[1]                      # 5P + (-5)P = infinity
+    assert w.g1_to_affine(w.var_msm(MsmWorkload(0, 0), np.zeros((0, 4), dtype=np.uint64)))[1]
+    from distributed_plonk_amd._ffi import PlonkError
+    with pytest.raises(PlonkError):
+        w.var_msm(MsmWorkload(1, 5), s)                # out of range: the reference would panic (worker.rs:180)
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_commit_and_round1(gpu_workers, oracle, curve, cid):
+    w = gpu_workers(curve)
+    n = 1 << 10
+    bases = oracle.gen_bases(cid, 2, 128, n + 32)
+    w.init(bases, n, 8 * n)
+    coeffs = oracle.rand_fr(cid, 8, n)
+    assert _affine_eq(w, oracle, cid, w.commit(coeffs), oracle.commit_polynomial(cid, bases, coeffs, threads=4))
+    evals = oracle.rand_fr(cid, 9, n)
+    bl = oracle.rand_fr(cid, 10, 2)
+    poly, cm = oracle.round1(cid, bases, evals, bl, threads=4)
+    got = w.round1(evals, bl)
+    assert np.array_equal(w.get_wire(n + 2), poly)
+    assert _affine_eq(w, oracle, cid, got, cm)
+
+
+def test_synth_inputs_match_oracle(gpu_workers, oracle):
+    for curve, cid in [("bn254", 0), ("bls12_381", 1)]:
+        w = gpu_workers(curve)
+        n = 1000
+        buf = w.alloc(n * 32)
+        w.synth_fr(123, buf.ptr, n)
+        assert np.array_equal(buf.download((n, 4)), oracle.rand_fr(cid, 123, n))
+        buf.free()
+        q = w.q64
+        pb = w.alloc(300 * 16 * q)
+        w.synth_bases(77, 100, 300, pb.ptr)
+        assert np.array_equal(pb.download((300, 2 * q)), oracle.gen_bases(cid, 77, 100, 300))
+        w.synth_bases(5, 0, 300, pb.ptr)               # pairwise-distinct variant
+        pts = pb.download((300, 2 * q))
+        assert all(oracle.on_curve(cid, p) for p in pts[:50])
+        assert len({p.tobytes() for p in pts}) == 300
+        pb.free()
