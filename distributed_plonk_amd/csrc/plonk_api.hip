@@ -75,7 +75,28 @@ struct plonk_ctx {
     int msm_window = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
+    // small free-list of exchange buffers so that back-to-back transforms do not hipMalloc/hipFree
+    std::vector<std::pair<size_t, void*>> pool;
 };
+
+static int pool_get(plonk_ctx* ctx, size_t bytes, void** out) {
+    for (size_t i = 0; i < ctx->pool.size(); i++)
+        if (ctx->pool[i].first == bytes) {
+            *out = ctx->pool[i].second;
+            ctx->pool.erase(ctx->pool.begin() + i);
+            return PLONK_OK;
+        }
+    HIP_TRY(hipMalloc(out, bytes));
+    return PLONK_OK;
+}
+static void pool_put(plonk_ctx* ctx, size_t bytes, void* p) {
+    if (!p) return;
+    if (ctx->pool.size() >= 6) {
+        (void)hipFree(ctx->pool.front().second);
+        ctx->pool.erase(ctx->pool.begin());
+    }
+    ctx->pool.push_back({bytes, p});
+}
 
 static size_t aff_bytes(int curve) { return curve == PLONK_BN254 ? 64 : 96; }
 static size_t jac_bytes(int curve) { return curve == PLONK_BN254 ? 96 : 144; }
@@ -111,10 +132,11 @@ static int ensure_scratch2(plonk_ctx* ctx, size_t bytes) {
         HIP_TRY(hipSetDevice((ctx)->device));                           \
     } while (0)
 
-static void free_task(FftTask& t) {
-    if (t.d_rows && !t.rows_external) hipFree(t.d_rows);
-    if (t.d_send) hipFree(t.d_send);
-    if (t.d_recv && t.d_recv != t.d_send) hipFree(t.d_recv);
+static void free_task(plonk_ctx* ctx, FftTask& t) {
+    const size_t tile_bytes = t.nrows * t.c * 32;
+    if (t.d_rows && !t.rows_external) pool_put(ctx, tile_bytes, t.d_rows);
+    if (t.d_send) pool_put(ctx, tile_bytes, t.d_send);
+    if (t.d_recv && t.d_recv != t.d_send) pool_put(ctx, tile_bytes, t.d_recv);
     t.d_rows = t.d_send = t.d_recv = nullptr;
 }
 
@@ -141,7 +163,8 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->tasks) free_task(kv.second);
+    for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
+    for (auto& pb : ctx->pool) (void)hipFree(pb.second);
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
     if (ctx->d_wire) hipFree(ctx->d_wire);
@@ -402,7 +425,7 @@ extern "C" int plonk_fft_init(plonk_ctx* ctx, uint64_t id, const plonk_fft_workl
         return plonk_fail(PLONK_ERR_ARG, "plonk_fft_init: %zu workers do not evenly split r=%llu, c=%llu", n_wl, (unsigned long long)t.r,
                           (unsigned long long)t.c);
     auto old = ctx->tasks.find(id);
-    if (old != ctx->tasks.end()) { free_task(old->second); ctx->tasks.erase(old); }   // HashMap::insert replaces
+    if (old != ctx->tasks.end()) { free_task(ctx, old->second); ctx->tasks.erase(old); }   // HashMap::insert replaces
     t.row_present.assign(t.nrows, 0);
     ctx->tasks[id] = t;
     return PLONK_OK;
@@ -424,7 +447,7 @@ extern "C" int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_
     if (!v || len != t->c) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1: row length %zu != c = %llu", len, (unsigned long long)t->c);
     if (i >= t->nrows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1: local row %llu >= %llu", (unsigned long long)i, (unsigned long long)t->nrows);
     if (t->prepared || t->rows_external) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1: rows already consumed");
-    if (!t->d_rows) HIP_TRY(hipMalloc((void**)&t->d_rows, t->nrows * t->c * 32));
+    if (!t->d_rows) { int prc = pool_get(ctx, t->nrows * t->c * 32, (void**)&t->d_rows); if (prc) return prc; }
     HIP_TRY(hipMemcpyAsync(t->d_rows + i * t->c, v, t->c * 32, hipMemcpyHostToDevice, ctx->stream));
     if (!t->row_present[i]) { t->row_present[i] = 1; t->rows_filled++; }
     return PLONK_OK;
@@ -437,7 +460,7 @@ extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows) {
     if (rc) return rc;
     if (!d_rows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev: null");
     if (t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1_dev: already prepared");
-    if (t->d_rows && !t->rows_external) hipFree(t->d_rows);
+    if (t->d_rows && !t->rows_external) pool_put(ctx, t->nrows * t->c * 32, t->d_rows);
     t->d_rows = (Fr*)const_cast<void*>(d_rows);
     t->rows_external = true;
     t->rows_filled = t->nrows;
@@ -456,7 +479,7 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     const size_t S = t->wl.size();
     if (S > 1 && !exchange) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu ranks need an exchange callback", S);
     const size_t tile_bytes = t->nrows * t->c * 32;     // == r * ncols * 32
-    HIP_TRY(hipMalloc((void**)&t->d_send, tile_bytes));
+    if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_send))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     // row pass (fft1_helper, worker.rs:66-94) for all local rows, written straight into the
     // per-peer blocks of the send buffer (the pack of worker.rs:327-330)
@@ -474,8 +497,8 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     c.split_log = ilog2_exact(t->ncols);
     c.split_blk = t->nrows * t->ncols;
     if ((rc = ntt_run(ctx->tables, c, ctx->stream))) return rc;
-    if (S > 1) {
-        HIP_TRY(hipMalloc((void**)&t->d_recv, tile_bytes));
+    if (exchange) {          // also honoured for a single rank (all-to-all with oneself), so the transport is testable on one GPU
+        if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_recv))) return rc;
         const int xr = exchange(user, t->d_send, t->d_recv, t->nrows * t->ncols * 32, (int)S, (void*)ctx->stream);
         if (xr) return plonk_fail(PLONK_ERR_EXCHANGE, "exchange callback returned %d", xr);
     } else {
@@ -483,7 +506,7 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     }
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
-    if (t->d_rows && !t->rows_external) { hipFree(t->d_rows); }     // task.rows = vec![] (worker.rs:341)
+    if (t->d_rows && !t->rows_external) pool_put(ctx, tile_bytes, t->d_rows);     // task.rows = vec![] (worker.rs:341)
     t->d_rows = nullptr;
     t->prepared = true;
     return PLONK_OK;
@@ -521,7 +544,7 @@ extern "C" int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layo
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     auto it = ctx->tasks.find(id);
-    free_task(it->second);
+    free_task(ctx, it->second);
     ctx->tasks.erase(it);                       // worker.rs:378
     return PLONK_OK;
 }
@@ -538,7 +561,7 @@ extern "C" int plonk_fft2(plonk_ctx* ctx, uint64_t id, uint64_t* out_cols) {
     HIP_TRY(hipMemcpyAsync(out_cols, ctx->d_scratch2, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     auto it = ctx->tasks.find(id);
-    free_task(it->second);
+    free_task(ctx, it->second);
     ctx->tasks.erase(it);
     return PLONK_OK;
 }

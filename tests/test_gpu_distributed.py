@@ -1,0 +1,154 @@
+"""The reference's distributed call sequence (fftInit / fft1 / fft2Prepare+fftExchange / fft2, varMsm)
+on S in-process workers sharing cuda:0 — the shape of dispatcher.rs:246-350 (`test_fft`: domains 2^11 and
+2^13, all four modes) and dispatcher2.rs:1088-1216 (128 / 1024), checked bit-for-bit against the oracle."""
+import numpy as np
+import pytest
+
+from distributed_plonk_amd.dispatcher import Dispatcher, make_fft_workloads, split_rc
+
+pytestmark = pytest.mark.gpu
+
+MODES = [(False, False), (True, False), (False, True), (True, True)]
+
+
+@pytest.fixture(scope="module")
+def workers4():
+    from distributed_plonk_amd.worker import PlonkWorker
+    ws = {c: [PlonkWorker(me=i, device=0, curve=c) for i in range(4)] for c in ("bn254", "bls12_381")}
+    yield ws
+    for l in ws.values():
+        for w in l:
+            w.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_fft_like_reference_test_fft(workers4, oracle, curve, cid, S):
+    d = Dispatcher(workers4[curve][:S])
+    d.init(None, 1 << 11, 1 << 13)
+    for is_quot in (False, True):
+        N = d.quot_domain_size if is_quot else d.domain_size
+        coeffs = oracle.rand_fr(cid, 31 + is_quot, N)
+        for is_inv, is_coset in MODES:
+            got = d.fft(coeffs, is_quot, is_inv, is_coset)
+            want = oracle.ntt(cid, coeffs, is_inv, is_coset, threads=4)
+            assert np.array_equal(got, want), f"{curve} S={S} quot={is_quot} inv={is_inv} coset={is_coset}"
+
+
+@pytest.mark.parametrize("sizes", [(128, 1024), (1 << 16, 1 << 19)])
+def test_fft_other_sizes_and_short_input(workers4, oracle, sizes):
+    """dispatcher2.rs:1088-1216 sizes, a 2-pass row/column case, and the zero-padding of :746."""
+    d = Dispatcher(workers4["bn254"][:2])
+    d.init(None, sizes[0], sizes[1])
+    for is_quot in (False, True):
+        N = sizes[1] if is_quot else sizes[0]
+        coeffs = oracle.rand_fr(0, 5, N // 2 + 3)                 # shorter than the domain
+        padded = np.zeros((N, 4), dtype=np.uint64)
+        padded[:len(coeffs)] = coeffs
+        for is_inv, is_coset in [(False, True), (True, False), (True, True)]:
+            assert np.array_equal(d.fft(coeffs, is_quot, is_inv, is_coset), oracle.ntt(0, padded, is_inv, is_coset, threads=8))
+
+
+def test_per_step_parity_fft1_exchange_fft2(workers4, oracle):
+    """Each step against its own restatement: fft1_helper (worker.rs:66-94), the pack/scatter index maps
+    (worker.rs:327-330,432-435) and fft2_helper (worker.rs:96-115)."""
+    S, log_n, cid = 2, 9, 0
+    N = 1 << log_n
+    r, c = split_rc(N)
+    ws = workers4["bn254"][:S]
+    d = Dispatcher(ws)
+    d.init(None, N, 0)
+    wl = make_fft_workloads(N, S)
+    coeffs = oracle.rand_fr(cid, 99, N)
+    rows = coeffs.reshape(c, r, 4).transpose(1, 0, 2).copy()
+    for is_inv, is_coset in MODES:
+        # oracle pipeline
+        o_rows = np.stack([oracle.fft1_helper(cid, rows[b], b, log_n, is_inv, is_coset) for b in range(r)])
+        o_cols = [np.zeros((wl[s].num_cols(), r, 4), dtype=np.uint64) for s in range(S)]
+        for src in range(S):
+            for dst in range(S):
+                blk = oracle.exchange_pack(o_rows[wl[src].row_start:wl[src].row_end].reshape(-1, c, 4).reshape(wl[src].num_rows(), c * 4).view(np.uint64).reshape(wl[src].num_rows(), c, 4),
+                                           wl[dst].col_start, wl[dst].col_end)
+                oracle.exchange_scatter(o_cols[dst], wl[src].row_start, blk)
+        want = [np.stack([oracle.fft2_helper(cid, o_cols[s][i], i + wl[s].col_start, log_n, is_inv, is_coset)
+                          for i in range(wl[s].num_cols())]) for s in range(S)]
+        # device pipeline
+        id = 1234 + 2 * is_inv + is_coset
+        for w in ws:
+            w.fft_init(id, wl, False, is_inv, is_coset)
+        for s, w in enumerate(ws):
+            for j in range(wl[s].num_rows()):
+                w.fft1(id, j, rows[wl[s].row_start + j])
+        d._fft2_prepare_all(id)
+        for s, w in enumerate(ws):
+            assert np.array_equal(w.fft2(id, r), want[s]), f"rank {s} inv={is_inv} coset={is_coset}"
+
+
+def test_call_order_errors(workers4):
+    from distributed_plonk_amd._ffi import PlonkError
+    w = workers4["bn254"][0]
+    w.me = 0
+    w.init(None, 1 << 6, 0)
+    wl = make_fft_workloads(1 << 6, 1)
+    with pytest.raises(PlonkError) as e:
+        w.fft1(42, 0, np.zeros((8, 4), dtype=np.uint64))         # unknown id (reference: unwrap panic)
+    assert e.value.code == -4
+    w.fft_init(43, wl, False, False, False)
+    with pytest.raises(PlonkError):
+        w.fft1(43, 0, np.zeros((5, 4), dtype=np.uint64))         # wrong row length
+    with pytest.raises(PlonkError) as e:
+        w.fft2_prepare(43, None)                                 # rows missing
+    assert e.value.code == -4
+    with pytest.raises(PlonkError):
+        w.fft_init(44, wl, True, False, False)                   # quot domain not initialised
+
+
+def test_commit_polynomial_sharded(workers4, oracle):
+    cid = 1
+    ws = workers4["bls12_381"][:2]
+    d = Dispatcher(ws)
+    n = 1 << 9
+    bases = oracle.gen_bases(cid, 4, 64, n + 32)
+    bases[7] = 0                                                 # infinity in the SRS padding style
+    inf = np.zeros(len(bases), dtype=np.uint8); inf[7] = 1
+    d.init(bases, n, 0)
+    poly = oracle.rand_fr(cid, 6, n + 2)
+    xy, isinf = d.commit_polynomial(poly)
+    oxy, oinf = oracle.jac_to_affine(cid, oracle.commit_polynomial(cid, bases, poly, inf, threads=4))
+    assert isinf == oinf and np.array_equal(xy, oxy)
+
+
+def test_rank_prover_rccl_single_rank(oracle):
+    """The one-process-per-GPU path (RankProver) with the RCCL transport forced on a world of 1:
+    HBM-resident rows -> row pass -> torch.distributed.all_to_all_single (backend nccl = RCCL) ->
+    column pass, output in the [r][c/S] layout; plus the MSM all-gather + host add."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from distributed_plonk_amd.dispatcher import RankProver, gather_points
+    from distributed_plonk_amd.worker import PlonkWorker
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    w = PlonkWorker(me=0, device=0, curve="bn254")
+    try:
+        log_n = 13
+        N = 1 << log_n
+        r, c = split_rc(N)
+        w.init(None, N, 0)
+        rp = RankProver(w, 0, 1, force_exchange=True)
+        coeffs = oracle.rand_fr(0, 17, N)
+        rows = np.ascontiguousarray(coeffs.reshape(c, r, 4).transpose(1, 0, 2))      # [r][c]
+        for is_inv, is_coset in MODES:
+            d_rows = w.alloc(N * 32).upload(rows)
+            d_out = w.alloc(N * 32)
+            rp.fft_dev(d_rows.ptr, d_out.ptr, N, False, is_inv, is_coset, out_layout=1)
+            got = d_out.download((N, 4))                  # [r][c] with (j, i) = X[i + j*c]  == natural order
+            assert np.array_equal(got, oracle.ntt(0, coeffs, is_inv, is_coset, threads=4))
+            d_rows.free(); d_out.free()
+        pts = gather_points(np.arange(12, dtype=np.uint64), None, torch.device("cuda", 0))
+        assert len(pts) == 1 and np.array_equal(pts[0], np.arange(12, dtype=np.uint64))
+    finally:
+        w.close()
+        dist.destroy_process_group()
