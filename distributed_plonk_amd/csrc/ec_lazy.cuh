@@ -1,0 +1,90 @@
+// ec_lazy.cuh — XYZZ mixed addition on unsaturated limbs with lazy reduction (hot loop of the MSM
+// bucket accumulation).  Same group law and the same exceptional-case handling as ec.cuh; only the
+// field representation differs (flimb.cuh).
+//
+// Invariants of an accumulator (X, Y, ZZ, ZZZ): limbs normalised, values bounded by
+//     X < 5.2 p,  Y < 3.3 p,  ZZ < 2 p,  ZZZ < 2 p ;   infinity <=> every limb of ZZ is exactly 0.
+// Affine inputs are canonical (< p); infinity is x = y = 0.
+// Bound bookkeeping (p/R' <= 2^-7.4):  every product of operands (a, b) is < a*b/R' + p, so
+//     P  = U2 + 8p - X1  < 9.2p      R  = S2 + 4p - Y1 < 5.2p
+//     PP < 1.5p  PPP < 1.1p  Q < 1.1p  RR < 1.2p
+//     X3 = RR + 4p - (PPP + 2Q) < 5.2p          (PPP + 2Q < 3.3p, limbs < 3*2^29 < 2^31)
+//     T  = Q + 8p - X3 < 9.1p
+//     Y3 = R*T + 2p - Y1*PPP < 3.3p             (each product < 1.3p)
+#pragma once
+#include "flimb.cuh"
+
+template <int NL, int B> struct AffL { FL<NL, B> x, y; };
+template <int NL, int B> struct XyzzL { FL<NL, B> x, y, zz, zzz; };
+
+template <int NL, int B> FP_HD bool affl_is_inf(const AffL<NL, B>& p) {
+    uint32_t t = 0;
+#pragma unroll
+    for (int i = 0; i < NL; i++) t |= p.x.l[i] | p.y.l[i];
+    return t == 0;
+}
+template <int NL, int B> FP_HD XyzzL<NL, B> xyzzl_inf() {
+    XyzzL<NL, B> r;
+    r.x = fl_zero<NL, B>(); r.y = fl_zero<NL, B>(); r.zz = fl_zero<NL, B>(); r.zzz = fl_zero<NL, B>();
+    return r;
+}
+
+// 2*q for affine q (mdbl-2008-s-1), lazy.  Cold: only reached when a bucket receives the same point twice.
+template <int NL, int B>
+__device__ __attribute__((noinline)) XyzzL<NL, B> xyzzl_dbl_affine(const AffL<NL, B>& q, const FLParams<NL, B>& P) {
+    XyzzL<NL, B> r;
+    FL<NL, B> u = fl_add(q.y, q.y);
+    fl_norm(u);                                             // 2y < 2p
+    const FL<NL, B> v = fl_mul(u, u, P);
+    const FL<NL, B> w = fl_mul(u, v, P);
+    const FL<NL, B> s = fl_mul(q.x, v, P);
+    const FL<NL, B> xx = fl_mul(q.x, q.x, P);
+    FL<NL, B> m = fl_add(fl_add(xx, xx), xx);
+    fl_norm(m);                                             // 3x^2 < 3.6p
+    FL<NL, B> s2 = fl_add(s, s);                            // limbs < 2^30
+    FL<NL, B> x3 = fl_sub(fl_mul(m, m, P), s2, P.c4);
+    fl_norm(x3);                                            // < 5.2p
+    FL<NL, B> t = fl_sub(s, x3, P.c8);
+    fl_norm(t);
+    FL<NL, B> y3 = fl_sub(fl_mul(m, t, P), fl_mul(w, q.y, P), P.c2);
+    fl_norm(y3);
+    r.x = x3; r.y = y3; r.zz = v; r.zzz = w;
+    return r;
+}
+
+// acc + q (madd-2008-s), complete.
+template <int NL, int B>
+__device__ __forceinline__ XyzzL<NL, B> xyzzl_madd(const XyzzL<NL, B>& a, const AffL<NL, B>& q, const FLParams<NL, B>& P) {
+    if (affl_is_inf(q)) return a;
+    if (fl_all_zero(a.zz)) {
+        XyzzL<NL, B> r;
+        r.x = q.x; r.y = q.y;
+        r.zz = fl_load_const<NL, B>(P.one); r.zzz = r.zz;
+        return r;
+    }
+    const FL<NL, B> u2 = fl_mul(q.x, a.zz, P);
+    const FL<NL, B> s2 = fl_mul(q.y, a.zzz, P);
+    FL<NL, B> p = fl_sub(u2, a.x, P.c8);
+    fl_norm(p);
+    FL<NL, B> r = fl_sub(s2, a.y, P.c4);
+    fl_norm(r);
+    const FL<NL, B> pp = fl_mul(p, p, P);
+    if (fl_is_zero_mod_p_lt3p(pp, P)) {                      // same x: P + P or P + (-P)
+        const FL<NL, B> rc = fl_canon_small(r, P, 6);
+        if (fl_all_zero(rc)) return xyzzl_dbl_affine(q, P);
+        return xyzzl_inf<NL, B>();
+    }
+    XyzzL<NL, B> o;
+    const FL<NL, B> ppp = fl_mul(p, pp, P);
+    const FL<NL, B> qq = fl_mul(a.x, pp, P);
+    FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));             // PPP + 2Q, limbs < 3*2^B
+    o.x = fl_sub(fl_mul(r, r, P), sub, P.c4);
+    fl_norm(o.x);
+    FL<NL, B> t = fl_sub(qq, o.x, P.c8);
+    fl_norm(t);
+    o.y = fl_sub(fl_mul(r, t, P), fl_mul(a.y, ppp, P), P.c2);
+    fl_norm(o.y);
+    o.zz = fl_mul(a.zz, pp, P);
+    o.zzz = fl_mul(a.zzz, ppp, P);
+    return o;
+}

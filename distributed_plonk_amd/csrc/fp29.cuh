@@ -1,0 +1,172 @@
+// fp29.cuh — 9 x 29-bit "unsaturated" limb arithmetic for the 254/255-bit scalar fields, gfx950 VALU.
+//
+// Why: measured on MI355X (profiles/r01_valu_microbench.txt) v_mad_u64_u32 issues at the same rate
+// (~4.5 clk per wave-instruction) as v_add_co/v_addc/v_lshl_add_u64, so a saturated 8x32 CIOS
+// multiplier spends as many issue slots on carry plumbing (and v_mov zero-extensions) as on products
+// (~550 VALU instructions).  With 29-bit limbs a column of nine 58-bit products plus the Montgomery
+// correction fits a 64-bit accumulator: product scanning needs ONE v_mad_u64_u32 per limb product and
+// no carries at all (162 mads + 9 v_mul_lo + 17 shifts/masks ~ 205 instructions), additions are nine
+// independent v_add_u32, and reduction is lazy.
+//
+// Semantics: HBM keeps the reference's representation (8 x u32, a*2^256 mod p, fully reduced,
+// utils.rs:27-43).  Inside a kernel a value is re-limbed to 9 x 29 bits (same residue).  Every
+// multiplication on the NTT path is data x precomputed constant; constants are stored as c*2^261 mod p,
+// so  mont261(x, c*2^261) = x*c  keeps x's 2^256 factor untouched.  Values are canonicalised
+// (conditional subtraction) before the final store, so results are bit-identical to ark-ff's.
+//
+// Bounds (p < 2^255, R = 2^261):  f29_mul accepts x < 2^259.4 with limbs < 2^31 and a normalised
+// constant w < p, and returns a normalised value < 1.36 p.  x + C - t with C = "2p in borrow form"
+// needs t normalised (a product).  Decimation-in-time butterflies grow the bound by at most 2p per
+// stage, so up to ~20 stages run between canonicalisations.
+#pragma once
+#include <stdint.h>
+#include "fp.cuh"
+
+struct F29 { uint32_t l[9]; };
+
+struct F29Params {
+    uint32_t p[9];      // modulus, normalised 29-bit limbs
+    uint32_t c2p[9];    // 2p with limbs lifted by 2^30 (borrowed from the next limb): every limb >= any product limb
+    uint32_t one[9];    // 2^261 mod p  (the constant that multiplies by 1)
+    uint32_t inv;       // -p^{-1} mod 2^29
+};
+
+#define F29_MASK 0x1fffffffu
+
+FP_HD F29 f29_from_sat(const Fp<8>& a) {
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, w = bit >> 5, off = bit & 31;
+        uint32_t v = a.l[w] >> off;
+        if (off + 29 > 32 && w + 1 < 8) v |= a.l[w + 1] << (32 - off);
+        r.l[k] = (k == 8) ? v : (v & F29_MASK);
+    }
+    return r;
+}
+
+// normalised limbs, value < 2^256
+FP_HD Fp<8> f29_to_sat(const F29& a) {
+    Fp<8> r;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        const int bit = 32 * j, k = bit / 29, sh = bit - 29 * k;       // word j starts inside limb k at bit sh
+        uint32_t v = a.l[k] >> sh;
+        v |= a.l[k + 1] << (29 - sh);
+        r.l[j] = v;
+    }
+    return r;
+}
+
+// carry pass: limbs 0..7 back below 2^29, excess accumulates in limb 8
+FP_HD void f29_norm(F29& a) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        a.l[i + 1] += a.l[i] >> 29;
+        a.l[i] &= F29_MASK;
+    }
+}
+
+FP_HD F29 f29_add(const F29& a, const F29& b) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + b.l[i];
+    return r;
+}
+
+// a + 2p - t   (t normalised, t < 2p)
+FP_HD F29 f29_sub2p(const F29& a, const F29& t, const F29Params& P) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P.c2p[i] - t.l[i];
+    return r;
+}
+
+// Montgomery product x*w/2^261 mod p, product scanning with one 64-bit accumulator.
+// x: limbs < 2^31, value < 2^259.4 ; w: normalised, < p.  Result normalised, < 1.36 p.
+FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) acc += (uint64_t)x.l[i] * w.l[k - i];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        m[k] = ((uint32_t)acc * P.inv) & F29_MASK;
+        acc += (uint64_t)m[k] * P.p[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)x.l[i] * w.l[k - i];
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        r.l[k - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+// normalised a < 2p  ->  a mod p (canonical), still normalised
+FP_HD F29 f29_canon(const F29& a, const F29Params& P) {
+    F29 d;
+    int32_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        const int32_t t = (int32_t)a.l[i] - (int32_t)P.p[i] + br;
+        br = t >> 31;                                  // -1 on borrow
+        d.l[i] = (i == 8) ? (uint32_t)t : ((uint32_t)t & F29_MASK);
+    }
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = br ? a.l[i] : d.l[i];
+    return r;
+}
+
+// ---- host-side helpers (table construction)
+// canonical integer limbs (8 x u32, < p) -> F29
+inline F29 f29_from_canonical_host(const Fp<8>& c) { return f29_from_sat(c); }
+
+inline F29Params f29_make_params(const FpParams<8>& P) {
+    F29Params q;
+    Fp<8> pm;
+    for (int i = 0; i < 8; i++) pm.l[i] = P.p[i];
+    F29 p29 = f29_from_sat(pm);
+    for (int i = 0; i < 9; i++) q.p[i] = p29.l[i];
+    // 2p, normalised, then lift: c[0] += 2^30 ; c[i] += 2^30 - 2 (0<i<8) ; c[8] -= 2
+    uint32_t d[9];
+    uint32_t carry = 0;
+    for (int i = 0; i < 9; i++) {
+        uint32_t v = 2 * q.p[i] + carry;
+        carry = (i < 8) ? (v >> 29) : 0;
+        d[i] = (i < 8) ? (v & F29_MASK) : v;
+    }
+    q.c2p[0] = d[0] + (1u << 30);
+    for (int i = 1; i < 8; i++) q.c2p[i] = d[i] + (1u << 30) - 2;
+    q.c2p[8] = d[8] - 2;
+    // inv = -p^{-1} mod 2^29 (Newton)
+    uint32_t x = 1;
+    for (int i = 0; i < 6; i++) x *= 2 - q.p[0] * x;
+    q.inv = (0u - x) & F29_MASK;
+    // one = 2^261 mod p : R256 mod p doubled five times (as residues)
+    Fp<8> o;
+    for (int i = 0; i < 8; i++) o.l[i] = P.one[i];
+    for (int i = 0; i < 5; i++) o = fp_add(o, o, P);
+    F29 o29 = f29_from_sat(o);
+    for (int i = 0; i < 9; i++) q.one[i] = o29.l[i];
+    return q;
+}
+
+// value v given in the reference's Montgomery form (v*2^256) -> constant form v*2^261 mod p, 29-bit limbs
+inline F29 f29_const_from_mont256(const Fp<8>& v_mont, const FpParams<8>& P) {
+    Fp<8> r261;                                   // 2^261 mod p as a plain residue
+    for (int i = 0; i < 8; i++) r261.l[i] = P.one[i];
+    for (int i = 0; i < 5; i++) r261 = fp_add(r261, r261, P);
+    Fp<8> k_mont = fp_to_mont(r261, P);           // (2^261) * 2^256
+    Fp<8> prod = fp_mul(v_mont, k_mont, P);       // v * 2^261 * 2^256
+    return f29_from_sat(fp_from_mont(prod, P));   // v * 2^261 mod p, canonical
+}

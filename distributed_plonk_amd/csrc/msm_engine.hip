@@ -26,6 +26,7 @@
 
 #include "constants.h"
 #include "ec.cuh"
+#include "ec_lazy.cuh"
 #include "plonk_internal.hpp"
 
 template <int NQ> static const FpParams<NQ>& fq_params(int curve);
@@ -155,19 +156,65 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------- 4: bucket accumulation
+// Limb geometry of the lazy base-field arithmetic per curve (flimb.cuh)
+template <int NQ> struct LimbGeom;
+template <> struct LimbGeom<8> { static constexpr int NL = 9, B = 29; };      // BN254 Fq, R' = 2^261
+template <> struct LimbGeom<12> { static constexpr int NL = 14, B = 28; };    // BLS12-381 Fq, R' = 2^392
+
+template <typename T> __device__ __forceinline__ T load8(const T* p) {
+    static_assert(sizeof(T) % 8 == 0, "8-byte multiple");
+    T r;
+    const uint2* s = reinterpret_cast<const uint2*>(p);
+    uint2* d = reinterpret_cast<uint2*>(&r);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; i++) d[i] = s[i];
+    return r;
+}
+template <typename T> __device__ __forceinline__ void store8(T* p, const T& v) {
+    uint2* d = reinterpret_cast<uint2*>(p);
+    const uint2* s = reinterpret_cast<const uint2*>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 8; i++) d[i] = s[i];
+}
+
+// SRS bases: reference layout (x||y, R = 2^(32N) Montgomery, canonical) -> resident limb form (R' Montgomery)
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffPt<NQ>* __restrict__ bases, const uint32_t* __restrict__ sorted,
-                                                             const uint32_t* __restrict__ offsets, uint64_t nbuckets,
-                                                             XyzzPt<NQ>* __restrict__ buckets, const FpParams<NQ> P) {
+__global__ void __launch_bounds__(256) bases_to_limbs_kernel(const AffPt<NQ>* __restrict__ in, uint64_t n,
+                                                             AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out,
+                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffPt<NQ> a = load16(in + i);
+    const FL<NL, B> fix = fl_load_const<NL, B>(P.r2fix);
+    AffL<NL, B> o;
+    o.x = fl_canon_lt2p(fl_mul(fl_from_sat<NL, B, NQ>(a.x), fix, P), P);
+    o.y = fl_canon_lt2p(fl_mul(fl_from_sat<NL, B, NQ>(a.y), fix, P), P);
+    store8(out + i, o);
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+                                                             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                             uint64_t nbuckets, XyzzPt<NQ>* __restrict__ buckets,
+                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= nbuckets) return;
     const uint32_t beg = offsets[b], end = offsets[b + 1];
-    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
     for (uint32_t j = beg; j < end; j++) {
-        const AffPt<NQ> q = load16(bases + sorted[j]);
-        acc = xyzz_madd(acc, q, P);
+        const AffL<NL, B> q = load8(bases + sorted[j]);
+        acc = xyzzl_madd(acc, q, P);
     }
-    store16(buckets + b, acc);
+    // back to the canonical R = 2^(32N) Montgomery form the rest of the pipeline (and the reference) uses
+    const FL<NL, B> rs = fl_load_const<NL, B>(P.r_std);
+    XyzzPt<NQ> o;
+    o.x = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.x, rs, P), P));
+    o.y = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.y, rs, P), P));
+    o.zz = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.zz, rs, P), P));
+    o.zzz = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.zzz, rs, P), P));
+    store16(buckets + b, o);
 }
 
 // ---------------------------------------------------------------------------------------------- 5: window reduction
@@ -248,6 +295,26 @@ int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, h
     return PLONK_OK;
 }
 
+template <int NQ> static const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& fl_params(int curve) {
+    static const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P = fl_make_params<LimbGeom<NQ>::NL, LimbGeom<NQ>::B, NQ>(fq_params<NQ>(curve));
+    return P;
+}
+
+size_t msm_limb_base_bytes(int curve) { return curve == PLONK_BN254 ? sizeof(AffL<9, 29>) : sizeof(AffL<14, 28>); }
+
+// XY (reference layout) -> resident limb form; d_out holds n * msm_limb_base_bytes(curve) bytes
+int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    const uint32_t grid = (uint32_t)((n + 255) / 256);
+    if (curve == PLONK_BN254)
+        hipLaunchKernelGGL(bases_to_limbs_kernel<8>, dim3(grid), dim3(256), 0, stream, (const AffPt<8>*)d_xy, (uint64_t)n, (AffL<9, 29>*)d_out, fl_params<8>(curve));
+    else
+        hipLaunchKernelGGL(bases_to_limbs_kernel<12>, dim3(grid), dim3(256), 0, stream, (const AffPt<12>*)d_xy, (uint64_t)n, (AffL<14, 28>*)d_out, fl_params<12>(curve));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "bases_to_limbs launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- host orchestration
 static int choose_window(size_t n, int bits) {
     double best = 1e300;
@@ -273,7 +340,7 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int NQ>
-static int msm_slice(int curve, const AffPt<NQ>* d_bases, const uint32_t* d_scalars, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
+static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
                      int window_bits, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
@@ -317,7 +384,7 @@ static int msm_slice(int curve, const AffPt<NQ>* d_bases, const uint32_t* d_scal
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, offsets, counts, sorted); }
     { ProfScope ps("msm_accumulate_kernel", stream);
     hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, nbuckets,
-                       buckets, P); }
+                       buckets, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_reduce_chunks_kernel", stream);
     hipLaunchKernelGGL(msm_reduce_chunks_kernel<NQ>, dim3((uint32_t)((nchunks_total + 255) / 256)), dim3(256), 0, stream, buckets, c, logk,
                        nchunks_total, chunks, P); }
@@ -352,7 +419,7 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, 
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
         XyzzPt<NQ> part;
-        int rc = msm_slice<NQ>(curve, (const AffPt<NQ>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, stream);
+        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, stream);
         if (rc) return rc;
         total = xyzz_add(total, part, P);
     }

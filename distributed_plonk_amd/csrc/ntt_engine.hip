@@ -20,12 +20,20 @@ static Fr host_pow2k(const Fr& a, int k, const FrParams& P) {   // a^(2^k)
     return r;
 }
 
-static int upload_powers(Fr** d_out, const Fr& base, size_t count, const Fr& first, const FrParams& P, hipStream_t stream) {
-    std::vector<Fr> h(count);
+// first * base^i for i < count, converted to constant form (c*2^261 mod p, 29-bit limbs)
+static int upload_powers(F29** d_out, const Fr& base, size_t count, const Fr& first, const FrParams& P, hipStream_t stream) {
+    std::vector<F29> h(count);
+    Fr r261;
+    for (int i = 0; i < 8; i++) r261.l[i] = P.one[i];
+    for (int i = 0; i < 5; i++) r261 = fp_add(r261, r261, P);
+    const Fr k_mont = fp_to_mont(r261, P);
     Fr acc = first;
-    for (size_t i = 0; i < count; i++) { h[i] = acc; acc = fp_mul(acc, base, P); }
-    HIP_TRY(hipMalloc((void**)d_out, count * sizeof(Fr)));
-    HIP_TRY(hipMemcpyAsync(*d_out, h.data(), count * sizeof(Fr), hipMemcpyHostToDevice, stream));
+    for (size_t i = 0; i < count; i++) {
+        h[i] = f29_from_sat(fp_from_mont(fp_mul(acc, k_mont, P), P));
+        acc = fp_mul(acc, base, P);
+    }
+    HIP_TRY(hipMalloc((void**)d_out, count * sizeof(F29)));
+    HIP_TRY(hipMemcpyAsync(*d_out, h.data(), count * sizeof(F29), hipMemcpyHostToDevice, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     return PLONK_OK;
 }
@@ -33,6 +41,7 @@ static int upload_powers(Fr** d_out, const Fr& base, size_t count, const Fr& fir
 int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
     T.curve = curve;
     T.fp = fr_params(curve);
+    T.fp29 = f29_make_params(T.fp);
     const FrParams& P = T.fp;
     const uint32_t* root_l = curve == PLONK_BN254 ? BN254_FR_TWO_ADIC_ROOT_MONT : BLS12_381_FR_TWO_ADIC_ROOT_MONT;
     const uint32_t* g_l = curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
@@ -75,10 +84,10 @@ void ntt_tables_destroy(NttTables& T) {
 }
 
 // w^-e * 2^-log_m for e < 2^lt (inverse transforms of size 2^log_m fold their 1/M here)
-static int get_scaled_lo(NttTables& T, int log_m, Fr** out, hipStream_t stream) {
+static int get_scaled_lo(NttTables& T, int log_m, F29** out, hipStream_t stream) {
     auto it = T.tw_lo_scaled.find(log_m);
     if (it != T.tw_lo_scaled.end()) { *out = it->second; return PLONK_OK; }
-    Fr* d = nullptr;
+    F29* d = nullptr;
     int rc = upload_powers(&d, T.h_root[1], (size_t)1 << T.lt, T.h_pow2_inv[log_m], T.fp, stream);
     if (rc) return rc;
     T.tw_lo_scaled[log_m] = d;
@@ -100,10 +109,9 @@ std::vector<int> ntt_plan_widths(int log_m) {
 static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
 
 static int pref_log_t(int log_r) {
-    if (log_r >= 10) return 2;
-    if (log_r == 9) return 3;
-    if (log_r < 3) return 9;  // EPT = R there: one lane per column, at most 512 lanes
-    return 11 - log_r;        // 2048-element tiles (64 KiB)
+    if (log_r >= 9) return 3;  // 4096-element tile: 144 KiB of the CU's 160 KiB LDS
+    if (log_r < 3) return 9;   // EPT = R there: one lane per column, at most 512 lanes
+    return 11 - log_r;         // 2048-element tiles (72 KiB: two workgroups per CU)
 }
 
 bool ntt_single_pass_inplace_ok(const NttCall& c) {
@@ -155,7 +163,6 @@ static hipError_t launch_pass(int log_r, const NttPassParams& P, uint64_t grid, 
         case 7: return launch_one<7>(P, grid, threads, lds, s);
         case 8: return launch_one<8>(P, grid, threads, lds, s);
         case 9: return launch_one<9>(P, grid, threads, lds, s);
-        case 10: return launch_one<10>(P, grid, threads, lds, s);
     }
     return hipErrorInvalidValue;
 }
@@ -182,7 +189,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         const bool last = (p == NP - 1);
         NttPassParams P;
         memset(&P, 0, sizeof P);
-        P.fp = T.fp;
+        P.fp = T.fp29;
         P.tw_small = T.tw_small[dir];
         P.tw_lo = T.tw_lo[dir];
         P.tw_hi = T.tw_hi[dir];
@@ -195,7 +202,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
             P.out = const_cast<Fr*>(c.in);
             P.tw_shift = T.two_adicity - ilog2(r_prev);
             if (p == 0 && c.inverse) {
-                Fr* scaled = nullptr;
+                F29* scaled = nullptr;
                 int rc = get_scaled_lo(T, L, &scaled, stream);
                 if (rc) return rc;
                 P.tw_lo = scaled;
@@ -267,25 +274,19 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
             if (c.out_layout == NTT_CONTIGUOUS) { P.oq = M; P.ok = 1; } else { P.oq = 1; P.ok = Bt; }
             P.split_log = c.split_log;
             P.split_blk = c.split_blk;
-            if (c.inverse && NP == 1) { P.scale_const_enabled = 1; P.scale_const = T.h_pow2_inv[L]; }
+            if (c.inverse && NP == 1) { P.scale_const_enabled = 1; P.scale_const = f29_const_from_mont256(T.h_pow2_inv[L], T.fp); }
             P.epi = make_scale(T, c.epi, c.q_offset);
-            // LDS pitch: +1 word of padding when lanes walk `a` on load, if it fits
-            const uint64_t Tt = (uint64_t)1 << P.log_t;
-            P.tile_pitch = (uint32_t)Tt;
-            if (P.load_a_fast) {
-                size_t padded = 8 * R * (Tt + 1) * 4 + std::max<size_t>(R / 2, 1) * 32;
-                if (padded <= 150 * 1024) P.tile_pitch = (uint32_t)(Tt + 1);
-            }
+            P.tile_pitch = (uint32_t)((uint64_t)1 << P.log_t);
         }
         if (p == 0) P.pro = make_scale(T, c.pro, c.q_offset);
         const uint64_t Tt = (uint64_t)1 << P.log_t;
         const uint32_t ept = (w >= 3) ? 8 : (uint32_t)R;
         const uint32_t threads = (uint32_t)(R * Tt / ept);
-        const size_t lds = (size_t)8 * R * P.tile_pitch * 4 + std::max<size_t>(R / 2, 1) * 32;
+        const size_t lds = (size_t)9 * R * P.tile_pitch * 4 + std::max<size_t>(R / 2, 1) * 36;
         if (grid == 0 || grid > 0x7fffffffull) return plonk_fail(PLONK_ERR_ARG, "ntt_run: grid %llu out of range", (unsigned long long)grid);
-        static const char* const kNames[11] = {"", "ntt_pass_kernel<1>", "ntt_pass_kernel<2>", "ntt_pass_kernel<3>", "ntt_pass_kernel<4>",
+        static const char* const kNames[10] = {"", "ntt_pass_kernel<1>", "ntt_pass_kernel<2>", "ntt_pass_kernel<3>", "ntt_pass_kernel<4>",
                                                "ntt_pass_kernel<5>", "ntt_pass_kernel<6>", "ntt_pass_kernel<7>", "ntt_pass_kernel<8>",
-                                               "ntt_pass_kernel<9>", "ntt_pass_kernel<10>"};
+                                               "ntt_pass_kernel<9>"};
         hipError_t e;
         {
             ProfScope ps_all("ntt_pass_kernel", stream);

@@ -14,27 +14,29 @@
 //   pass P   : contiguous runs of R_P elements get a size-R_P NTT and are scattered to their
 //              natural-order position  m + j*(M/R_P)  (m = mixed-radix digit reversal of the run index).
 //   One workgroup owns a tile of T columns x R_p elements: HBM is touched in T*32-byte (coalesced
-//   256-bit-limb) pieces, exactly once per pass; butterflies run out of LDS (limb-major SoA so that
-//   consecutive lanes hit consecutive banks), 8 elements per lane held in VGPRs for up to three
-//   radix-2 stages between LDS exchanges.  The in-LDS transform is decimation-in-frequency, so the
-//   last stage carries no multiplication; the bit-reversed result order is undone for free in the
-//   store addressing.
+//   256-bit-limb) pieces, exactly once per pass, in the reference's 8x32-bit Montgomery layout.
+//   Inside the kernel elements live as 9 x 29-bit limbs (fp29.cuh): butterflies run out of LDS
+//   (limb-major SoA: consecutive lanes hit consecutive banks), 8 elements per lane are held in
+//   VGPRs for up to three decimation-in-time stages between LDS exchanges; reduction is lazy
+//   (bounds grow by 2p per stage), only the final store canonicalises.  The bit-reversed input
+//   order DIT needs is produced for free by the load addressing; its first stage has no products.
 //
 // Roofline: algorithmic bytes 2*32 B per element per transform; the kernels are
 // VALU (v_mad_u64_u32) bound, not HBM bound — see DESIGN.md.
 #pragma once
 #include "fp.cuh"
+#include "fp29.cuh"
 
 typedef Fp<8> Fr;
 typedef FpParams<8> FrParams;
 
-#define NTT_LOG_RMAX 10   // largest in-LDS transform (2^10 elements)
+#define NTT_LOG_RMAX 9    // largest in-LDS transform (2^9 elements: 4096-element tile x 36 B = 144 KiB)
 #define NTT_MAX_PASSES 4
 
-// exponent = idx * (bq*q + b0) + (aq*q + a0); value = lo[e & mask] * hi[e >> lt]
+// exponent = idx * (bq*q + b0) + (aq*q + a0); value = lo[e & mask] * hi[e >> lt]   (constants: c*2^261 mod p)
 struct TwoLevelScale {
-    const Fr* lo;       // base^e,        e < 2^lt
-    const Fr* hi;       // base^(e<<lt),  e < 2^lt   (may be null when exponents are < 2^lt)
+    const F29* lo;
+    const F29* hi;
     uint64_t aq, a0, bq, b0;
     uint32_t lt;
     uint32_t enabled;
@@ -43,10 +45,10 @@ struct TwoLevelScale {
 struct NttPassParams {
     const Fr* in;
     Fr* out;
-    FrParams fp;
-    const Fr* tw_small;       // w_Rmax^e, e < Rmax/2 (direction already chosen)
-    const Fr* tw_lo;          // w_Nmax^e, e < 2^tw_lt      (inter-pass twiddles; may carry 1/N)
-    const Fr* tw_hi;          // w_Nmax^(e << tw_lt)
+    F29Params fp;
+    const F29* tw_small;      // w_Rmax^e, e < Rmax/2 (direction already chosen)
+    const F29* tw_lo;         // w_Nmax^e, e < 2^tw_lt      (inter-pass twiddles; may carry 1/N)
+    const F29* tw_hi;         // w_Nmax^(e << tw_lt)
     uint32_t tw_lt;
     uint32_t tw_shift;        // exponent = (b*i) << tw_shift   (log Nmax - log r_{p-1})
     uint32_t log_t;           // tile columns
@@ -73,7 +75,7 @@ struct NttPassParams {
     int32_t split_log;                    // >=0: out = (k>>split_log)*split_blk + q<<split_log + (k & mask)
     uint64_t split_blk;
     uint32_t scale_const_enabled;         // multiply outputs by `scale_const` (1/N when P==1)
-    Fr scale_const;
+    F29 scale_const;
     TwoLevelScale pro;                    // prologue (first pass) scale, idx = pos
     TwoLevelScale epi;                    // epilogue (last pass) scale, idx = k
 };
@@ -91,17 +93,26 @@ __device__ __forceinline__ void store_fr(Fr* p, const Fr& v) {
     q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
     q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
+__device__ __forceinline__ F29 load_f29(const F29* p) {
+    F29 r;
+    const uint32_t* q = reinterpret_cast<const uint32_t*>(p);
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = q[i];
+    return r;
+}
+__device__ __forceinline__ F29 params_one(const F29Params& P) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = P.one[i];
+    return r;
+}
 
-__device__ __forceinline__ Fr two_level(const TwoLevelScale& s, uint64_t idx, uint64_t q, const FrParams& fp) {
-    uint64_t e = idx * (s.bq * q + s.b0) + (s.aq * q + s.a0);
-    uint64_t mask = ((uint64_t)1 << s.lt) - 1;
-    Fr v = load_fr(s.lo + (e & mask));
-    uint64_t eh = e >> s.lt;
-    if (s.hi != nullptr) {
-        Fr h = load_fr(s.hi + (eh & mask));
-        v = fp_mul(v, h, fp);
-    }
-    return v;
+__device__ __forceinline__ F29 two_level(const TwoLevelScale& s, uint64_t idx, uint64_t q, const F29Params& fp) {
+    const uint64_t e = idx * (s.bq * q + s.b0) + (s.aq * q + s.a0);
+    const uint64_t mask = ((uint64_t)1 << s.lt) - 1;
+    F29 v = load_f29(s.lo + (e & mask));
+    F29 h = load_f29(s.hi + ((e >> s.lt) & mask));
+    return f29_mul(v, h, fp);
 }
 
 __device__ __forceinline__ uint32_t brev(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0; }
@@ -110,55 +121,62 @@ __device__ __forceinline__ uint32_t brev(uint32_t x, int bits) { return bits ? (
 struct LdsTile {
     uint32_t* base;
     uint32_t plane;
-    __device__ __forceinline__ Fr get(uint32_t idx) const {
-        Fr r;
+    __device__ __forceinline__ F29 get(uint32_t idx) const {
+        F29 r;
 #pragma unroll
-        for (int l = 0; l < 8; l++) r.l[l] = base[l * plane + idx];
+        for (int l = 0; l < 9; l++) r.l[l] = base[l * plane + idx];
         return r;
     }
-    __device__ __forceinline__ void put(uint32_t idx, const Fr& v) const {
+    __device__ __forceinline__ void put(uint32_t idx, const F29& v) const {
 #pragma unroll
-        for (int l = 0; l < 8; l++) base[l * plane + idx] = v.l[l];
+        for (int l = 0; l < 9; l++) base[l * plane + idx] = v.l[l];
     }
 };
 
-// K radix-2 DIF stages (s0 .. s0+K-1 of a size-2^LOG_R transform) on the EPT elements a lane holds.
-template <int LOG_R, int K, int EPT>
-__device__ __forceinline__ void ntt_step(const LdsTile& tile, const Fr* tw_lds, int s0, uint32_t w, uint32_t t,
-                                         uint32_t pitch, const FrParams& fp) {
+// K radix-2 decimation-in-time stages (s0 .. s0+K-1 of a size-2^LOG_R transform whose input sits in
+// bit-reversed order) on the EPT elements a lane holds.  Tile contents are normalised on entry and exit.
+template <int LOG_R, int K, int EPT, bool FIRST>
+__device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw_lds, int s0, uint32_t w, uint32_t t,
+                                         uint32_t pitch, const F29Params& fp) {
     constexpr int R = 1 << LOG_R;
     constexpr int RADIX = 1 << K;
     constexpr int NG = EPT / RADIX;
     constexpr int GROUPS_PER_STRIDE = R / EPT;     // lanes along `w`
-    const int logh = LOG_R - s0 - K;
-    const uint32_t h = 1u << logh;
-    const bool last_step = (logh == 0);
+    constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
+    const uint32_t h = 1u << s0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const uint32_t G = w + g * GROUPS_PER_STRIDE;
-        const uint32_t lo = G & (h - 1), hi = G >> logh;
-        const uint32_t a0 = (hi << (logh + K)) | lo;
-        Fr v[RADIX];
+        const uint32_t lo = G & (h - 1), hi = G >> s0;
+        const uint32_t a0 = (hi << (s0 + K)) | lo;
+        F29 v[RADIX];
 #pragma unroll
         for (int k = 0; k < RADIX; k++) v[k] = tile.get((a0 + k * h) * pitch + t);
 #pragma unroll
         for (int ds = 0; ds < K; ds++) {
-            const int span = RADIX >> (ds + 1);
+            const int span = 1 << ds;
 #pragma unroll
             for (int k = 0; k < RADIX; k++) {
                 if (k & span) continue;
                 const int kk = k & (span - 1);
-                Fr x = v[k], y = v[k + span];
-                v[k] = fp_add(x, y, fp);
-                Fr d = fp_sub(x, y, fp);
-                // twiddle exponent ((lo + kk*h) << (s0+ds)); it is 0 when lo==0 && kk==0
-                if (last_step && kk == 0) {
-                    v[k + span] = d;                      // w = 1 (lo == 0 in the last step)
+                F29 tt;
+                if (FIRST && ds == 0) {
+                    tt = v[k + span];                                  // w^0 = 1: the first DIT stage has no products
                 } else {
-                    const uint32_t e = (lo + kk * h) << (s0 + ds);
-                    Fr tw = load_fr(tw_lds + e);
-                    v[k + span] = fp_mul(d, tw, fp);
+                    const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
+                    F29 tw;
+#pragma unroll
+                    for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
+                    tt = f29_mul(v[k + span], tw, fp);
                 }
+                const F29 x = v[k];
+                v[k] = f29_add(x, tt);
+                v[k + span] = f29_sub2p(x, tt, fp);
+                __builtin_amdgcn_sched_barrier(0);                     // keep one butterfly's temporaries live at a time
+            }
+            if (ds == 1 || ds == K - 1) {
+#pragma unroll
+                for (int k = 0; k < RADIX; k++) f29_norm(v[k]);
             }
         }
 #pragma unroll
@@ -170,6 +188,7 @@ template <int LOG_R>
 __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
     constexpr int R = 1 << LOG_R;
     constexpr int EPT = (LOG_R >= 3) ? 8 : R;
+    constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t T = 1u << P.log_t;
     const uint32_t pitch = P.tile_pitch;
@@ -177,7 +196,7 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
     const uint32_t nthreads = (R * T) / EPT;
     const uint32_t u = threadIdx.x;
     LdsTile tile{smem, plane};
-    Fr* tw_lds = reinterpret_cast<Fr*>(smem + 8 * plane);
+    uint32_t* tw_lds = smem + 9 * plane;            // limb-major: word(l, e) = l*TWN + e
 
     // ---- tile decode (scalar)
     const uint64_t ti = blockIdx.x;
@@ -186,61 +205,66 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
     const uint64_t b0 = x0 * P.bs0 + x1 * P.bs1;
     const uint64_t q0 = x0 * P.qs0 + x1 * P.qs1 + x2 * P.qs2;
 
-    // ---- small twiddle table -> LDS : tw_lds[e] = w_R^e , e < R/2
-    for (uint32_t e = u; e < (R / 2 > 0 ? R / 2 : 1); e += nthreads)
-        store_fr(tw_lds + e, load_fr(P.tw_small + ((uint64_t)e << (NTT_LOG_RMAX - LOG_R))));
+    // ---- small twiddle table -> LDS : w_R^e , e < R/2
+    for (uint32_t e = u; e < TWN; e += nthreads) {
+        const F29 tw = load_f29(P.tw_small + ((uint64_t)e << (NTT_LOG_RMAX - LOG_R)));
+#pragma unroll
+        for (int l = 0; l < 9; l++) tw_lds[l * TWN + e] = tw.l[l];
+    }
 
-    // ---- load tile
+    // ---- load tile (element a of the column goes to LDS row brev(a): DIT input order)
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const uint32_t e = u + i * nthreads;
         uint32_t a, t;
         if (P.load_a_fast) { a = e & (R - 1); t = e >> LOG_R; }
         else               { t = e & (T - 1); a = e >> P.log_t; }
-        Fr v = load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride);
+        F29 v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));
         if (P.pro.enabled) {
             const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
-            Fr s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
-            v = fp_mul(v, s, P.fp);
+            const F29 s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
+            v = f29_mul(v, s, P.fp);
         }
-        tile.put(a * pitch + t, v);
+        tile.put(brev(a, LOG_R) * pitch + t, v);
     }
     __syncthreads();
 
-    // ---- in-LDS DIF transform, stages grouped (LOG_R % 3 first, then threes)
+    // ---- in-LDS DIT transform, stages grouped (LOG_R % 3 first, then threes)
     {
         const uint32_t t = u & (T - 1), w = u >> P.log_t;
         constexpr int K0 = LOG_R % 3;
-        int s = 0;
         if constexpr (LOG_R < 3) {
-            ntt_step<LOG_R, LOG_R, EPT>(tile, tw_lds, 0, w, t, pitch, P.fp);
-        } else {
-            if constexpr (K0 != 0) {
-                ntt_step<LOG_R, K0, EPT>(tile, tw_lds, 0, w, t, pitch, P.fp);
-                s = K0;
+            ntt_step<LOG_R, LOG_R, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            __syncthreads();
+        } else if constexpr (K0 != 0) {
+            ntt_step<LOG_R, K0, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            __syncthreads();
+#pragma unroll 1
+            for (int s = K0; s < LOG_R; s += 3) {
+                ntt_step<LOG_R, 3, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
                 __syncthreads();
             }
+        } else {
+            ntt_step<LOG_R, 3, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            __syncthreads();
 #pragma unroll 1
-            for (; s < LOG_R; s += 3) {
-                ntt_step<LOG_R, 3, EPT>(tile, tw_lds, s, w, t, pitch, P.fp);
+            for (int s = 3; s < LOG_R; s += 3) {
+                ntt_step<LOG_R, 3, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
                 __syncthreads();
             }
         }
-        if constexpr (LOG_R < 3) __syncthreads();
     }
 
-    // ---- store: LDS position a holds output index i = brev(a)
+    // ---- store: LDS row i holds output index i
     uint64_t m0 = 0;
     if (P.is_last) {
         m0 = x0 * P.ms0;
-        uint64_t rest = x1;
-        // x1 holds rev_ndig digits, most significant first; digit d goes to shift rev_shift0 + sum of earlier widths
         uint32_t total = 0;
         for (uint32_t d = 0; d < P.rev_ndig; d++) total += P.rev_w[d];
         uint32_t sh = P.rev_shift0, consumed = 0;
-        for (uint32_t d = 0; d < P.rev_ndig; d++) {
+        for (uint32_t d = 0; d < P.rev_ndig; d++) {      // x1 holds rev_ndig digits, most significant first
             consumed += P.rev_w[d];
-            const uint64_t dig = (rest >> (total - consumed)) & (((uint64_t)1 << P.rev_w[d]) - 1);
+            const uint64_t dig = (x1 >> (total - consumed)) & (((uint64_t)1 << P.rev_w[d]) - 1);
             m0 |= dig << sh;
             sh += P.rev_w[d];
         }
@@ -249,33 +273,35 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const uint32_t e = u + i * nthreads;
-        const uint32_t t = e & (T - 1), a = e >> P.log_t;
-        const uint32_t idx = brev(a, LOG_R);
-        Fr v = tile.get(a * pitch + t);
+        const uint32_t t = e & (T - 1), idx = e >> P.log_t;
+        F29 v = tile.get(idx * pitch + t);
         if (!P.is_last) {
             const uint64_t b = b0 + (uint64_t)t * P.tb;
             const uint64_t ex = (b * idx) << P.tw_shift;
             const uint64_t mask = ((uint64_t)1 << P.tw_lt) - 1;
-            Fr tw = load_fr(P.tw_lo + (ex & mask));
-            const uint64_t eh = (ex >> P.tw_lt) & mask;
-            Fr th = load_fr(P.tw_hi + eh);
-            tw = fp_mul(tw, th, P.fp);
-            v = fp_mul(v, tw, P.fp);
-            store_fr(P.out + sbase + (uint64_t)idx * P.s_istride + (uint64_t)t * P.s_tstride, v);
+            const F29 tl = load_f29(P.tw_lo + (ex & mask));
+            const F29 th = load_f29(P.tw_hi + ((ex >> P.tw_lt) & mask));
+            v = f29_mul(v, f29_mul(tl, th, P.fp), P.fp);
+            // < 1.36 p < 2^256: stored re-packed but not canonicalised (the next pass does not care)
+            store_fr(P.out + sbase + (uint64_t)idx * P.s_istride + (uint64_t)t * P.s_tstride, f29_to_sat(v));
         } else {
             const uint64_t q = q0 + (uint64_t)t * P.tq;
             const uint64_t k = m0 + (uint64_t)t * P.tk + (uint64_t)idx * P.kstride;
-            if (P.scale_const_enabled) v = fp_mul(v, P.scale_const, P.fp);
             if (P.epi.enabled) {
-                Fr s = two_level(P.epi, k, q, P.fp);
-                v = fp_mul(v, s, P.fp);
+                v = f29_mul(v, two_level(P.epi, k, q, P.fp), P.fp);
+                if (P.scale_const_enabled) v = f29_mul(v, P.scale_const, P.fp);
+            } else if (P.scale_const_enabled) {
+                v = f29_mul(v, P.scale_const, P.fp);
+            } else {
+                v = f29_mul(v, params_one(P.fp), P.fp);          // brings the lazy value below 1.36 p
             }
+            v = f29_canon(v, P.fp);
             uint64_t addr;
             if (P.split_log >= 0)
                 addr = (k >> P.split_log) * P.split_blk + (q << P.split_log) + (k & (((uint64_t)1 << P.split_log) - 1));
             else
                 addr = q * P.oq + k * P.ok;
-            store_fr(P.out + addr, v);
+            store_fr(P.out + addr, f29_to_sat(v));
         }
     }
 }

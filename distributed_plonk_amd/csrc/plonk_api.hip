@@ -57,10 +57,9 @@ struct plonk_ctx {
     int device = 0, curve = 0;
     hipStream_t stream = nullptr;
     NttTables tables;
-    // SRS (State.bases)
+    // SRS (State.bases), kept in the MSM's resident limb form (flimb.cuh)
     void* d_bases = nullptr;
     size_t n_bases = 0;
-    bool bases_external = false;
     // domains (State.domain / quot_domain and their r/c splits are derived on demand)
     size_t domain_size = 0, quot_domain_size = 0;
     std::map<uint64_t, FftTask> tasks;          // State.fft_tasks
@@ -166,7 +165,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
     ntt_tables_destroy(ctx->tables);
-    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
+    if (ctx->d_bases) hipFree(ctx->d_bases);
     if (ctx->d_wire) hipFree(ctx->d_wire);
     if (ctx->d_scratch) hipFree(ctx->d_scratch);
     if (ctx->d_scratch2) hipFree(ctx->d_scratch2);
@@ -230,20 +229,25 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
     if (base_layout != PLONK_BASES_XY && base_layout != PLONK_BASES_ARK) return plonk_fail(PLONK_ERR_ARG, "plonk_init: layout %d", base_layout);
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
-    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
-    ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->bases_external = false;
+    if (ctx->d_bases) hipFree(ctx->d_bases);
+    ctx->d_bases = nullptr; ctx->n_bases = 0;
     if (n_bases) {
         const size_t ab = aff_bytes(ctx->curve);
-        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * ab));
+        void* d_xy = nullptr;
+        HIP_TRY(hipMalloc(&d_xy, n_bases * ab));
         if (base_layout == PLONK_BASES_XY) {
-            HIP_TRY(hipMemcpyAsync(ctx->d_bases, bases, n_bases * ab, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(d_xy, bases, n_bases * ab, hipMemcpyHostToDevice, ctx->stream));
         } else {
             const size_t rb = ark_aff_bytes(ctx->curve) * n_bases;
             if ((rc = ensure_scratch(ctx, rb))) return rc;
             HIP_TRY(hipMemcpyAsync(ctx->d_scratch, bases, rb, hipMemcpyHostToDevice, ctx->stream));
-            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, ctx->d_bases, ctx->stream))) return rc;
+            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy, ctx->stream))) return rc;
         }
+        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * msm_limb_base_bytes(ctx->curve)));
+        rc = bases_to_limbs(ctx->curve, d_xy, n_bases, ctx->d_bases, ctx->stream);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        (void)hipFree(d_xy);
+        if (rc) return rc;
         ctx->n_bases = n_bases;
     }
     return PLONK_OK;
@@ -251,12 +255,17 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
 
 extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size, size_t quot_domain_size) {
     CHECK_CTX(ctx);
+    if (n_bases && !d_bases_xy) return plonk_fail(PLONK_ERR_ARG, "plonk_init_dev: null bases");
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
-    if (ctx->d_bases && !ctx->bases_external) hipFree(ctx->d_bases);
-    ctx->d_bases = const_cast<void*>(d_bases_xy);
-    ctx->n_bases = n_bases;
-    ctx->bases_external = true;
+    if (ctx->d_bases) hipFree(ctx->d_bases);
+    ctx->d_bases = nullptr; ctx->n_bases = 0;
+    if (n_bases) {
+        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * msm_limb_base_bytes(ctx->curve)));
+        if ((rc = bases_to_limbs(ctx->curve, d_bases_xy, n_bases, ctx->d_bases, ctx->stream))) return rc;
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ctx->n_bases = n_bases;
+    }
     return PLONK_OK;
 }
 
@@ -268,7 +277,7 @@ static int msm_device(plonk_ctx* ctx, size_t start, size_t n, const uint32_t* d_
         return msm_jac_add_host(ctx->curve, (uint32_t*)a, (uint32_t*)b, (uint32_t*)out_jac);
     }
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * aff_bytes(ctx->curve), d_scalars, n, (uint32_t*)out_jac, ctx->msm_ws,
+    int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * msm_limb_base_bytes(ctx->curve), d_scalars, n, (uint32_t*)out_jac, ctx->msm_ws,
                      ctx->msm_window, ctx->stream);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;

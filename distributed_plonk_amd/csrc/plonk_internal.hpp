@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "fp.cuh"
+#include "fp29.cuh"
 #include "../../include/plonk_hip.h"
 
 typedef Fp<8> Fr;
@@ -52,14 +53,16 @@ struct ProfScope {       // RAII: brackets the launches issued in its lifetime
 struct NttTables {
     int curve = 0;
     FrParams fp;
+    F29Params fp29;
     int two_adicity = 0;
     int lt = 0;                       // two-level table split: 2^lt entries per level, 2*lt >= two_adicity
-    Fr* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
-    Fr* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
-    Fr* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
-    Fr* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e
-    Fr* g_hi[2] = {nullptr, nullptr};       // [0] g^(e<<lt) ...
-    std::unordered_map<int, Fr*> tw_lo_scaled;   // key = log_m (inverse only): w^-e * 2^-log_m
+    // all device tables hold constants c*2^261 mod p as 9 x 29-bit limbs (fp29.cuh)
+    F29* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
+    F29* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
+    F29* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
+    F29* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e
+    F29* g_hi[2] = {nullptr, nullptr};       // [0] g^(e<<lt) ...
+    std::unordered_map<int, F29*> tw_lo_scaled;   // key = log_m (inverse only): w^-e * 2^-log_m
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };
@@ -104,13 +107,15 @@ struct MsmConfig {
     int curve;
     int window_bits;     // 0 = auto
 };
-// bases: device, compact x||y Montgomery (2*Q u32-limb field elements), infinity encoded as all-zero.
+// bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point).
 // scalars: device, canonical 8xu32.  out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac,
             MsmWorkspace& ws, int window_bits, hipStream_t stream);
 int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);
 int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf);
 int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream);
+int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream_t stream);
+size_t msm_limb_base_bytes(int curve);
 
 // elementwise helpers (device pointers)
 int fr_from_mont_dev(int curve, const Fr* in, Fr* out, size_t n, hipStream_t stream);

@@ -139,7 +139,8 @@ int plonk_synth_fr(plonk_ctx* ctx, uint64_t seed, void* d_out, size_t n);
 /* SRS-like bases in PLONK_BASES_XY layout.  unique > 0: `unique` points k_j*G tiled to n (the
  * distribution of dispatcher.rs:190-196); unique == 0: n pairwise-distinct points A[i%4096] + B[i/4096]. */
 int plonk_synth_bases(plonk_ctx* ctx, uint64_t seed, size_t unique, size_t n, void* d_out);
-/* Use n_bases points already in HBM (PLONK_BASES_XY) as the SRS without a host round trip. */
+/* Use n_bases points already in HBM (PLONK_BASES_XY) as the SRS without a host round trip; they are
+ * re-encoded into the library's resident limb form (72 B / 112 B per point), the caller keeps its buffer. */
 int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size,
                    size_t quot_domain_size);
 /* element-wise field ops on the device, for pinning the arithmetic layer.
