@@ -1,0 +1,169 @@
+"""Pin the C oracle (oracle/plonk_oracle.c) before trusting it.
+
+The reference has no golden vectors or KATs for this path ("parity unpinned" by data),
+so the oracle is pinned by (1) the constants of SURVEY Appendix B, (2) an independent pure-Python
+big-int statement of the same published algorithms (oracle/bigint_ref.py), (3) O(N^2) DFTs and
+double-and-add, (4) the committed tests/golden/*.json, and (5) the identities the reference's own
+tests assert (playground.rs:95-102, dispatcher.rs:240,334-342)."""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import bigint_ref as B
+from oracle import oracle as O
+
+import golden_util as G
+
+CURVES = [("bn254", O.BN254, B.BN254), ("bls12_381", O.BLS12_381, B.BLS12_381)]
+MODES = [(False, False), (True, False), (False, True), (True, True)]
+
+
+def ints(a):
+    return [B.from_limbs(r) for r in a]
+
+
+def to_limbs(vals, n=4):
+    return np.array([B.to_limbs(v, n) for v in vals], dtype=np.uint64)
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_constants_match_survey_appendix_b(name, cid, cv):
+    f = cv.fr
+    assert B.from_limbs(O.field_const(cid, 0, 0)) == f.p
+    assert B.from_limbs(O.field_const(cid, 1, 0)) == cv.fq.p
+    assert B.from_limbs(O.field_const(cid, 0, 1)) == pow(2, 256, f.p)
+    assert B.from_limbs(O.field_const(cid, 1, 1)) == pow(2, 64 * cv.fq.limbs64, cv.fq.p)
+    w = f.from_mont(B.from_limbs(O.field_const(cid, 0, 3)))
+    assert pow(w, 1 << f.two_adicity, f.p) == 1 and pow(w, 1 << (f.two_adicity - 1), f.p) == f.p - 1
+    if name == "bn254":
+        assert f.two_adicity == 28 and f.generator == 5
+        assert w == 19103219067921713944291392827692070036145651957329286315305642004821462161904
+        assert O.field_inv64(cid, 0) == 0xc2e1f593efffffff
+    else:
+        assert f.two_adicity == 32 and f.generator == 7
+        assert w == 10238227357739495823651030575849232062558860180284477541189508159991286009131
+        assert O.field_inv64(cid, 0) == 0xfffffffeffffffff
+    assert O.on_curve(cid, O.generator(cid))
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_field_ops_vs_bigint(name, cid, cv):
+    rng = random.Random(5)
+    for fld, ff in ((0, cv.fr), (1, cv.fq)):
+        n64 = ff.limbs64
+        a = [rng.randrange(ff.p) for _ in range(40)] + [0, 1, ff.p - 1]
+        b = [rng.randrange(ff.p) for _ in range(40)] + [ff.p - 1, 0, ff.p - 1]
+        A, Bm = to_limbs(a, n64), to_limbs(b, n64)
+        rinv = pow(ff.R, -1, ff.p)
+        assert ints(O.field_op(cid, fld, "mul", A, Bm)) == [x * y * rinv % ff.p for x, y in zip(a, b)]
+        assert ints(O.field_op(cid, fld, "add", A, Bm)) == [(x + y) % ff.p for x, y in zip(a, b)]
+        assert ints(O.field_op(cid, fld, "sub", A, Bm)) == [(x - y) % ff.p for x, y in zip(a, b)]
+        assert ints(O.field_op(cid, fld, "from_mont", A)) == [x * rinv % ff.p for x in a]
+        assert ints(O.field_op(cid, fld, "to_mont", A)) == [x * ff.R % ff.p for x in a]
+        nz = [x for x in a if x]
+        assert ints(O.field_op(cid, fld, "inv", to_limbs(nz, n64))) == [pow(x * rinv, -1, ff.p) * ff.R % ff.p for x in nz]
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_ntt_vs_bigint_and_naive_dft(name, cid, cv):
+    f = cv.fr
+    rng = random.Random(6)
+    for n in (1, 2, 4, 32, 256, 2048):
+        v = [rng.randrange(f.p) for _ in range(n)]
+        vm = to_limbs([f.to_mont(x) for x in v])
+        d = B.Radix2Domain(f, n)
+        for inv, coset in MODES:
+            ref = {(False, False): d.fft, (True, False): d.ifft, (False, True): d.coset_fft, (True, True): d.coset_ifft}[(inv, coset)](v)
+            assert ints(O.ntt(cid, vm, inv, coset)) == [f.to_mont(x) for x in ref], (n, inv, coset)
+        if 2 <= n <= 256:
+            assert np.array_equal(O.naive_dft(cid, vm, False), O.ntt(cid, vm, False, False))
+            assert np.array_equal(O.naive_dft(cid, vm, True), O.ntt(cid, vm, True, False))
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_reference_2d_decomposition_equals_direct(name, cid, cv):
+    """playground.rs:95-99, dispatcher.rs:334-342 (2^11 and 2^13: odd log N, c = 2r), dispatcher2.rs:1200-1208."""
+    for log_n in (4, 7, 11, 13):
+        v = O.rand_fr(cid, 40 + log_n, 1 << log_n)
+        for inv, coset in MODES:
+            want = O.ntt(cid, v, inv, coset)
+            assert np.array_equal(O.fourstep(cid, v, inv, coset), want)
+            for S in (1, 2, 4):
+                assert np.array_equal(O.distributed_fft(cid, v, S, inv, coset), want)
+
+
+def test_playground_identities():
+    """playground.rs:100-102."""
+    l = 512
+    exps = O.rand_fr(O.BLS12_381, 3, l)
+    t = np.zeros((2 * l, 4), dtype=np.uint64)
+    t[:l] = exps
+    assert np.array_equal(O.ntt(1, t, False, True), O.ntt(1, np.vstack([exps, np.zeros_like(exps)]), False, True))
+    assert np.array_equal(O.ntt(1, t, False, False), O.fourstep(1, t, False, False))
+    assert np.array_equal(O.ntt(1, O.ntt(1, exps, False, True), True, True), exps)
+
+
+def test_domain_creation_error():
+    """BN254's quotient domain for n = 2^28 does not exist (dispatcher2.rs:246-247)."""
+    buf = np.zeros((2, 4), dtype=np.uint64)
+    assert O.lib().orc_ntt(O.BN254, buf.ctypes.data, 29, 0, 0, 1) == -1          # two-adicity 28
+    assert O.lib().orc_ntt(O.BLS12_381, buf.ctypes.data, 33, 0, 0, 1) == -1      # two-adicity 32
+    with pytest.raises(ValueError):
+        B.Radix2Domain(B.BN254_FR, 1 << 29)
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_msm_vs_bigint(name, cid, cv):
+    rng = random.Random(8)
+    q = cv.fq.limbs64
+    bases = O.gen_bases(cid, 5, 8, 40)                              # 8 unique points tiled (dispatcher.rs:190-196)
+    pts = [(cv.fq.from_mont(B.from_limbs(b[:q])), cv.fq.from_mont(B.from_limbs(b[q:]))) for b in bases]
+    assert all(B.on_curve(cv, P) for P in pts)
+    inf = np.zeros(40, dtype=np.uint8)
+    inf[3] = 1
+    pts[3] = None                                                   # infinity base (dispatcher2.rs:1101)
+    sc = [rng.randrange(cv.fr.p) for _ in pts]
+    sc[0], sc[1], sc[2] = 0, 1, cv.fr.p - 1
+    scl = to_limbs(sc)
+    ref = B.msm_naive(cv, pts, sc)
+    for res in (O.msm(cid, bases, scl, inf, threads=3), O.msm_naive(cid, bases, scl, inf), O.sharded_msm(cid, bases, scl, 4, inf)):
+        xy, isinf = O.jac_to_affine(cid, res)
+        assert not isinf
+        assert (cv.fq.from_mont(B.from_limbs(xy[:q])), cv.fq.from_mont(B.from_limbs(xy[q:]))) == ref
+    # commit_polynomial = into_repr + zero-pad + MSM (worker.rs:117-123)
+    coeffs = O.rand_fr(cid, 77, 30)
+    cm = O.commit_polynomial(cid, bases, coeffs, inf)
+    sc2 = [cv.fr.from_mont(x) for x in ints(coeffs)]
+    xy, isinf = O.jac_to_affine(cid, cm)
+    want = B.msm_naive(cv, pts[:30], sc2)
+    assert (cv.fq.from_mont(B.from_limbs(xy[:q])), cv.fq.from_mont(B.from_limbs(xy[q:]))) == want
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_oracle_matches_golden_fixtures(name, cid, cv):
+    g = G.load(name)
+    assert int(g["fr_modulus"], 16) == cv.fr.p and int(g["fr_R"], 16) == cv.fr.R
+    for e in g["field_mul"]:
+        fld = 0 if e["field"] == "fr" else 1
+        n64 = 4 if fld == 0 else cv.fq.limbs64
+        got = O.field_op(cid, fld, "mul", G.limbs([e["a"]], n64), G.limbs([e["b"]], n64))
+        assert B.from_limbs(got[0]) == int(e["mont_mul"], 16)
+    for e in g["ntt"]:
+        v = G.limbs(e["input_mont"])
+        for key, (inv, coset) in {"fft": (False, False), "ifft": (True, False), "coset_fft": (False, True), "coset_ifft": (True, True)}.items():
+            assert np.array_equal(O.ntt(cid, v, inv, coset), G.limbs(e[key])), (e["log_n"], key)
+    q = cv.fq.limbs64
+    for e in g["msm"]:
+        bases, inf = G.bases_from_golden(e, q)
+        sc = G.limbs(e["scalars"])
+        xy, isinf = O.jac_to_affine(cid, O.msm(cid, bases, sc, inf, threads=2))
+        want = e["result_affine_mont"]
+        assert not isinf and B.from_limbs(xy[:q]) == int(want[0], 16) and B.from_limbs(xy[q:]) == int(want[1], 16)
+
+
+def test_rand_fr_is_uniform_montgomery_draw():
+    for cid, cv in ((O.BN254, B.BN254), (O.BLS12_381, B.BLS12_381)):
+        r = ints(O.rand_fr(cid, 9, 2000))
+        assert all(x < cv.fr.p for x in r) and len(set(r)) == 2000
+        assert np.array_equal(O.rand_fr(cid, 9, 10), O.rand_fr(cid, 9, 2000)[:10])       # per-index streams
