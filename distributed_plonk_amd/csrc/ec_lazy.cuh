@@ -52,6 +52,48 @@ __device__ __attribute__((noinline)) XyzzL<NL, B> xyzzl_dbl_affine(const AffL<NL
     return r;
 }
 
+// -q for affine q: y -> 2p - y  (value in (p, 2p], which every formula below tolerates)
+template <int NL, int B> FP_HD AffL<NL, B> affl_neg(const AffL<NL, B>& q, const FLParams<NL, B>& P) {
+    AffL<NL, B> r;
+    r.x = q.x;
+    r.y = fl_sub(fl_zero<NL, B>(), q.y, P.c2);
+    fl_norm(r.y);
+    return r;
+}
+
+// acc += q without the exceptional cases: returns false (acc untouched) when q has the x of acc
+// (P + P or P + (-P)), which the caller hands to the complete out-of-line path.  q must not be infinity.
+template <int NL, int B>
+__device__ __forceinline__ bool xyzzl_madd_fast(XyzzL<NL, B>& a, const AffL<NL, B>& q, const FLParams<NL, B>& P) {
+    if (fl_all_zero(a.zz)) {
+        a.x = q.x; a.y = q.y;
+        a.zz = fl_load_const<NL, B>(P.one); a.zzz = a.zz;
+        return true;
+    }
+    const FL<NL, B> u2 = fl_mul(q.x, a.zz, P);
+    const FL<NL, B> s2 = fl_mul(q.y, a.zzz, P);
+    FL<NL, B> p = fl_sub(u2, a.x, P.c8);
+    fl_norm(p);
+    FL<NL, B> r = fl_sub(s2, a.y, P.c4);
+    fl_norm(r);
+    const FL<NL, B> pp = fl_mul(p, p, P);
+    if (fl_is_zero_mod_p_lt3p(pp, P)) return false;
+    const FL<NL, B> ppp = fl_mul(p, pp, P);
+    const FL<NL, B> qq = fl_mul(a.x, pp, P);
+    const FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));       // PPP + 2Q, limbs < 3*2^B
+    FL<NL, B> x3 = fl_sub(fl_mul(r, r, P), sub, P.c4);
+    fl_norm(x3);
+    FL<NL, B> t = fl_sub(qq, x3, P.c8);
+    fl_norm(t);
+    FL<NL, B> y3 = fl_sub(fl_mul(r, t, P), fl_mul(a.y, ppp, P), P.c2);
+    fl_norm(y3);
+    a.zz = fl_mul(a.zz, pp, P);
+    a.zzz = fl_mul(a.zzz, ppp, P);
+    a.x = x3;
+    a.y = y3;
+    return true;
+}
+
 // acc + q (madd-2008-s), complete.
 template <int NL, int B>
 __device__ __forceinline__ XyzzL<NL, B> xyzzl_madd(const XyzzL<NL, B>& a, const AffL<NL, B>& q, const FLParams<NL, B>& P) {

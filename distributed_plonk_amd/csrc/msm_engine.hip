@@ -50,22 +50,30 @@ template <typename T> __device__ __forceinline__ void store16(T* p, const T& v) 
     for (unsigned i = 0; i < sizeof(T) / 16; i++) d[i] = s[i];
 }
 
-__device__ __forceinline__ uint32_t scalar_digit(const uint32_t* s, int bit0, int c) {
+// Signed c-bit digits: d_w in [-2^(c-1), 2^(c-1)], sum_w d_w 2^(wc) = s.  Bucket index |d|-1 in [0, 2^(c-1)),
+// the sign travels in bit 31 of the sorted point index (a negative digit adds -P: y -> -y).  Halves the
+// bucket count (and the reduction work) of the unsigned decomposition arkworks uses; the group element
+// is the same.  W*c >= bits+1 guarantees the last carry is absorbed.
+__device__ __forceinline__ uint32_t scalar_raw_digit(const uint32_t* s, int bit0, int c) {
     const int limb = bit0 >> 5, off = bit0 & 31;
+    if (limb >= 8) return 0;
     uint64_t v = s[limb];
     if (limb + 1 < 8) v |= (uint64_t)s[limb + 1] << 32;
     return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
-// ---------------------------------------------------------------------------------------------- 1/3: histogram + scatter
 __global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
                                                         uint32_t* __restrict__ counts) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t half = 1u << (c - 1);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t* s = scalars + 8 * i;
+        uint32_t carry = 0;
         for (int w = 0; w < W; w++) {
-            const uint32_t d = scalar_digit(s, w * c, c);
-            if (d) atomicAdd(&counts[((uint64_t)w << c) + d], 1u);
+            uint32_t raw = scalar_raw_digit(s, w * c, c) + carry;
+            carry = raw > half;
+            const uint32_t mag = carry ? (1u << c) - raw : raw;
+            if (mag) atomicAdd(&counts[((uint64_t)w << (c - 1)) + (mag - 1)], 1u);
         }
     }
 }
@@ -74,17 +82,66 @@ __global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t* __rest
                                                           const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
                                                           uint32_t* __restrict__ sorted) {
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t half = 1u << (c - 1);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t* s = scalars + 8 * i;
+        uint32_t carry = 0;
         for (int w = 0; w < W; w++) {
-            const uint32_t d = scalar_digit(s, w * c, c);
-            if (d) {
-                const uint64_t b = ((uint64_t)w << c) + d;
+            uint32_t raw = scalar_raw_digit(s, w * c, c) + carry;
+            carry = raw > half;
+            const uint32_t mag = carry ? (1u << c) - raw : raw;
+            if (mag) {
+                const uint64_t b = ((uint64_t)w << (c - 1)) + (mag - 1);
                 const uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
-                sorted[pos] = (uint32_t)i;
+                sorted[pos] = (uint32_t)i | (carry << 31);
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------- 3b: schedule buckets by size
+// One lane owns one bucket, so a wave runs as long as its fullest bucket.  A counting sort of the bucket
+// ids by (clamped) size, largest first, puts equally loaded buckets in the same wave.
+#define SIZE_BINS 256
+__device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint64_t b) {
+    const uint32_t sz = offsets[b + 1] - offsets[b];
+    return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
+}
+__global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint32_t* __restrict__ ghist) {
+    __shared__ uint32_t h[SIZE_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbuckets) atomicAdd(&h[size_bin(offsets, b)], 1u);
+    __syncthreads();
+    if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ bin_cursor) {
+    __shared__ uint32_t buf[SIZE_BINS];
+    const uint32_t v = ghist[threadIdx.x];
+    buf[threadIdx.x] = v;
+    __syncthreads();
+    for (int d = 1; d < SIZE_BINS; d <<= 1) {
+        uint32_t t = (int)threadIdx.x >= d ? buf[threadIdx.x - d] : 0;
+        __syncthreads();
+        buf[threadIdx.x] += t;
+        __syncthreads();
+    }
+    bin_cursor[threadIdx.x] = buf[threadIdx.x] - v;
+}
+__global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint32_t* __restrict__ bin_cursor,
+                                                                uint32_t* __restrict__ order) {
+    __shared__ uint32_t h[SIZE_BINS];
+    __shared__ uint32_t base[SIZE_BINS];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t bin = 0, rank = 0;
+    if (b < nbuckets) { bin = size_bin(offsets, b); rank = atomicAdd(&h[bin], 1u); }
+    __syncthreads();
+    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], h[threadIdx.x]);
+    __syncthreads();
+    if (b < nbuckets) order[base[bin] + rank] = (uint32_t)b;
 }
 
 // ---------------------------------------------------------------------------------------------- 2: exclusive scan (u32)
@@ -194,19 +251,9 @@ __global__ void __launch_bounds__(256) bases_to_limbs_kernel(const AffPt<NQ>* __
 }
 
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
-                                                             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                             uint64_t nbuckets, XyzzPt<NQ>* __restrict__ buckets,
-                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+__device__ __forceinline__ void store_bucket(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& acc,
+                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
-    const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nbuckets) return;
-    const uint32_t beg = offsets[b], end = offsets[b + 1];
-    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-    for (uint32_t j = beg; j < end; j++) {
-        const AffL<NL, B> q = load8(bases + sorted[j]);
-        acc = xyzzl_madd(acc, q, P);
-    }
     // back to the canonical R = 2^(32N) Montgomery form the rest of the pipeline (and the reference) uses
     const FL<NL, B> rs = fl_load_const<NL, B>(P.r_std);
     XyzzPt<NQ> o;
@@ -214,36 +261,86 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
     o.y = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.y, rs, P), P));
     o.zz = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.zz, rs, P), P));
     o.zzz = fl_to_sat<NL, B, NQ>(fl_canon_lt2p(fl_mul(acc.zzz, rs, P), P));
-    store16(buckets + b, o);
+    store16(dst, o);
+}
+
+// Hot kernel: lane i owns bucket order[i] (size-sorted).  Exceptional additions (same x) abort the
+// bucket, which is queued for msm_accumulate_redo_kernel — keeps calls, scratch and the doubling
+// formula out of this kernel.
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+                                                             const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                             const uint32_t* __restrict__ order, uint64_t nbuckets,
+                                                             XyzzPt<NQ>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
+                                                             uint32_t* __restrict__ redo_list,
+                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbuckets) return;
+    const uint32_t b = order[i];
+    const uint32_t beg = offsets[b], end = offsets[b + 1];
+    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+    bool ok = true;
+    for (uint32_t j = beg; j < end; j++) {
+        const uint32_t e = sorted[j];
+        AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
+        if (affl_is_inf(q)) continue;
+        if (e >> 31) q = affl_neg(q, P);
+        if (!xyzzl_madd_fast(acc, q, P)) { ok = false; break; }
+    }
+    if (ok) store_bucket<NQ>(buckets + b, acc, P);
+    else redo_list[atomicAdd(redo_count, 1u)] = b;
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                                 XyzzPt<NQ>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
+                                                                 const uint32_t* __restrict__ redo_list,
+                                                                 const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint32_t total = *redo_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint32_t b = redo_list[i];
+        const uint32_t beg = offsets[b], end = offsets[b + 1];
+        XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+        for (uint32_t j = beg; j < end; j++) {
+            const uint32_t e = sorted[j];
+            AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
+            if (affl_is_inf(q)) continue;
+            if (e >> 31) q = affl_neg(q, P);
+            acc = xyzzl_madd(acc, q, P);
+        }
+        store_bucket<NQ>(buckets + b, acc, P);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- 5: window reduction
-// chunk (w, ch) covers digits d in [ch*K, (ch+1)*K): out = sum_d d * B_d
+// chunk (w, ch) covers bucket indices j in [ch*K, (ch+1)*K) of a window with 2^cb buckets (bucket j holds
+// the digit magnitude j+1): out = sum_j (j+1) * B_j
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_reduce_chunks_kernel(const XyzzPt<NQ>* __restrict__ buckets, int c, int logk, uint64_t nchunks_total,
+__global__ void __launch_bounds__(256) msm_reduce_chunks_kernel(const XyzzPt<NQ>* __restrict__ buckets, int cb, int logk, uint64_t nchunks_total,
                                                                 XyzzPt<NQ>* __restrict__ chunk_out, const FpParams<NQ> P) {
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= nchunks_total) return;
-    const uint64_t nch = (uint64_t)1 << (c - logk);
+    const uint64_t nch = (uint64_t)1 << (cb - logk);
     const uint64_t w = id / nch, ch = id % nch;
     const uint64_t K = (uint64_t)1 << logk;
-    const XyzzPt<NQ>* B = buckets + (w << c) + ch * K;
+    const XyzzPt<NQ>* Bk = buckets + (w << cb) + ch * K;
     XyzzPt<NQ> running = xyzz_inf<NQ>(), acc = xyzz_inf<NQ>();
     for (uint64_t d = K; d-- > 0;) {
         acc = xyzz_add_cold(acc, running, P);
-        const XyzzPt<NQ> bd = load16(B + d);
+        const XyzzPt<NQ> bd = load16(Bk + d);
         running = xyzz_add_cold(running, bd, P);
     }
-    // acc = sum (d - lo) B_d ; add lo * S, lo = ch*K
-    if (ch != 0 && !xyzz_is_inf(running)) {
-        XyzzPt<NQ> t = running;
-        // t = ch * S (MSB-first double-and-add over the c-logk bits of ch), then K doublings
+    // acc = sum (j - lo) B_j ; add (lo + 1) * S, lo = ch*K  (MSB-first double-and-add)
+    if (!xyzz_is_inf(running)) {
+        const uint64_t k = ch * K + 1;
         XyzzPt<NQ> m = xyzz_inf<NQ>();
-        for (int i = c - logk - 1; i >= 0; i--) {
+        for (int i = cb; i >= 0; i--) {
             m = xyzz_dbl_cold(m, P);
-            if ((ch >> i) & 1) m = xyzz_add_cold(m, t, P);
+            if ((k >> i) & 1) m = xyzz_add_cold(m, running, P);
         }
-        for (int i = 0; i < logk; i++) m = xyzz_dbl_cold(m, P);
         acc = xyzz_add_cold(acc, m, P);
     }
     store16(chunk_out + id, acc);
@@ -320,9 +417,9 @@ static int choose_window(size_t n, int bits) {
     double best = 1e300;
     int bc = 4;
     for (int c = 4; c <= 20; c++) {
-        const int W = (bits + c - 1) / c;
-        // madd ~10 field products per (point, window); chunked reduction ~2 full adds (14 products) per bucket
-        const double cost = (double)W * ((double)n * 10.0 + (double)((size_t)1 << c) * 2.5 * 14.0);
+        const int W = (bits + 1 + c - 1) / c;
+        // madd ~10 field products per (point, window); chunked reduction ~2.5 full adds (14 products) per bucket
+        const double cost = (double)W * ((double)n * 10.0 + (double)((size_t)1 << (c - 1)) * 2.5 * 14.0 * 2.0);
         if (cost < best) { best = cost; bc = c; }
     }
     return bc;
@@ -345,9 +442,10 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
     const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 22) : choose_window(n, bits);
-    const int W = (bits + c - 1) / c;
-    const uint64_t nb = (uint64_t)1 << c, nbuckets = (uint64_t)W * nb;
-    const int logk = std::min(c, 4);
+    const int W = (bits + 1 + c - 1) / c;              // signed digits: one spare bit for the last carry
+    const int cb = c - 1;                              // 2^(c-1) buckets per window
+    const uint64_t nb = (uint64_t)1 << cb, nbuckets = (uint64_t)W * nb;
+    const int logk = std::min(cb, 4);
     const uint64_t nch = nb >> logk, nchunks_total = (uint64_t)W * nch;
     const uint64_t nscan_blocks = (nbuckets + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
@@ -357,6 +455,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_offsets = off; off = align_up(off + (nbuckets + 1) * 4, 256);
     const size_t o_bsums = off; off = align_up(off + (nscan_blocks + 1) * 4, 256);
     const size_t o_sorted = off; off = align_up(off + (size_t)n * W * 4, 256);
+    const size_t o_order = off; off = align_up(off + nbuckets * 4, 256);
+    const size_t o_redo = off; off = align_up(off + (nbuckets + 1) * 4, 256);
+    const size_t o_hist = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(XyzzPt<NQ>), 256);
     const size_t o_chunks = off; off = align_up(off + nchunks_total * sizeof(XyzzPt<NQ>), 256);
     const size_t o_wsum = off; off = align_up(off + (size_t)W * sizeof(XyzzPt<NQ>), 256);
@@ -367,6 +468,10 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     uint32_t* offsets = (uint32_t*)(base + o_offsets);
     uint32_t* bsums = (uint32_t*)(base + o_bsums);
     uint32_t* sorted = (uint32_t*)(base + o_sorted);
+    uint32_t* order = (uint32_t*)(base + o_order);
+    uint32_t* redo = (uint32_t*)(base + o_redo);            // [0] = count, [1..] = list
+    uint32_t* ghist = (uint32_t*)(base + o_hist);
+    uint32_t* bin_cursor = ghist + SIZE_BINS;
     XyzzPt<NQ>* buckets = (XyzzPt<NQ>*)(base + o_buckets);
     XyzzPt<NQ>* chunks = (XyzzPt<NQ>*)(base + o_chunks);
     XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
@@ -382,11 +487,21 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, stream));
     { ProfScope ps("msm_scatter_kernel", stream);
     hipLaunchKernelGGL(msm_scatter_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, offsets, counts, sorted); }
+    { ProfScope ps("msm_bucket_order", stream);
+    HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
+    HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
+    const uint32_t bgrid = (uint32_t)((nbuckets + 255) / 256);
+    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, ghist);
+    hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
+    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, bin_cursor, order); }
     { ProfScope ps("msm_accumulate_kernel", stream);
-    hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, nbuckets,
-                       buckets, fl_params<NQ>(curve)); }
+    hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
+                       nbuckets, buckets, redo, redo + 1, fl_params<NQ>(curve)); }
+    { ProfScope ps("msm_accumulate_redo_kernel", stream);
+    hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, buckets, redo, redo + 1,
+                       fl_params<NQ>(curve)); }
     { ProfScope ps("msm_reduce_chunks_kernel", stream);
-    hipLaunchKernelGGL(msm_reduce_chunks_kernel<NQ>, dim3((uint32_t)((nchunks_total + 255) / 256)), dim3(256), 0, stream, buckets, c, logk,
+    hipLaunchKernelGGL(msm_reduce_chunks_kernel<NQ>, dim3((uint32_t)((nchunks_total + 255) / 256)), dim3(256), 0, stream, buckets, cb, logk,
                        nchunks_total, chunks, P); }
     const uint32_t wthreads = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, nch));
     // blockDim must be a power of two for the tree
