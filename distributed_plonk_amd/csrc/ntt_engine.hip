@@ -9,6 +9,7 @@
 #include "plonk_internal.hpp"
 
 static int g_ntt_max_log_r = NTT_LOG_RMAX;
+void ntt_set_ept(int v);
 void ntt_set_max_log_r(int v) { g_ntt_max_log_r = std::max(3, std::min(v, NTT_LOG_RMAX)); }
 
 const FrParams& fr_params(int curve) { return curve == PLONK_BN254 ? BN254_FR_PARAMS : BLS12_381_FR_PARAMS; }
@@ -109,8 +110,15 @@ std::vector<int> ntt_plan_widths(int log_m) {
 static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
 
 static int pref_log_t(int log_r) {
+    static const char* ept_env = getenv("PLONK_NTT_EPT");
+    static bool ept_done = false;
+    if (!ept_done) { ept_done = true; if (ept_env) ntt_set_ept(atoi(ept_env)); }
+    static const char* ov9 = getenv("PLONK_NTT_LOGT9");     // tuning overrides (experiments)
+    static const char* ov8 = getenv("PLONK_NTT_LOGT8");
+    if (log_r >= 9 && ov9) return atoi(ov9);
+    if (log_r == 8 && ov8) return atoi(ov8);
     if (log_r >= 9) return 3;  // 4096-element tile: 144 KiB of the CU's 160 KiB LDS
-    if (log_r < 3) return 9;   // EPT = R there: one lane per column, at most 512 lanes
+    if (log_r < 3) return 8;   // EPT = R there: one lane per column
     return 11 - log_r;         // 2048-element tiles (72 KiB: two workgroups per CU)
 }
 
@@ -139,17 +147,26 @@ static TwoLevelScale make_scale(const NttTables& T, const ScaleSpec& s, uint64_t
     return o;
 }
 
-template <int LOG_R>
-static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+static int g_ntt_ept = 4;      // elements per lane: 8 (radix-8 steps) or 4 (radix-4 steps, twice the waves per tile)
+void ntt_set_ept(int v) { g_ntt_ept = (v == 4 || v == 2) ? v : 8; }
+
+template <int LOG_R, int EPT>
+static hipError_t launch_one_e(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(ntt_pass_kernel<LOG_R>, dim3((uint32_t)grid), dim3(threads), lds, stream, P);
+    hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
     return hipGetLastError();
+}
+template <int LOG_R>
+static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    if (g_ntt_ept == 4) return launch_one_e<LOG_R, 4>(P, grid, threads, lds, stream);
+    if (g_ntt_ept == 2) return launch_one_e<LOG_R, 2>(P, grid, threads, lds, stream);
+    return launch_one_e<LOG_R, 8>(P, grid, threads, lds, stream);
 }
 
 static hipError_t launch_pass(int log_r, const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t s) {
@@ -280,8 +297,9 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         }
         if (p == 0) P.pro = make_scale(T, c.pro, c.q_offset);
         const uint64_t Tt = (uint64_t)1 << P.log_t;
-        const uint32_t ept = (w >= 3) ? 8 : (uint32_t)R;
+        const uint32_t ept = (R >= (uint64_t)g_ntt_ept) ? (uint32_t)g_ntt_ept : (uint32_t)R;
         const uint32_t threads = (uint32_t)(R * Tt / ept);
+        if (threads > 1024) return plonk_fail(PLONK_ERR_ARG, "ntt_run: tile of %llu x %llu needs %u lanes", (unsigned long long)R, (unsigned long long)Tt, threads);
         const size_t lds = (size_t)9 * R * P.tile_pitch * 4 + std::max<size_t>(R / 2, 1) * 36;
         if (grid == 0 || grid > 0x7fffffffull) return plonk_fail(PLONK_ERR_ARG, "ntt_run: grid %llu out of range", (unsigned long long)grid);
         static const char* const kNames[10] = {"", "ntt_pass_kernel<1>", "ntt_pass_kernel<2>", "ntt_pass_kernel<3>", "ntt_pass_kernel<4>",

@@ -184,10 +184,11 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
     }
 }
 
-template <int LOG_R>
-__global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
+template <int LOG_R, int EPT_REQ>
+__global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(const NttPassParams P) {
     constexpr int R = 1 << LOG_R;
-    constexpr int EPT = (LOG_R >= 3) ? 8 : R;
+    constexpr int EPT = (R >= EPT_REQ) ? EPT_REQ : R;
+    constexpr int KMAX = (EPT == 8) ? 3 : (EPT == 4) ? 2 : (EPT == 2 ? 1 : 1);
     constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     const uint32_t T = 1u << P.log_t;
@@ -229,27 +230,27 @@ __global__ void __launch_bounds__(512) ntt_pass_kernel(const NttPassParams P) {
     }
     __syncthreads();
 
-    // ---- in-LDS DIT transform, stages grouped (LOG_R % 3 first, then threes)
+    // ---- in-LDS DIT transform, stages grouped (LOG_R % KMAX first, then KMAX at a time)
     {
         const uint32_t t = u & (T - 1), w = u >> P.log_t;
-        constexpr int K0 = LOG_R % 3;
-        if constexpr (LOG_R < 3) {
+        constexpr int K0 = LOG_R % KMAX;
+        if constexpr (R <= EPT) {
             ntt_step<LOG_R, LOG_R, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
             __syncthreads();
         } else if constexpr (K0 != 0) {
             ntt_step<LOG_R, K0, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
             __syncthreads();
 #pragma unroll 1
-            for (int s = K0; s < LOG_R; s += 3) {
-                ntt_step<LOG_R, 3, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
+            for (int s = K0; s < LOG_R; s += KMAX) {
+                ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
                 __syncthreads();
             }
         } else {
-            ntt_step<LOG_R, 3, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            ntt_step<LOG_R, KMAX, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
             __syncthreads();
 #pragma unroll 1
-            for (int s = 3; s < LOG_R; s += 3) {
-                ntt_step<LOG_R, 3, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
+            for (int s = KMAX; s < LOG_R; s += KMAX) {
+                ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
                 __syncthreads();
             }
         }
