@@ -11,9 +11,10 @@ the reference prover issues per proof (/root/reference/src/dispatcher2.rs:294-69
 
 metric = constraints/sec = n / (time of one step); ms_per_step is the proof-equivalent hot-path time.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 20] [--curve bn254]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 24] [--curve bn254]
 
-N == 1: everything on one GPU (BASELINE.json configs[1] by default: 2^20 gates, BN254).
+N == 1: everything on one GPU.  Default n = 2^24, the size BASELINE.json's metric is quoted on (it fits one
+        MI355X: the 8n = 2^27 transforms ping-pong two 4 GiB buffers); `--log-n 20` is configs[1].
 N  > 1: launched by torchrun, one rank per GPU.  Same n (strong scaling): every NTT is the reference's
         2-D transform — row pass, ONE RCCL all-to-all over xGMI, column pass — and every MSM is
         index-sharded with a 96-byte all-gather + host add.
@@ -39,7 +40,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=int(os.environ.get("PLONK_BENCH_LOG_N", "20")))
+    ap.add_argument("--log-n", type=int, default=int(os.environ.get("PLONK_BENCH_LOG_N", "24")))
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
     ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
