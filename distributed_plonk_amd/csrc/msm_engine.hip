@@ -5,12 +5,16 @@
 // and src/dispatcher2.rs:835-893.  Only the group element is contractual
 // (Appendix A.1), so the GPU algorithm is free to differ from the CPU one:
 //
-//   1. digits      every scalar is cut into W = ceil(bits/c) unsigned c-bit digits; a histogram of
-//                  (window, digit) pairs is built with HBM atomics            (msm_count_kernel)
-//   2. offsets     exclusive prefix sum over the W*2^c counters               (scan_* kernels)
-//   3. scatter     point indices are written to their bucket's segment        (msm_scatter_kernel)
-//   4. accumulate  one lane per bucket walks its segment and adds the (affine, 256-bit-limb loaded)
-//                  bases into an XYZZ accumulator held in VGPRs               (msm_accumulate_kernel)
+//   1. digits      every scalar is cut into W = ceil((bits+1)/c) SIGNED c-bit digits, stored planar
+//                                                                              (msm_digits_kernel)
+//   2/3. sort      two-level LDS-staged counting sort of the (window, |digit|) keys: per-slice partition
+//                  histograms + one exclusive scan, a coalesced level-1 scatter, then one workgroup per
+//                  partition orders its L2-resident entries and emits the bucket offsets
+//                                                           (sort_hist / scan_* / sort_scatter / sort_partition)
+//   3b. schedule   bucket ids counting-sorted by size, so a wave's lanes own equally loaded buckets
+//   4. accumulate  one lane per bucket walks its segment and adds the resident limb-form bases (negated for
+//                  negative digits) into an XYZZ accumulator held in VGPRs   (msm_accumulate_kernel;
+//                  same-x exceptional additions are redone by msm_accumulate_redo_kernel)
 //   5. reduce      sum_d d*B_d per window: every lane does the running-sum trick on a chunk of K
 //                  buckets and fixes its offset with a small double-and-add   (msm_reduce_chunks_kernel)
 //                  followed by an LDS tree over the chunk sums                (msm_window_sum_kernel)
@@ -62,40 +66,114 @@ __device__ __forceinline__ uint32_t scalar_raw_digit(const uint32_t* s, int bit0
     return (uint32_t)(v >> off) & ((1u << c) - 1);
 }
 
-__global__ void __launch_bounds__(256) msm_count_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
-                                                        uint32_t* __restrict__ counts) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+// ---- 1: digits, planar: dig[w*n + i] = magnitude | sign << 31   (magnitude 0 = no contribution)
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
+                                                         uint32_t* __restrict__ dig) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[8];
+    const uint4* sp = reinterpret_cast<const uint4*>(scalars + 8 * i);
+    const uint4 lo = sp[0], hi = sp[1];
+    s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
     const uint32_t half = 1u << (c - 1);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t* s = scalars + 8 * i;
-        uint32_t carry = 0;
-        for (int w = 0; w < W; w++) {
-            uint32_t raw = scalar_raw_digit(s, w * c, c) + carry;
-            carry = raw > half;
-            const uint32_t mag = carry ? (1u << c) - raw : raw;
-            if (mag) atomicAdd(&counts[((uint64_t)w << (c - 1)) + (mag - 1)], 1u);
+    uint32_t carry = 0;
+    for (int w = 0; w < W; w++) {
+        // static limb selection keeps s[] in registers
+        const int bit0 = w * c, limb = bit0 >> 5, off = bit0 & 31;
+        uint64_t v = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            if (k == limb) v |= s[k];
+            if (k == limb + 1) v |= (uint64_t)s[k] << 32;
         }
+        uint32_t raw = ((uint32_t)(v >> off) & ((1u << c) - 1)) + carry;
+        carry = raw > half;
+        const uint32_t mag = carry ? (1u << c) - raw : raw;
+        dig[(uint64_t)w * n + i] = mag | (carry << 31);
     }
 }
 
-__global__ void __launch_bounds__(256) msm_scatter_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
-                                                          const uint32_t* __restrict__ offsets, uint32_t* __restrict__ cursor,
-                                                          uint32_t* __restrict__ sorted) {
-    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    const uint32_t half = 1u << (c - 1);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint32_t* s = scalars + 8 * i;
-        uint32_t carry = 0;
-        for (int w = 0; w < W; w++) {
-            uint32_t raw = scalar_raw_digit(s, w * c, c) + carry;
-            carry = raw > half;
-            const uint32_t mag = carry ? (1u << c) - raw : raw;
-            if (mag) {
-                const uint64_t b = ((uint64_t)w << (c - 1)) + (mag - 1);
-                const uint32_t pos = offsets[b] + atomicAdd(&cursor[b], 1u);
-                sorted[pos] = (uint32_t)i | (carry << 31);
-            }
-        }
+// ---- 3: two-level LDS-staged counting sort of the (window, bucket) keys.
+// Level 1 splits every window into 2^lp partitions by the top bits of the bucket index (all traffic in
+// contiguous pieces, no global atomics: per-slice histograms + one exclusive scan give every (slice, partition)
+// its exact range).  Level 2 sorts one partition per workgroup with LDS counters; its ~64 KiB of entries stay
+// in L2.  Replaces a histogram + scatter pair that issued one HBM atomic and one 4-byte random store per
+// (point, window) — 16x write amplification once n*W*4 B outgrows the 256 MiB Infinity Cache.
+#define SORT_SLICE 16384          // entries per level-1 workgroup
+struct SortGeom {
+    uint64_t n;
+    int W, cb, lp, low_bits, idx_bits;
+    uint32_t nblk;               // slices per window
+    uint32_t nreal;              // W << lp : real partitions; the W "digit == 0" partitions follow them
+};
+
+__global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blk_hist) {
+    extern __shared__ uint32_t h[];
+    const uint32_t np = (1u << g.lp) + 1;
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) h[k] = 0;
+    __syncthreads();
+    const uint32_t w = blockIdx.y, blk = blockIdx.x;
+    const uint64_t beg = (uint64_t)blk * SORT_SLICE, end = beg + SORT_SLICE < g.n ? beg + SORT_SLICE : g.n;
+    const uint32_t* d = dig + (uint64_t)w * g.n;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t mag = d[i] & 0x7fffffffu;
+        const uint32_t part = mag ? ((mag - 1) >> g.low_bits) : (np - 1);
+        atomicAdd(&h[part], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+        const uint64_t pid = (k == np - 1) ? (uint64_t)g.nreal + w : ((uint64_t)w << g.lp) + k;
+        blk_hist[pid * g.nblk + blk] = h[k];
+    }
+}
+
+__global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blk_off,
+                                                           uint32_t* __restrict__ tmp) {
+    extern __shared__ uint32_t h[];
+    const uint32_t np = (1u << g.lp) + 1;
+    const uint32_t w = blockIdx.y, blk = blockIdx.x;
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
+        const uint64_t pid = (k == np - 1) ? (uint64_t)g.nreal + w : ((uint64_t)w << g.lp) + k;
+        h[k] = blk_off[pid * g.nblk + blk];
+    }
+    __syncthreads();
+    const uint64_t beg = (uint64_t)blk * SORT_SLICE, end = beg + SORT_SLICE < g.n ? beg + SORT_SLICE : g.n;
+    const uint32_t* d = dig + (uint64_t)w * g.n;
+    const uint32_t low_mask = (1u << g.low_bits) - 1;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t e = d[i], mag = e & 0x7fffffffu;
+        if (!mag) continue;                                    // zero digits are counted (their partitions sit last) but never stored
+        const uint32_t key = mag - 1;
+        const uint32_t pos = atomicAdd(&h[key >> g.low_bits], 1u);
+        tmp[pos] = ((key & low_mask) << (g.idx_bits + 1)) | ((e >> 31) << g.idx_bits) | (uint32_t)i;
+    }
+}
+
+// one workgroup per real partition: final order + bucket offsets
+__global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
+                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+    extern __shared__ uint32_t cnt[];          // [2^low_bits] counts -> cursors
+    const uint32_t nlow = 1u << g.low_bits;
+    const uint64_t pid = blockIdx.x;
+    const uint32_t pbeg = blk_off[pid * g.nblk], pend = blk_off[(pid + 1) * g.nblk];
+    for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) cnt[k] = 0;
+    __syncthreads();
+    const int sh = g.idx_bits + 1;
+    for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) atomicAdd(&cnt[tmp[j] >> sh], 1u);
+    __syncthreads();
+    if (threadIdx.x == 0) {                    // nlow <= 2048: a serial exclusive scan is negligible
+        uint32_t run = pbeg;
+        for (uint32_t k = 0; k < nlow; k++) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) offsets[(pid << g.low_bits) + k] = cnt[k];
+    if (pid == g.nreal - 1 && threadIdx.x == 0) offsets[(uint64_t)g.nreal << g.low_bits] = pend;      // end sentinel
+    __syncthreads();
+    const uint32_t idx_mask = (1u << g.idx_bits) - 1;
+    for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
+        const uint32_t e = tmp[j];
+        const uint32_t pos = atomicAdd(&cnt[e >> sh], 1u);
+        sorted[pos] = (e & idx_mask) | (((e >> g.idx_bits) & 1u) << 31);
     }
 }
 
@@ -416,7 +494,7 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 static int choose_window(size_t n, int bits) {
     double best = 1e300;
     int bc = 4;
-    for (int c = 4; c <= 20; c++) {
+    for (int c = 4; c <= 18; c++) {
         const int W = (bits + 1 + c - 1) / c;
         // madd ~10 field products per (point, window); chunked reduction ~2.5 full adds (14 products) per bucket
         const double cost = (double)W * ((double)n * 10.0 + (double)((size_t)1 << (c - 1)) * 2.5 * 14.0 * 2.0);
@@ -447,46 +525,61 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const uint64_t nb = (uint64_t)1 << cb, nbuckets = (uint64_t)W * nb;
     const int logk = std::min(cb, 4);
     const uint64_t nch = nb >> logk, nchunks_total = (uint64_t)W * nch;
-    const uint64_t nscan_blocks = (nbuckets + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
+    SortGeom g;
+    g.n = n; g.W = W; g.cb = cb;
+    g.idx_bits = 1;
+    while (((uint64_t)1 << g.idx_bits) < n) g.idx_bits++;
+    g.lp = std::min(cb, std::max(std::min(cb, 10), cb + g.idx_bits + 1 - 32));
+    g.low_bits = cb - g.lp;
+    if (g.lp > 13 || g.low_bits > 11) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
+    g.nblk = (uint32_t)((n + SORT_SLICE - 1) / SORT_SLICE);
+    g.nreal = (uint32_t)W << g.lp;
+    const uint64_t nhist = ((uint64_t)g.nreal + W) * g.nblk;
+    const uint64_t nscan_blocks = (nhist + SCAN_CHUNK - 1) / SCAN_CHUNK;
 
     size_t off = 0;
-    const size_t o_counts = off; off = align_up(off + nbuckets * 4, 256);
+    const size_t o_dig = off; off = align_up(off + (size_t)n * W * 4, 256);
+    const size_t o_tmp = off; off = align_up(off + (size_t)n * W * 4, 256);
+    const size_t o_hist = off; off = align_up(off + (nhist + 1) * 4, 256);
+    const size_t o_hoff = off; off = align_up(off + (nhist + 1) * 4, 256);
     const size_t o_offsets = off; off = align_up(off + (nbuckets + 1) * 4, 256);
     const size_t o_bsums = off; off = align_up(off + (nscan_blocks + 1) * 4, 256);
     const size_t o_sorted = off; off = align_up(off + (size_t)n * W * 4, 256);
     const size_t o_order = off; off = align_up(off + nbuckets * 4, 256);
     const size_t o_redo = off; off = align_up(off + (nbuckets + 1) * 4, 256);
-    const size_t o_hist = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
+    const size_t o_szh = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(XyzzPt<NQ>), 256);
     const size_t o_chunks = off; off = align_up(off + nchunks_total * sizeof(XyzzPt<NQ>), 256);
     const size_t o_wsum = off; off = align_up(off + (size_t)W * sizeof(XyzzPt<NQ>), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
     char* base = (char*)ws.d_buf;
-    uint32_t* counts = (uint32_t*)(base + o_counts);
+    uint32_t* dig = (uint32_t*)(base + o_dig);
+    uint32_t* tmp = (uint32_t*)(base + o_tmp);
+    uint32_t* blk_hist = (uint32_t*)(base + o_hist);
+    uint32_t* blk_off = (uint32_t*)(base + o_hoff);
     uint32_t* offsets = (uint32_t*)(base + o_offsets);
     uint32_t* bsums = (uint32_t*)(base + o_bsums);
     uint32_t* sorted = (uint32_t*)(base + o_sorted);
     uint32_t* order = (uint32_t*)(base + o_order);
     uint32_t* redo = (uint32_t*)(base + o_redo);            // [0] = count, [1..] = list
-    uint32_t* ghist = (uint32_t*)(base + o_hist);
+    uint32_t* ghist = (uint32_t*)(base + o_szh);
     uint32_t* bin_cursor = ghist + SIZE_BINS;
     XyzzPt<NQ>* buckets = (XyzzPt<NQ>*)(base + o_buckets);
     XyzzPt<NQ>* chunks = (XyzzPt<NQ>*)(base + o_chunks);
     XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
 
-    const uint32_t sgrid = (uint32_t)std::min<uint64_t>((n + 255) / 256, 256 * 32);
-    HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, stream));
-    { ProfScope ps("msm_count_kernel", stream);
-    hipLaunchKernelGGL(msm_count_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, counts); }
-    { ProfScope ps("msm_scan", stream);
-    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, counts, nbuckets, bsums);
-    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsums, nscan_blocks, offsets + nbuckets);
-    hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, counts, nbuckets, bsums, offsets); }
-    HIP_TRY(hipMemsetAsync(counts, 0, nbuckets * 4, stream));
-    { ProfScope ps("msm_scatter_kernel", stream);
-    hipLaunchKernelGGL(msm_scatter_kernel, dim3(sgrid), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, offsets, counts, sorted); }
+    const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
+    { ProfScope ps("msm_digits_kernel", stream);
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, dig); }
+    { ProfScope ps("msm_sort", stream);
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_hist);
+    hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums);
+    hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsums, nscan_blocks, blk_off + nhist);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums, blk_off);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_off, tmp);
+    hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), ((size_t)1 << g.low_bits) * 4, stream, tmp, g, blk_off, sorted, offsets); }
     { ProfScope ps("msm_bucket_order", stream);
     HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
