@@ -82,6 +82,11 @@ void ntt_tables_destroy(NttTables& T) {
     }
     for (auto& kv : T.tw_lo_scaled) hipFree(kv.second);
     T.tw_lo_scaled.clear();
+    for (auto& kv : T.planes) hipFree(kv.second);
+    T.planes.clear();
+    for (auto& kv : T.rowtabs) hipFree(kv.second);
+    T.rowtabs.clear();
+    T.plane_bytes = 0;
 }
 
 // w^-e * 2^-log_m for e < 2^lt (inverse transforms of size 2^log_m fold their 1/M here)
@@ -92,6 +97,53 @@ static int get_scaled_lo(NttTables& T, int log_m, F29** out, hipStream_t stream)
     int rc = upload_powers(&d, T.h_root[1], (size_t)1 << T.lt, T.h_pow2_inv[log_m], T.fp, stream);
     if (rc) return rc;
     T.tw_lo_scaled[log_m] = d;
+    *out = d;
+    return PLONK_OK;
+}
+
+// Inter-pass factor plane (ntt_gen_plane_kernel) for pass `p` of a size-2^log_m transform, cached per
+// (log_m, r_prev, r_p, direction, inverse-scale folded, coset folded).  Returns nullptr (no error) when the plane
+// budget is exhausted — the pass then forms its factors on the fly.
+static int get_plane(NttTables& T, int log_m, int log_rprev, int log_rp, int dir, bool fold_scale, bool fold_coset, Fr** out,
+                     hipStream_t stream) {
+    *out = nullptr;
+    const uint64_t key = ((uint64_t)log_m << 32) | ((uint64_t)log_rprev << 24) | ((uint64_t)log_rp << 16) | ((uint64_t)dir << 2) |
+                         ((uint64_t)fold_scale << 1) | (uint64_t)fold_coset;
+    auto it = T.planes.find(key);
+    if (it != T.planes.end()) { *out = it->second; return PLONK_OK; }
+    const uint64_t r_prev = (uint64_t)1 << log_rprev;
+    const size_t bytes = r_prev * sizeof(Fr);
+    if (T.plane_bytes + bytes > T.plane_budget) return PLONK_OK;
+    F29* lo = T.tw_lo[dir];
+    if (fold_scale) {
+        int rc = get_scaled_lo(T, log_m, &lo, stream);
+        if (rc) return rc;
+    }
+    Fr* d = nullptr;
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipGetLastError(); return PLONK_OK; }     // out of memory: just no plane
+    hipLaunchKernelGGL(ntt_gen_plane_kernel, dim3((uint32_t)((r_prev + 255) / 256)), dim3(256), 0, stream, d, r_prev, (uint64_t)1 << log_rp, lo,
+                       T.tw_hi[dir], (uint32_t)T.lt, (uint32_t)(T.two_adicity - log_rprev), fold_coset ? T.g_lo[0] : (const F29*)nullptr,
+                       fold_coset ? T.g_hi[0] : (const F29*)nullptr, T.fp29);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "ntt_gen_plane launch: %s", hipGetErrorString(e)); }
+    T.planes[key] = d;
+    T.plane_bytes += bytes;
+    *out = d;
+    return PLONK_OK;
+}
+
+// G[a] = g^(a * 2^log_r1), a < 2^log_w  (forward coset shift split as g^(a*r_1) * g^b; the g^b half lives in the plane)
+static int get_rowtab(NttTables& T, int log_r1, int log_w, F29** out, hipStream_t stream) {
+    const uint64_t key = ((uint64_t)log_r1 << 8) | (uint64_t)log_w;
+    auto it = T.rowtabs.find(key);
+    if (it != T.rowtabs.end()) { *out = it->second; return PLONK_OK; }
+    const uint32_t* g_l = T.curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
+    Fr base = fp_from_limbs<8>(g_l);
+    for (int i = 0; i < log_r1; i++) base = fp_sqr(base, T.fp);         // g^(r_1)
+    F29* d = nullptr;
+    int rc = upload_powers(&d, base, (size_t)1 << log_w, fp_one(T.fp), T.fp, stream);
+    if (rc) return rc;
+    T.rowtabs[key] = d;
     *out = d;
     return PLONK_OK;
 }
@@ -198,6 +250,11 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(c))
         return plonk_fail(PLONK_ERR_ARG, "ntt_run: in-place only for contiguous single pass");
 
+    // forward coset shift of a whole contiguous vector: x[n] * g^n with n = a*r_1 + b splits into a per-row table
+    // (g^(a*r_1), applied at load) and g^b folded into the first inter-pass plane
+    const bool simple_coset = c.pro.kind == 1 && c.pro.aq == 0 && c.pro.a0 == 0 && c.pro.bq == 0 && c.pro.b0 == 1 && c.q_offset == 0;
+    bool coset_folded = false;
+    static const bool planes_on = getenv("PLONK_NTT_NO_PLANES") == nullptr;
     uint64_t r_prev = M;
     for (int p = 0; p < NP; p++) {
         const int w = widths[p];
@@ -223,6 +280,22 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
                 int rc = get_scaled_lo(T, L, &scaled, stream);
                 if (rc) return rc;
                 P.tw_lo = scaled;
+            }
+            if (planes_on) {
+                const bool want_coset = (p == 0 && simple_coset && !interleaved);
+                Fr* plane = nullptr;
+                int rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, want_coset, &plane, stream);
+                if (rc) return rc;
+                if (plane == nullptr && want_coset) {       // no room for the folded plane: try the plain one, keep the shift in the prologue
+                    rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, false, &plane, stream);
+                    if (rc) return rc;
+                } else if (plane != nullptr && want_coset) {
+                    coset_folded = true;
+                    int rc2 = get_rowtab(T, ilog2(r_p), w, const_cast<F29**>(&P.pro_rowtab), stream);
+                    if (rc2) return rc2;
+                }
+                P.tw_plane = plane;
+                P.plane_rp = r_p;
             }
             avail = interleaved ? Bt : r_p;
             int lt = std::min(pref_log_t(w), ilog2(avail));
@@ -295,7 +368,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
             P.epi = make_scale(T, c.epi, c.q_offset);
             P.tile_pitch = (uint32_t)((uint64_t)1 << P.log_t);
         }
-        if (p == 0) P.pro = make_scale(T, c.pro, c.q_offset);
+        if (p == 0 && !coset_folded) P.pro = make_scale(T, c.pro, c.q_offset);
         const uint64_t Tt = (uint64_t)1 << P.log_t;
         const uint32_t ept = (R >= (uint64_t)g_ntt_ept) ? (uint32_t)g_ntt_ept : (uint32_t)R;
         const uint32_t threads = (uint32_t)(R * Tt / ept);

@@ -74,6 +74,9 @@ struct NttPassParams {
     uint64_t oq, ok;
     int32_t split_log;                    // >=0: out = (k>>split_log)*split_blk + q<<split_log + (k & mask)
     uint64_t split_blk;
+    const Fr* tw_plane;                   // non-last pass: precomputed inter-pass factors, index i*r_p + b (nullable)
+    uint64_t plane_rp;                    // r_p (row pitch of the plane)
+    const F29* pro_rowtab;                // first pass: per-row input scale G[a] (coset shift g^(a*r_1)), nullable
     uint32_t scale_const_enabled;         // multiply outputs by `scale_const` (1/N when P==1)
     F29 scale_const;
     TwoLevelScale pro;                    // prologue (first pass) scale, idx = pos
@@ -221,7 +224,9 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         if (P.load_a_fast) { a = e & (R - 1); t = e >> LOG_R; }
         else               { t = e & (T - 1); a = e >> P.log_t; }
         F29 v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));
-        if (P.pro.enabled) {
+        if (P.pro_rowtab != nullptr) {
+            v = f29_mul(v, load_f29(P.pro_rowtab + a), P.fp);
+        } else if (P.pro.enabled) {
             const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
             const F29 s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
             v = f29_mul(v, s, P.fp);
@@ -278,11 +283,16 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         F29 v = tile.get(idx * pitch + t);
         if (!P.is_last) {
             const uint64_t b = b0 + (uint64_t)t * P.tb;
-            const uint64_t ex = (b * idx) << P.tw_shift;
-            const uint64_t mask = ((uint64_t)1 << P.tw_lt) - 1;
-            const F29 tl = load_f29(P.tw_lo + (ex & mask));
-            const F29 th = load_f29(P.tw_hi + ((ex >> P.tw_lt) & mask));
-            v = f29_mul(v, f29_mul(tl, th, P.fp), P.fp);
+            if (P.tw_plane != nullptr) {
+                // streamed factor plane: one 256-bit-limb load replaces two table gathers and a product
+                v = f29_mul(v, f29_from_sat(load_fr(P.tw_plane + (uint64_t)idx * P.plane_rp + b)), P.fp);
+            } else {
+                const uint64_t ex = (b * idx) << P.tw_shift;
+                const uint64_t mask = ((uint64_t)1 << P.tw_lt) - 1;
+                const F29 tl = load_f29(P.tw_lo + (ex & mask));
+                const F29 th = load_f29(P.tw_hi + ((ex >> P.tw_lt) & mask));
+                v = f29_mul(v, f29_mul(tl, th, P.fp), P.fp);
+            }
             // < 1.36 p < 2^256: stored re-packed but not canonicalised (the next pass does not care)
             store_fr(P.out + sbase + (uint64_t)idx * P.s_istride + (uint64_t)t * P.s_tstride, f29_to_sat(v));
         } else {
@@ -305,4 +315,23 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             store_fr(P.out + addr, f29_to_sat(v));
         }
     }
+}
+
+
+// Inter-pass factor plane for pass p of a size-M transform: plane[i*r_p + b] = w_{r_{p-1}}^{b*i} (times 1/M for the
+// first pass of an inverse transform via the scaled lo table, times g^b when a forward coset shift is folded in),
+// stored canonical in constant form (c*2^261 mod p) as 8 x u32.
+__global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restrict__ out, uint64_t r_prev, uint64_t r_p, const F29* __restrict__ tw_lo,
+                                                            const F29* __restrict__ tw_hi, uint32_t lt, uint32_t shift,
+                                                            const F29* __restrict__ g_lo, const F29* __restrict__ g_hi, const F29Params fp) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= r_prev) return;
+    const uint64_t i = pos / r_p, b = pos % r_p;
+    const uint64_t ex = (b * i) << shift, mask = ((uint64_t)1 << lt) - 1;
+    F29 v = f29_mul(load_f29(tw_lo + (ex & mask)), load_f29(tw_hi + ((ex >> lt) & mask)), fp);
+    if (g_lo != nullptr) {
+        const F29 g = f29_mul(load_f29(g_lo + (b & mask)), load_f29(g_hi + ((b >> lt) & mask)), fp);
+        v = f29_mul(v, g, fp);
+    }
+    store_fr(out + pos, f29_to_sat(f29_canon(v, fp)));
 }

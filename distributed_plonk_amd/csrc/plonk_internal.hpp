@@ -63,6 +63,10 @@ struct NttTables {
     F29* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e
     F29* g_hi[2] = {nullptr, nullptr};       // [0] g^(e<<lt) ...
     std::unordered_map<int, F29*> tw_lo_scaled;   // key = log_m (inverse only): w^-e * 2^-log_m
+    std::unordered_map<uint64_t, Fr*> planes;     // inter-pass factor planes (see ntt_engine.hip: plane_key)
+    std::unordered_map<uint64_t, F29*> rowtabs;   // coset row tables g^(a*r_1)
+    size_t plane_bytes = 0;                       // HBM currently held by planes
+    size_t plane_budget = (size_t)48 << 30;       // stop creating planes beyond this (fall back to on-the-fly factors)
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };
