@@ -76,12 +76,12 @@ __device__ __forceinline__ bool xyzzl_madd_fast(XyzzL<NL, B>& a, const AffL<NL, 
     fl_norm(p);
     FL<NL, B> r = fl_sub(s2, a.y, P.c4);
     fl_norm(r);
-    const FL<NL, B> pp = fl_mul(p, p, P);
+    const FL<NL, B> pp = fl_sqr(p, P);
     if (fl_is_zero_mod_p_lt3p(pp, P)) return false;
     const FL<NL, B> ppp = fl_mul(p, pp, P);
     const FL<NL, B> qq = fl_mul(a.x, pp, P);
     const FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));       // PPP + 2Q, limbs < 3*2^B
-    FL<NL, B> x3 = fl_sub(fl_mul(r, r, P), sub, P.c4);
+    FL<NL, B> x3 = fl_sub(fl_sqr(r, P), sub, P.c4);
     fl_norm(x3);
     FL<NL, B> t = fl_sub(qq, x3, P.c8);
     fl_norm(t);
@@ -110,7 +110,7 @@ __device__ __forceinline__ XyzzL<NL, B> xyzzl_madd(const XyzzL<NL, B>& a, const 
     fl_norm(p);
     FL<NL, B> r = fl_sub(s2, a.y, P.c4);
     fl_norm(r);
-    const FL<NL, B> pp = fl_mul(p, p, P);
+    const FL<NL, B> pp = fl_sqr(p, P);
     if (fl_is_zero_mod_p_lt3p(pp, P)) {                      // same x: P + P or P + (-P)
         const FL<NL, B> rc = fl_canon_small(r, P, 6);
         if (fl_all_zero(rc)) return xyzzl_dbl_affine(q, P);
@@ -120,7 +120,7 @@ __device__ __forceinline__ XyzzL<NL, B> xyzzl_madd(const XyzzL<NL, B>& a, const 
     const FL<NL, B> ppp = fl_mul(p, pp, P);
     const FL<NL, B> qq = fl_mul(a.x, pp, P);
     FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));             // PPP + 2Q, limbs < 3*2^B
-    o.x = fl_sub(fl_mul(r, r, P), sub, P.c4);
+    o.x = fl_sub(fl_sqr(r, P), sub, P.c4);
     fl_norm(o.x);
     FL<NL, B> t = fl_sub(qq, o.x, P.c8);
     fl_norm(t);

@@ -130,6 +130,40 @@ template <int NL, int B> FP_HD FL<NL, B> fl_mul(const FL<NL, B>& x, const FL<NL,
     return r;
 }
 
+// Montgomery square: the cross products x_i*x_j (i != j) are taken once against the doubled limb.
+// x normalised (limbs < 2^B, top limb may be larger but 2*x_top must stay below 2^31).
+template <int NL, int B> FP_HD FL<NL, B> fl_sqr(const FL<NL, B>& x, const FLParams<NL, B>& P) {
+    constexpr uint32_t MASK = (1u << B) - 1;
+    uint64_t acc = 0;
+    uint32_t m[NL], x2[NL];
+    FL<NL, B> r;
+#pragma unroll
+    for (int i = 0; i < NL; i++) x2[i] = x.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        m[k] = ((uint32_t)acc * P.inv) & MASK;
+        acc += (uint64_t)m[k] * P.p[0];
+        acc >>= B;
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        r.l[k - NL] = (uint32_t)acc & MASK;
+        acc >>= B;
+    }
+    r.l[NL - 1] = (uint32_t)acc;
+    return r;
+}
+
 // value (normalised) == 0 mod p, given value < 3p
 template <int NL, int B> FP_HD bool fl_is_zero_mod_p_lt3p(const FL<NL, B>& a, const FLParams<NL, B>& P) {
     return fl_all_zero(a) || fl_equals_const(a, P.p) || fl_equals_const(a, P.p2);

@@ -163,8 +163,10 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
                 if (k & span) continue;
                 const int kk = k & (span - 1);
                 F29 tt;
-                if (FIRST && ds == 0) {
-                    tt = v[k + span];                                  // w^0 = 1: the first DIT stage has no products
+                if (FIRST && kk == 0) {
+                    // first step (s0 = 0, lo = 0): exponent kk << ... is 0, the twiddle is 1 — no product.
+                    // Covers the whole first stage and the kk = 0 half of the later stages of this step.
+                    tt = v[k + span];
                 } else {
                     const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
                     F29 tw;
@@ -235,27 +237,27 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
     }
     __syncthreads();
 
-    // ---- in-LDS DIT transform, stages grouped (LOG_R % KMAX first, then KMAX at a time)
+    // ---- in-LDS DIT transform, stages grouped KMAX at a time from stage 0 (the first group enjoys the
+    //      trivial twiddles), the LOG_R % KMAX remainder last
     {
         const uint32_t t = u & (T - 1), w = u >> P.log_t;
-        constexpr int K0 = LOG_R % KMAX;
+        constexpr int KREM = LOG_R % KMAX;
+        constexpr int SFULL = LOG_R - KREM;          // stages covered by full groups
         if constexpr (R <= EPT) {
             ntt_step<LOG_R, LOG_R, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
             __syncthreads();
-        } else if constexpr (K0 != 0) {
-            ntt_step<LOG_R, K0, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
-            __syncthreads();
-#pragma unroll 1
-            for (int s = K0; s < LOG_R; s += KMAX) {
-                ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
-                __syncthreads();
-            }
         } else {
-            ntt_step<LOG_R, KMAX, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
-            __syncthreads();
+            if constexpr (SFULL > 0) {
+                ntt_step<LOG_R, KMAX, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+                __syncthreads();
 #pragma unroll 1
-            for (int s = KMAX; s < LOG_R; s += KMAX) {
-                ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
+                for (int s = KMAX; s < SFULL; s += KMAX) {
+                    ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
+                    __syncthreads();
+                }
+            }
+            if constexpr (KREM != 0) {
+                ntt_step<LOG_R, KREM, EPT, SFULL == 0>(tile, tw_lds, SFULL, w, t, pitch, P.fp);
                 __syncthreads();
             }
         }
