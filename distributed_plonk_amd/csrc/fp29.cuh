@@ -27,6 +27,7 @@ struct F29 { uint32_t l[9]; };
 struct F29Params {
     uint32_t p[9];      // modulus, normalised 29-bit limbs
     uint32_t c2p[9];    // 2p with limbs lifted by 2^30 (borrowed from the next limb): every limb >= any product limb
+    uint32_t c4p[9];    // 4p lifted the same way: for subtracting an un-normalised sum of two values (< 2.8p, limbs < 2^30)
     uint32_t one[9];    // 2^261 mod p  (the constant that multiplies by 1)
     uint32_t inv;       // -p^{-1} mod 2^29
 };
@@ -79,6 +80,13 @@ FP_HD F29 f29_sub2p(const F29& a, const F29& t, const F29Params& P) {
     F29 r;
 #pragma unroll
     for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P.c2p[i] - t.l[i];
+    return r;
+}
+// a + 4p - t   (t < 4p - with limbs <= 2^30 - 2, e.g. the lazy sum of two values below 1.4p)
+FP_HD F29 f29_sub4p(const F29& a, const F29& t, const F29Params& P) {
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.l[i] = a.l[i] + P.c4p[i] - t.l[i];
     return r;
 }
 
@@ -148,6 +156,15 @@ inline F29Params f29_make_params(const FpParams<8>& P) {
     q.c2p[0] = d[0] + (1u << 30);
     for (int i = 1; i < 8; i++) q.c2p[i] = d[i] + (1u << 30) - 2;
     q.c2p[8] = d[8] - 2;
+    carry = 0;
+    for (int i = 0; i < 9; i++) {
+        uint32_t v = 4 * q.p[i] + carry;
+        carry = (i < 8) ? (v >> 29) : 0;
+        d[i] = (i < 8) ? (v & F29_MASK) : v;
+    }
+    q.c4p[0] = d[0] + (1u << 30);
+    for (int i = 1; i < 8; i++) q.c4p[i] = d[i] + (1u << 30) - 2;
+    q.c4p[8] = d[8] - 2;
     // inv = -p^{-1} mod 2^29 (Newton)
     uint32_t x = 1;
     for (int i = 0; i < 6; i++) x *= 2 - q.p[0] * x;

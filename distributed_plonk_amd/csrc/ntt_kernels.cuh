@@ -163,20 +163,24 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
                 if (k & span) continue;
                 const int kk = k & (span - 1);
                 F29 tt;
-                if (FIRST && kk == 0) {
+                const F29 x = v[k];
+                if (FIRST && kk == 0 && ds <= 1) {
                     // first step (s0 = 0, lo = 0): exponent kk << ... is 0, the twiddle is 1 — no product.
-                    // Covers the whole first stage and the kk = 0 half of the later stages of this step.
+                    // ds == 0: the partner is a fresh input (< 1.4p, normalised): x + 2p - y.
+                    // ds == 1: the partner is the lazy sum of two inputs (< 2.8p, limbs <= 2^30 - 2), so the
+                    //          offset must be 4p or the VALUE can go negative (caught by tests/test_gpu_fullsize.py).
                     tt = v[k + span];
+                    v[k] = f29_add(x, tt);
+                    v[k + span] = (ds == 0) ? f29_sub2p(x, tt, fp) : f29_sub4p(x, tt, fp);
                 } else {
                     const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
                     F29 tw;
 #pragma unroll
                     for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
                     tt = f29_mul(v[k + span], tw, fp);
+                    v[k] = f29_add(x, tt);
+                    v[k + span] = f29_sub2p(x, tt, fp);
                 }
-                const F29 x = v[k];
-                v[k] = f29_add(x, tt);
-                v[k + span] = f29_sub2p(x, tt, fp);
                 __builtin_amdgcn_sched_barrier(0);                     // keep one butterfly's temporaries live at a time
             }
             if (ds == 1 || ds == K - 1) {
