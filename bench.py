@@ -67,61 +67,70 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
-    from distributed_plonk_amd.dispatcher import RankProver, split_rc
+    from distributed_plonk_amd.dispatcher import RankProver, gather_points, split_rc
     from distributed_plonk_amd.worker import PlonkWorker
 
     n = 1 << args.log_n
     m = 8 * n
-    w = PlonkWorker(me=rank, device=local_rank, curve=args.curve)
-    q64 = w.q64
     S = world
     if (split_rc(n)[0] % S) or (n % S):
         raise SystemExit(f"{S} ranks do not divide r = {split_rc(n)[0]}")
-    prover = RankProver(w, rank, world)
     dev = torch.device("cuda", local_rank)
+    # N > 1: two contexts (two HIP streams) per rank, so that the all-to-all of one transform overlaps the
+    # row / column passes of the next (the 26 size-8n transforms of a proof are independent polynomials)
+    n_lanes = 2 if S > 1 else 1
+    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_lanes)]
+    w = workers[0]
+    q64 = w.q64
+    provers = [RankProver(x, rank, world) for x in workers]
 
     # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
     n_loc, m_loc = n // S, m // S
-    buf_n = [w.alloc(n_loc * 32), w.alloc(n_loc * 32)]
-    buf_m = [w.alloc(m_loc * 32), w.alloc(m_loc * 32)]
-    w.synth_fr(0xD15EA5E + rank, buf_n[0].ptr, n_loc)
-    w.synth_fr(0xBADC0DE + rank, buf_m[0].ptr, m_loc)
+    buf_n = [[w.alloc(n_loc * 32), w.alloc(n_loc * 32)] for _ in range(n_lanes)]
+    buf_m = [[w.alloc(m_loc * 32), w.alloc(m_loc * 32)] for _ in range(n_lanes)]
+    for lane in range(n_lanes):
+        w.synth_fr(0xD15EA5E + 16 * rank + lane, buf_n[lane][0].ptr, n_loc)
+        w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
     bases = w.alloc(n_loc * 16 * q64)
     # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
     w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
     w.init_dev(bases.ptr, n_loc, n, m)
+    for x in workers[1:]:
+        x.init_dev(bases.ptr, 0, n, m)          # domains only: the MSMs run on lane 0
     w.sync()
 
-    def ntt(bufs, size, inv, coset, is_quot):
+    def ntt(lane, bufs, size, inv, coset, is_quot):
         if S == 1:
             w.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
         else:
-            prover.fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
+            provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
 
     def commit():
-        part = w.commit_dev(buf_n[0].ptr, n_loc)
+        part = w.commit_dev(buf_n[0][0].ptr, n_loc)
         if S == 1:
             return part
-        from distributed_plonk_amd.dispatcher import gather_points
         acc = None
         for p in gather_points(part, None, dev):
             acc = p if acc is None else w.g1_add(acc, p)
         return acc
 
     def step():
-        for _ in range(N_NTT_SMALL):
-            ntt(buf_n, n, True, False, False)
-        for _ in range(N_NTT_BIG - 1):
-            ntt(buf_m, m, False, True, True)
-        ntt(buf_m, m, True, True, True)
+        for i in range(N_NTT_SMALL):
+            ntt(i % n_lanes, buf_n[i % n_lanes], n, True, False, False)
+        for i in range(N_NTT_BIG - 1):
+            ntt(i % n_lanes, buf_m[i % n_lanes], m, False, True, True)
+        ntt(0, buf_m[0], m, True, True, True)
+        for x in workers[1:]:
+            x.sync()                              # the commitments read lane-0 buffers only; keep lanes in step
         last = None
         for _ in range(N_MSM):
             last = commit()
         return last
 
     def full_sync():
-        w.sync()
+        for x in workers:
+            x.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -223,9 +232,12 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(out))
-    for b in buf_n + buf_m + [bases]:
-        b.free()
-    w.close()
+    for pair in buf_n + buf_m:
+        for b in pair:
+            b.free()
+    bases.free()
+    for x in workers:
+        x.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -551,7 +551,8 @@ extern "C" int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layo
     if (!d_out || (layout != 0 && layout != 1)) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_dev: bad argument");
     int rc = fft2_common(ctx, id, (Fr*)d_out, layout);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // no host synchronisation: the task's buffers go back to the context's pool and are only ever reused by
+    // work ordered on the same stream, so several transforms (on several contexts) can be in flight
     auto it = ctx->tasks.find(id);
     free_task(ctx, it->second);
     ctx->tasks.erase(it);                       // worker.rs:378

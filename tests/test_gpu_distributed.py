@@ -152,3 +152,45 @@ def test_rank_prover_rccl_single_rank(oracle):
     finally:
         w.close()
         dist.destroy_process_group()
+
+
+def test_two_contexts_pipelined_transforms(oracle):
+    """bench.py's N>1 schedule on one rank: two contexts (two HIP streams) alternate transforms whose exchange goes
+    through the RCCL transport, nothing synchronises with the host in between; every result must still be exact."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from distributed_plonk_amd.dispatcher import RankProver
+    from distributed_plonk_amd.worker import PlonkWorker
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = "29541"
+    torch.cuda.set_device(0)
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    lanes = [PlonkWorker(me=0, device=0, curve="bn254") for _ in range(2)]
+    try:
+        log_n = 16
+        N = 1 << log_n
+        r, c = split_rc(N)
+        provers = []
+        for wk in lanes:
+            wk.init(None, N, 0)
+            provers.append(RankProver(wk, 0, 1, force_exchange=True))
+        K = 6
+        coeffs = [oracle.rand_fr(0, 300 + i, N) for i in range(K)]
+        ins, outs = [], []
+        for i in range(K):
+            wk = lanes[i % 2]
+            rows = np.ascontiguousarray(coeffs[i].reshape(c, r, 4).transpose(1, 0, 2))
+            ins.append(wk.alloc(N * 32).upload(rows))
+            outs.append(wk.alloc(N * 32))
+        for i in range(K):                      # enqueue everything, no host sync in between
+            provers[i % 2].fft_dev(ins[i].ptr, outs[i].ptr, N, False, bool(i & 2), True, out_layout=1)
+        for wk in lanes:
+            wk.sync()
+        for i in range(K):
+            want = oracle.ntt(0, coeffs[i], bool(i & 2), True, threads=8)
+            assert np.array_equal(outs[i].download((N, 4)), want), i
+    finally:
+        for wk in lanes:
+            wk.close()
+        dist.destroy_process_group()
