@@ -130,3 +130,97 @@ __device__ __forceinline__ XyzzL<NL, B> xyzzl_madd(const XyzzL<NL, B>& a, const 
     o.zzz = fl_mul(a.zzz, ppp, P);
     return o;
 }
+
+
+// 2*a for an XYZZ accumulator (dbl-2008-s-1), lazy.  Cold (only the P + P branch of xyzzl_add).
+template <int NL, int B>
+__device__ __attribute__((noinline)) XyzzL<NL, B> xyzzl_dbl(const XyzzL<NL, B>& a, const FLParams<NL, B>& P) {
+    if (fl_all_zero(a.zz)) return a;
+    XyzzL<NL, B> r;
+    FL<NL, B> u = fl_add(a.y, a.y);
+    fl_norm(u);                                             // < 6.6p
+    const FL<NL, B> v = fl_sqr(u, P);
+    const FL<NL, B> w = fl_mul(u, v, P);
+    const FL<NL, B> s = fl_mul(a.x, v, P);
+    const FL<NL, B> xx = fl_sqr(a.x, P);
+    FL<NL, B> m = fl_add(fl_add(xx, xx), xx);
+    fl_norm(m);
+    const FL<NL, B> s2 = fl_add(s, s);
+    FL<NL, B> x3 = fl_sub(fl_sqr(m, P), s2, P.c4);
+    fl_norm(x3);
+    FL<NL, B> t = fl_sub(s, x3, P.c8);
+    fl_norm(t);
+    FL<NL, B> y3 = fl_sub(fl_mul(m, t, P), fl_mul(w, a.y, P), P.c2);
+    fl_norm(y3);
+    r.x = x3; r.y = y3;
+    r.zz = fl_mul(v, a.zz, P);
+    r.zzz = fl_mul(w, a.zzz, P);
+    return r;
+}
+
+// a + b for two XYZZ accumulators (add-2008-s), complete, lazy; same invariants in and out as xyzzl_madd.
+//   U1, U2, S1, S2 < 1.1p ;  P = U2 + 2p - U1 < 3.1p ;  R = S2 + 2p - S1 < 3.1p ;  rest as in the mixed addition.
+template <int NL, int B>
+__device__ __forceinline__ XyzzL<NL, B> xyzzl_add(const XyzzL<NL, B>& a, const XyzzL<NL, B>& b, const FLParams<NL, B>& P) {
+    if (fl_all_zero(a.zz)) return b;
+    if (fl_all_zero(b.zz)) return a;
+    const FL<NL, B> u1 = fl_mul(a.x, b.zz, P);
+    const FL<NL, B> u2 = fl_mul(b.x, a.zz, P);
+    const FL<NL, B> s1 = fl_mul(a.y, b.zzz, P);
+    const FL<NL, B> s2 = fl_mul(b.y, a.zzz, P);
+    FL<NL, B> p = fl_sub(u2, u1, P.c2);
+    fl_norm(p);
+    FL<NL, B> r = fl_sub(s2, s1, P.c2);
+    fl_norm(r);
+    const FL<NL, B> pp = fl_sqr(p, P);
+    if (fl_is_zero_mod_p_lt3p(pp, P)) {
+        const FL<NL, B> rc = fl_canon_small(r, P, 4);
+        if (fl_all_zero(rc)) return xyzzl_dbl(a, P);
+        return xyzzl_inf<NL, B>();
+    }
+    XyzzL<NL, B> o;
+    const FL<NL, B> ppp = fl_mul(p, pp, P);
+    const FL<NL, B> qq = fl_mul(u1, pp, P);
+    const FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));
+    o.x = fl_sub(fl_sqr(r, P), sub, P.c4);
+    fl_norm(o.x);
+    FL<NL, B> t = fl_sub(qq, o.x, P.c8);
+    fl_norm(t);
+    o.y = fl_sub(fl_mul(r, t, P), fl_mul(s1, ppp, P), P.c2);
+    fl_norm(o.y);
+    o.zz = fl_mul(fl_mul(a.zz, b.zz, P), pp, P);
+    o.zzz = fl_mul(fl_mul(a.zzz, b.zzz, P), ppp, P);
+    return o;
+}
+
+
+// a += b without the exceptional same-x cases: returns false (a untouched) when they occur.
+template <int NL, int B>
+__device__ __forceinline__ bool xyzzl_add_fast(XyzzL<NL, B>& a, const XyzzL<NL, B>& b, const FLParams<NL, B>& P) {
+    if (fl_all_zero(b.zz)) return true;
+    if (fl_all_zero(a.zz)) { a = b; return true; }
+    const FL<NL, B> u1 = fl_mul(a.x, b.zz, P);
+    const FL<NL, B> u2 = fl_mul(b.x, a.zz, P);
+    const FL<NL, B> s1 = fl_mul(a.y, b.zzz, P);
+    const FL<NL, B> s2 = fl_mul(b.y, a.zzz, P);
+    FL<NL, B> p = fl_sub(u2, u1, P.c2);
+    fl_norm(p);
+    FL<NL, B> r = fl_sub(s2, s1, P.c2);
+    fl_norm(r);
+    const FL<NL, B> pp = fl_sqr(p, P);
+    if (fl_is_zero_mod_p_lt3p(pp, P)) return false;
+    const FL<NL, B> ppp = fl_mul(p, pp, P);
+    const FL<NL, B> qq = fl_mul(u1, pp, P);
+    const FL<NL, B> sub = fl_add(ppp, fl_add(qq, qq));
+    FL<NL, B> x3 = fl_sub(fl_sqr(r, P), sub, P.c4);
+    fl_norm(x3);
+    FL<NL, B> t = fl_sub(qq, x3, P.c8);
+    fl_norm(t);
+    FL<NL, B> y3 = fl_sub(fl_mul(r, t, P), fl_mul(s1, ppp, P), P.c2);
+    fl_norm(y3);
+    a.zz = fl_mul(fl_mul(a.zz, b.zz, P), pp, P);
+    a.zzz = fl_mul(fl_mul(a.zzz, b.zzz, P), ppp, P);
+    a.x = x3;
+    a.y = y3;
+    return true;
+}

@@ -329,8 +329,8 @@ __global__ void __launch_bounds__(256) bases_to_limbs_kernel(const AffPt<NQ>* __
 }
 
 template <int NQ>
-__device__ __forceinline__ void store_bucket(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& acc,
-                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& P) {
+__device__ __forceinline__ void store_std(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& acc,
+                                          const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     // back to the canonical R = 2^(32N) Montgomery form the rest of the pipeline (and the reference) uses
     const FL<NL, B> rs = fl_load_const<NL, B>(P.r_std);
@@ -342,6 +342,8 @@ __device__ __forceinline__ void store_bucket(XyzzPt<NQ>* dst, const XyzzL<LimbGe
     store16(dst, o);
 }
 
+#define HEAVY_BUCKET 2048u      // entries above which a bucket is shared by HEAVY_SEGS workgroups
+#define HEAVY_SEGS 8
 // Hot kernel: lane i owns bucket order[i] (size-sorted).  Exceptional additions (same x) abort the
 // bucket, which is queued for msm_accumulate_redo_kernel — keeps calls, scratch and the doubling
 // formula out of this kernel.
@@ -349,14 +351,19 @@ template <int NQ>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ order, uint64_t nbuckets,
-                                                             XyzzPt<NQ>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
-                                                             uint32_t* __restrict__ redo_list,
+                                                             XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
+                                                             uint32_t* __restrict__ redo_list, uint32_t* __restrict__ heavy_count,
+                                                             uint32_t* __restrict__ heavy_list,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbuckets) return;
     const uint32_t b = order[i];
     const uint32_t beg = offsets[b], end = offsets[b + 1];
+    if (end - beg > HEAVY_BUCKET) {              // skewed scalars / a nearly empty top window: one lane must not walk it alone
+        heavy_list[atomicAdd(heavy_count, 1u)] = b;
+        return;
+    }
     XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
     bool ok = true;
     for (uint32_t j = beg; j < end; j++) {
@@ -366,14 +373,65 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
         if (e >> 31) q = affl_neg(q, P);
         if (!xyzzl_madd_fast(acc, q, P)) { ok = false; break; }
     }
-    if (ok) store_bucket<NQ>(buckets + b, acc, P);
+    if (ok) store8(buckets + b, acc);
     else redo_list[atomicAdd(redo_count, 1u)] = b;
+}
+
+// Heavy buckets: HEAVY_SEGS workgroups share one bucket (strided slices), every lane accumulates a strided subset
+// with the complete addition, an LDS tree folds the workgroup, msm_heavy_finish_kernel folds the segments.
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+                                                        const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                        const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
+                                                        XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
+                                                        const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
+    const uint32_t total = *heavy_count, seg = blockIdx.y;
+    for (uint32_t h = blockIdx.x; h < total; h += gridDim.x) {
+        const uint32_t b = heavy_list[h];
+        const uint32_t beg = offsets[b], end = offsets[b + 1];
+        XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+        for (uint32_t j = beg + seg * blockDim.x + threadIdx.x; j < end; j += HEAVY_SEGS * blockDim.x) {
+            const uint32_t e = sorted[j];
+            AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
+            if (affl_is_inf(q)) continue;                // before negating: affl_neg would turn (0,0) into (0, 2p)
+            if (e >> 31) q = affl_neg(q, P);
+            acc = xyzzl_madd(acc, q, P);
+        }
+        __syncthreads();
+        sh[threadIdx.x] = acc;
+        __syncthreads();
+        for (int d = blockDim.x / 2; d > 0; d >>= 1) {
+            if ((int)threadIdx.x < d) {
+                const XyzzL<NL, B> a = sh[threadIdx.x], b2 = sh[threadIdx.x + d];
+                sh[threadIdx.x] = xyzzl_add(a, b2, P);
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) store8(partial + (uint64_t)h * HEAVY_SEGS + seg, sh[0]);
+    }
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(64) msm_heavy_finish_kernel(const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
+                                                              const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
+                                                              XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets,
+                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint32_t total = *heavy_count;
+    for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < total; h += gridDim.x * blockDim.x) {
+        XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+        for (int s = 0; s < HEAVY_SEGS; s++) acc = xyzzl_add(acc, load8(partial + (uint64_t)h * HEAVY_SEGS + s), P);
+        store8(buckets + heavy_list[h], acc);
+    }
 }
 
 template <int NQ>
 __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                                 XyzzPt<NQ>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
+                                                                 XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
                                                                  const uint32_t* __restrict__ redo_list,
                                                                  const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
@@ -389,59 +447,95 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
             if (e >> 31) q = affl_neg(q, P);
             acc = xyzzl_madd(acc, q, P);
         }
-        store_bucket<NQ>(buckets + b, acc, P);
+        store8(buckets + b, acc);
     }
 }
 
+#define REDUCE_LOGK 2
+#define REDUCE_K (1u << REDUCE_LOGK)
 // ---------------------------------------------------------------------------------------------- 5: window reduction
-// chunk (w, ch) covers bucket indices j in [ch*K, (ch+1)*K) of a window with 2^cb buckets (bucket j holds
-// the digit magnitude j+1): out = sum_j (j+1) * B_j
+// V_w = sum_j (j+1) * B_j over the 2^cb buckets of a window, as a short pyramid of running-sum passes:
+//   level l holds n_l = 2^cb / K^l entries (K = REDUCE_K = 4: the serial depth 2K*log_K(2^cb) is what bounds
+//   this phase, not its work); one lane takes a chunk of min(K, n_l) entries and emits
+//   acc = sum_t t * E_t  and  S = sum_t E_t  (2K point additions, no scalar multiplications);
+//   the S values are the next level's entries.  With A_l = sum of level l's acc values and Sigma = the single
+//   entry left at the top:  V_w = Sigma + sum_l K^l * A_l   (host: a handful of doublings per window).
+// All in lazy limb arithmetic (ec_lazy.cuh); only the W*(L+1) results are converted to the standard form.
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_reduce_chunks_kernel(const XyzzPt<NQ>* __restrict__ buckets, int cb, int logk, uint64_t nchunks_total,
-                                                                XyzzPt<NQ>* __restrict__ chunk_out, const FpParams<NQ> P) {
+__global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ in, uint64_t n_in,
+                                                               uint32_t K, uint64_t nch, uint64_t total,
+                                                               XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_acc,
+                                                               XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_s,
+                                                               uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_list,
+                                                               const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= nchunks_total) return;
-    const uint64_t nch = (uint64_t)1 << (cb - logk);
+    if (id >= total) return;
     const uint64_t w = id / nch, ch = id % nch;
-    const uint64_t K = (uint64_t)1 << logk;
-    const XyzzPt<NQ>* Bk = buckets + (w << cb) + ch * K;
-    XyzzPt<NQ> running = xyzz_inf<NQ>(), acc = xyzz_inf<NQ>();
-    for (uint64_t d = K; d-- > 0;) {
-        acc = xyzz_add_cold(acc, running, P);
-        const XyzzPt<NQ> bd = load16(Bk + d);
-        running = xyzz_add_cold(running, bd, P);
+    const XyzzL<NL, B>* E = in + w * n_in + ch * K;
+    XyzzL<NL, B> running = xyzzl_inf<NL, B>(), acc = xyzzl_inf<NL, B>();
+    bool ok = true;
+    for (uint32_t d = K; d-- > 0;) {
+        if (!xyzzl_add_fast(acc, running, P)) { ok = false; break; }
+        if (!xyzzl_add_fast(running, load8(E + d), P)) { ok = false; break; }
     }
-    // acc = sum (j - lo) B_j ; add (lo + 1) * S, lo = ch*K  (MSB-first double-and-add)
-    if (!xyzz_is_inf(running)) {
-        const uint64_t k = ch * K + 1;
-        XyzzPt<NQ> m = xyzz_inf<NQ>();
-        for (int i = cb; i >= 0; i--) {
-            m = xyzz_dbl_cold(m, P);
-            if ((k >> i) & 1) m = xyzz_add_cold(m, running, P);
-        }
-        acc = xyzz_add_cold(acc, m, P);
+    if (ok) {
+        store8(out_acc + id, acc);
+        store8(out_s + id, running);
+    } else {
+        redo_list[atomicAdd(redo_count, 1u)] = (uint32_t)id;      // same-x additions: redone by the complete kernel
     }
-    store16(chunk_out + id, acc);
 }
 
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_window_sum_kernel(const XyzzPt<NQ>* __restrict__ chunks, uint64_t nch, XyzzPt<NQ>* __restrict__ wsum,
-                                                             const FpParams<NQ> P) {
+__global__ void __launch_bounds__(64) msm_reduce_level_redo_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ in, uint64_t n_in,
+                                                                   uint32_t K, uint64_t nch,
+                                                                   XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_acc,
+                                                                   XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_s,
+                                                                   const uint32_t* __restrict__ redo_count, const uint32_t* __restrict__ redo_list,
+                                                                   const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint32_t total = *redo_count;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const uint64_t id = redo_list[i];
+        const uint64_t w = id / nch, ch = id % nch;
+        const XyzzL<NL, B>* E = in + w * n_in + ch * K;
+        XyzzL<NL, B> running = xyzzl_inf<NL, B>(), acc = xyzzl_inf<NL, B>();
+        for (uint32_t d = K; d-- > 0;) {
+            acc = xyzzl_add(acc, running, P);
+            running = xyzzl_add(running, load8(E + d), P);
+        }
+        store8(out_acc + id, acc);
+        store8(out_s + id, running);
+    }
+}
+
+// block (l, w): sum of `count[l]` consecutive limb-form points starting at src[l] + w*count[l]  ->  standard form
+struct SumJobs {
+    const void* src[16];
+    uint64_t count[16];
+};
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels,
+                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    XyzzPt<NQ>* sh = reinterpret_cast<XyzzPt<NQ>*>(smem_raw);
-    const uint64_t w = blockIdx.x;
-    XyzzPt<NQ> acc = xyzz_inf<NQ>();
-    for (uint64_t i = threadIdx.x; i < nch; i += blockDim.x) acc = xyzz_add_cold(acc, load16(chunks + w * nch + i), P);
+    XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
+    const uint32_t l = blockIdx.x, w = blockIdx.y;
+    const uint64_t cnt = jobs.count[l];
+    const XyzzL<NL, B>* src = reinterpret_cast<const XyzzL<NL, B>*>(jobs.src[l]) + (uint64_t)w * cnt;
+    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+    for (uint64_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int d = blockDim.x / 2; d > 0; d >>= 1) {
         if ((int)threadIdx.x < d) {
-            XyzzPt<NQ> a = sh[threadIdx.x], b = sh[threadIdx.x + d];
-            sh[threadIdx.x] = xyzz_add_cold(a, b, P);
+            const XyzzL<NL, B> a = sh[threadIdx.x], b2 = sh[threadIdx.x + d];
+            sh[threadIdx.x] = xyzzl_add(a, b2, P);
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store16(wsum + w, sh[0]);
+    if (threadIdx.x == 0) store_std<NQ>(out + (uint64_t)w * nlevels + l, sh[0], P);
 }
 
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
@@ -491,13 +585,30 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------- host orchestration
+// level-1 partition bits of the sort for (cb, n); returns false when the packed 32-bit entry cannot hold it
+static bool sort_geometry(int cb, size_t n, int* lp_out, int* idx_bits_out) {
+    int idx_bits = 1;
+    while (((uint64_t)1 << idx_bits) < n) idx_bits++;
+    const int lp = std::min(cb, std::max(std::min(cb, 10), cb + idx_bits + 1 - 32));
+    if (lp > 13 || cb - lp > 11) return false;
+    *lp_out = lp;
+    *idx_bits_out = idx_bits;
+    return true;
+}
+
+static double g_reduce_cost = 2.7 * 3300.0 * 2.0;     // VALU instructions per bucket in the reduction pyramid (x2: it runs at lower occupancy)
 static int choose_window(size_t n, int bits) {
+    // measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
+    // addition; the reduction pyramid does ~2.7 full additions per bucket
     double best = 1e300;
     int bc = 4;
-    for (int c = 4; c <= 18; c++) {
+    for (int c = 4; c <= 20; c++) {
+        int lp, ib;
+        if (!sort_geometry(c - 1, n, &lp, &ib)) continue;
         const int W = (bits + 1 + c - 1) / c;
-        // madd ~10 field products per (point, window); chunked reduction ~2.5 full adds (14 products) per bucket
-        const double cost = (double)W * ((double)n * 10.0 + (double)((size_t)1 << (c - 1)) * 2.5 * 14.0 * 2.0);
+        const int top_bits = bits - (W - 1) * c;               // entropy of the last window's digit
+        if (W > 1 && top_bits < std::min(c - 3, 8)) continue;  // a near-empty top window puts every point in a few buckets
+        const double cost = (double)W * ((double)n * 2480.0 + (double)((size_t)1 << (c - 1)) * g_reduce_cost);
         if (cost < best) { best = cost; bc = c; }
     }
     return bc;
@@ -519,20 +630,15 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
                      int window_bits, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
-    const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 22) : choose_window(n, bits);
+    const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits);
     const int W = (bits + 1 + c - 1) / c;              // signed digits: one spare bit for the last carry
     const int cb = c - 1;                              // 2^(c-1) buckets per window
     const uint64_t nb = (uint64_t)1 << cb, nbuckets = (uint64_t)W * nb;
-    const int logk = std::min(cb, 4);
-    const uint64_t nch = nb >> logk, nchunks_total = (uint64_t)W * nch;
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
     SortGeom g;
     g.n = n; g.W = W; g.cb = cb;
-    g.idx_bits = 1;
-    while (((uint64_t)1 << g.idx_bits) < n) g.idx_bits++;
-    g.lp = std::min(cb, std::max(std::min(cb, 10), cb + g.idx_bits + 1 - 32));
+    if (!sort_geometry(cb, n, &g.lp, &g.idx_bits)) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
     g.low_bits = cb - g.lp;
-    if (g.lp > 13 || g.low_bits > 11) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
     g.nblk = (uint32_t)((n + SORT_SLICE - 1) / SORT_SLICE);
     g.nreal = (uint32_t)W << g.lp;
     const uint64_t nhist = ((uint64_t)g.nreal + W) * g.nblk;
@@ -549,9 +655,25 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_order = off; off = align_up(off + nbuckets * 4, 256);
     const size_t o_redo = off; off = align_up(off + (nbuckets + 1) * 4, 256);
     const size_t o_szh = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
-    const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(XyzzPt<NQ>), 256);
-    const size_t o_chunks = off; off = align_up(off + nchunks_total * sizeof(XyzzPt<NQ>), 256);
-    const size_t o_wsum = off; off = align_up(off + (size_t)W * sizeof(XyzzPt<NQ>), 256);
+    const uint64_t max_heavy = ((uint64_t)n * W) / HEAVY_BUCKET + 1;     // a bucket is heavy only above HEAVY_BUCKET entries
+    const size_t o_heavy = off; off = align_up(off + (max_heavy + 1) * 4, 256);
+    typedef XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> BucketL;
+    // reduction pyramid geometry
+    int nlev = 0;
+    uint64_t lev_n[16], lev_k[16], lev_nch[16];
+    for (uint64_t cur = nb; cur > 1 && nlev < 15; nlev++) {
+        lev_n[nlev] = cur;
+        lev_k[nlev] = std::min<uint64_t>(REDUCE_K, cur);
+        lev_nch[nlev] = cur / lev_k[nlev];
+        cur = lev_nch[nlev];
+    }
+    uint64_t pyr = 0;
+    for (int l = 0; l < nlev; l++) pyr += (uint64_t)W * lev_nch[l];
+    const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(BucketL), 256);
+    const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
+    const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
+    const size_t o_wsum = off; off = align_up(off + (size_t)W * (nlev + 1) * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
     char* base = (char*)ws.d_buf;
@@ -564,11 +686,14 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     uint32_t* sorted = (uint32_t*)(base + o_sorted);
     uint32_t* order = (uint32_t*)(base + o_order);
     uint32_t* redo = (uint32_t*)(base + o_redo);            // [0] = count, [1..] = list
+    uint32_t* heavy = (uint32_t*)(base + o_heavy);          // [0] = count, [1..] = list
     uint32_t* ghist = (uint32_t*)(base + o_szh);
     uint32_t* bin_cursor = ghist + SIZE_BINS;
-    XyzzPt<NQ>* buckets = (XyzzPt<NQ>*)(base + o_buckets);
-    XyzzPt<NQ>* chunks = (XyzzPt<NQ>*)(base + o_chunks);
+    BucketL* buckets = (BucketL*)(base + o_buckets);
+    BucketL* acc_arr = (BucketL*)(base + o_acc);
+    BucketL* s_arr = (BucketL*)(base + o_sarr);
     XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
+    BucketL* hpart = (BucketL*)(base + o_hpart);
 
     const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
     { ProfScope ps("msm_digits_kernel", stream);
@@ -583,36 +708,64 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     { ProfScope ps("msm_bucket_order", stream);
     HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
+    HIP_TRY(hipMemsetAsync(heavy, 0, 4, stream));
     const uint32_t bgrid = (uint32_t)((nbuckets + 255) / 256);
     hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, ghist);
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
     hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, bin_cursor, order); }
     { ProfScope ps("msm_accumulate_kernel", stream);
     hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                       nbuckets, buckets, redo, redo + 1, fl_params<NQ>(curve)); }
+                       nbuckets, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
+    { ProfScope ps("msm_heavy", stream);
+    hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, heavy, heavy + 1,
+                       hpart, fl_params<NQ>(curve));
+    hipLaunchKernelGGL(msm_heavy_finish_kernel<NQ>, dim3(16), dim3(64), 0, stream, heavy, heavy + 1, hpart, buckets, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_accumulate_redo_kernel", stream);
     hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, buckets, redo, redo + 1,
                        fl_params<NQ>(curve)); }
-    { ProfScope ps("msm_reduce_chunks_kernel", stream);
-    hipLaunchKernelGGL(msm_reduce_chunks_kernel<NQ>, dim3((uint32_t)((nchunks_total + 255) / 256)), dim3(256), 0, stream, buckets, cb, logk,
-                       nchunks_total, chunks, P); }
-    const uint32_t wthreads = (uint32_t)std::min<uint64_t>(256, std::max<uint64_t>(1, nch));
-    // blockDim must be a power of two for the tree
-    uint32_t wt = 1;
-    while (wt * 2 <= wthreads) wt *= 2;
-    { ProfScope ps("msm_window_sum_kernel", stream);
-    hipLaunchKernelGGL(msm_window_sum_kernel<NQ>, dim3((uint32_t)W), dim3(wt), wt * sizeof(XyzzPt<NQ>), stream, chunks, nch, wsum, P); }
+    {
+        ProfScope ps("msm_reduce", stream);
+        SumJobs jobs;
+        memset(&jobs, 0, sizeof jobs);
+        const BucketL* in = buckets;
+        uint64_t at = 0;
+        for (int l = 0; l < nlev; l++) {
+            const uint64_t total_chunks = (uint64_t)W * lev_nch[l];
+            HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));          // the accumulate redo list is dead by now: reuse it per level
+            hipLaunchKernelGGL(msm_reduce_level_kernel<NQ>, dim3((uint32_t)((total_chunks + 255) / 256)), dim3(256), 0, stream, in, lev_n[l],
+                               (uint32_t)lev_k[l], lev_nch[l], total_chunks, acc_arr + at, s_arr + at, redo, redo + 1, fl_params<NQ>(curve));
+            hipLaunchKernelGGL(msm_reduce_level_redo_kernel<NQ>, dim3(64), dim3(64), 0, stream, in, lev_n[l], (uint32_t)lev_k[l], lev_nch[l],
+                               acc_arr + at, s_arr + at, redo, redo + 1, fl_params<NQ>(curve));
+            jobs.src[l] = acc_arr + at;
+            jobs.count[l] = lev_nch[l];
+            in = s_arr + at;
+            at += total_chunks;
+        }
+        jobs.src[nlev] = in;            // the single entry left per window: Sigma (nb == 1: the bucket itself)
+        jobs.count[nlev] = 1;
+        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, W), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
+                           fl_params<NQ>(curve));
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
 
-    std::vector<XyzzPt<NQ>> h(W);
-    HIP_TRY(hipMemcpyAsync(h.data(), wsum, (size_t)W * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
+    std::vector<XyzzPt<NQ>> h((size_t)W * (nlev + 1));
+    HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     for (int w = W - 1; w >= 0; w--) {
+        // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
+        const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1);
+        XyzzPt<NQ> v = xyzz_inf<NQ>();
+        for (int l = nlev - 1; l >= 0; l--) {
+            if (!xyzz_is_inf(v))
+                for (int k = 0; k < REDUCE_LOGK; k++) v = xyzz_dbl(v, P);
+            v = xyzz_add(v, hw[l], P);
+        }
+        v = xyzz_add(v, hw[nlev], P);
         if (!xyzz_is_inf(total))
             for (int k = 0; k < c; k++) total = xyzz_dbl(total, P);
-        total = xyzz_add(total, h[w], P);
+        total = xyzz_add(total, v, P);
     }
     *h_result = total;
     return PLONK_OK;

@@ -107,3 +107,53 @@ def test_synth_inputs_match_oracle(gpu_workers, oracle):
         assert all(oracle.on_curve(cid, p) for p in pts[:50])
         assert len({p.tobytes() for p in pts}) == 300
         pb.free()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_msm_single_repeated_base_hits_every_exceptional_path(gpu_workers, oracle, curve, cid):
+    """All bases equal: every bucket is a multiple of one point, so bucket accumulation meets P + P on its
+    second addition and the reduction pyramid keeps adding equal / opposite points.  sum_i s_i * P = (sum_i s_i) * P."""
+    w = gpu_workers(curve)
+    for n, small in [(4096, False), (3000, True)]:
+        bases = oracle.gen_bases(cid, 4, 1, n)
+        sc = oracle.from_mont(cid, oracle.rand_fr(cid, 6, n))
+        if small:                                  # tiny scalars: only window 0 is populated, buckets 1..16 heavily
+            sc[:] = 0
+            sc[:, 0] = np.arange(n) % 17
+        p = int.from_bytes(oracle.field_const(cid, 0, 0).tobytes(), "little")
+        tot = sum(int.from_bytes(s.tobytes(), "little") for s in sc) % p
+        k = np.array([(tot >> (64 * i)) & (2**64 - 1) for i in range(4)], dtype=np.uint64)
+        w.init(bases, 0, 0)
+        got, gi = w.g1_to_affine(w.var_msm(MsmWorkload(0, n), sc))
+        exp, ei = oracle.jac_to_affine(cid, oracle.scalar_mul(cid, bases[0], k))
+        assert gi == ei and np.array_equal(got, exp)
+
+
+def test_msm_skewed_scalars_and_forced_windows(gpu_workers, oracle):
+    """Distributions that put (almost) every point of a window into one bucket — real witnesses are full of 0/1
+    values, and a window width that leaves two bits for the top window does it for uniform scalars too.
+    Buckets above 2048 entries are shared by several workgroups (msm_heavy_kernel)."""
+    w = gpu_workers("bn254")
+    n = 1 << 16
+    bases = oracle.gen_bases(0, 12, 257, n)
+    bases[100] = 0
+    inf = np.zeros(n, dtype=np.uint8); inf[100] = 1
+    w.init(bases, 0, 0)
+    rnd = oracle.from_mont(0, oracle.rand_fr(0, 13, n))
+    cases = {}
+    same = np.repeat(rnd[:1], n, axis=0)                       # one scalar everywhere: one bucket per window
+    cases["all-equal"] = same
+    small = np.zeros((n, 4), dtype=np.uint64); small[:, 0] = np.arange(n) % 3      # 0 / 1 / 2
+    cases["tiny"] = small
+    ones = np.zeros((n, 4), dtype=np.uint64); ones[:, 0] = 1
+    cases["all-ones"] = ones
+    try:
+        for name, sc in cases.items():
+            got = w.var_msm(MsmWorkload(0, n), sc)
+            assert _affine_eq(w, oracle, 0, got, oracle.msm(0, bases, sc, inf, threads=8)), name
+        for c in (18, 12, 5):                                  # 18: two bits left for the top window of a 254-bit scalar
+            w.set_option("msm_window", c)
+            got = w.var_msm(MsmWorkload(0, n), rnd)
+            assert _affine_eq(w, oracle, 0, got, oracle.msm(0, bases, rnd, inf, threads=8)), c
+    finally:
+        w.set_option("msm_window", 0)
