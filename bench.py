@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
     ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=17)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=19)
     return ap.parse_args()
 
 
@@ -156,7 +156,7 @@ def main():
     # ---- roofline of the dominant kernel (HIP events recorded around every launch in the timed region)
     kernels = {}
     for name in ["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order",
-                 "msm_accumulate_redo_kernel", "msm_reduce"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)]:
+                 "msm_accumulate_redo_kernel", "msm_heavy", "msm_reduce"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)]:
         ms, cnt = w.profile_get(name)
         if cnt:
             kernels[name] = {"total_ms": ms, "launches": int(cnt), "avg_ms": ms / cnt}

@@ -155,7 +155,7 @@ int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms);
 
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel launch
  * (off by default).  Names: "ntt_pass_kernel", "ntt_pass_kernel<9>" (per in-LDS size),
- * "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_accumulate_redo_kernel",
+ * "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_accumulate_redo_kernel", "msm_heavy",
  * "msm_reduce".  total_ms / launches accumulate until reset. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_reset(plonk_ctx* ctx);

@@ -105,3 +105,23 @@ def test_ntt_full_size_round_trip_and_sample(gpu_workers, oracle, log_n):
         full = b.download((N, 4))
         assert np.array_equal(full[:: N // M], oracle.ntt(0, x, False, False))
     a.free(); b.free()
+
+
+def test_ntt_maximum_domain_2p28(gpu_workers):
+    """BN254's largest radix-2 domain (two-adicity 28; configs[4] is an n = 2^28 transform): four 2^7 passes over
+    8 GiB, every element must survive NTT -> iNTT; 2^29 is a DomainCreationError."""
+    from distributed_plonk_amd._ffi import PlonkError
+    w = gpu_workers("bn254")
+    N = 1 << 28
+    a, b, c = w.alloc(N * 32), w.alloc(N * 32), w.alloc(N * 32)
+    w.synth_fr(28, a.ptr, N)
+    w.memcpy_d2d(c.ptr, a.ptr, N * 32)
+    w.ntt_dev(c.ptr, b.ptr, N, False, True)
+    w.ntt_dev(b.ptr, c.ptr, N, True, True)
+    CH = 1 << 23
+    for off in range(0, N, CH):
+        assert np.array_equal(c.download((CH, 4), byte_offset=off * 32), a.download((CH, 4), byte_offset=off * 32)), off
+    with pytest.raises(PlonkError) as e:
+        w.ntt_dev(a.ptr, b.ptr, 1 << 29, False, False)
+    assert e.value.code == -2
+    a.free(); b.free(); c.free()
