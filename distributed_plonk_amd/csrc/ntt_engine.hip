@@ -8,6 +8,7 @@
 #include "ntt_kernels.cuh"
 #include "plonk_internal.hpp"
 
+static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
 static int g_ntt_max_log_r = NTT_LOG_RMAX;
 void ntt_set_ept(int v);
 void ntt_set_max_log_r(int v) { g_ntt_max_log_r = std::max(3, std::min(v, NTT_LOG_RMAX)); }
@@ -104,11 +105,11 @@ static int get_scaled_lo(NttTables& T, int log_m, F29** out, hipStream_t stream)
 // Inter-pass factor plane (ntt_gen_plane_kernel) for pass `p` of a size-2^log_m transform, cached per
 // (log_m, r_prev, r_p, direction, inverse-scale folded, coset folded).  Returns nullptr (no error) when the plane
 // budget is exhausted — the pass then forms its factors on the fly.
-static int get_plane(NttTables& T, int log_m, int log_rprev, int log_rp, int dir, bool fold_scale, bool fold_coset, Fr** out,
-                     hipStream_t stream) {
+static int get_plane(NttTables& T, int log_m, int log_rprev, int log_rp, int dir, bool fold_scale, bool fold_coset, int log_coset_mult,
+                     Fr** out, hipStream_t stream) {
     *out = nullptr;
-    const uint64_t key = ((uint64_t)log_m << 32) | ((uint64_t)log_rprev << 24) | ((uint64_t)log_rp << 16) | ((uint64_t)dir << 2) |
-                         ((uint64_t)fold_scale << 1) | (uint64_t)fold_coset;
+    const uint64_t key = ((uint64_t)log_m << 32) | ((uint64_t)log_rprev << 24) | ((uint64_t)log_rp << 16) | ((uint64_t)log_coset_mult << 8) |
+                         ((uint64_t)dir << 2) | ((uint64_t)fold_scale << 1) | (uint64_t)fold_coset;
     auto it = T.planes.find(key);
     if (it != T.planes.end()) { *out = it->second; return PLONK_OK; }
     const uint64_t r_prev = (uint64_t)1 << log_rprev;
@@ -123,9 +124,32 @@ static int get_plane(NttTables& T, int log_m, int log_rprev, int log_rp, int dir
     if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipGetLastError(); return PLONK_OK; }     // out of memory: just no plane
     hipLaunchKernelGGL(ntt_gen_plane_kernel, dim3((uint32_t)((r_prev + 255) / 256)), dim3(256), 0, stream, d, r_prev, (uint64_t)1 << log_rp, lo,
                        T.tw_hi[dir], (uint32_t)T.lt, (uint32_t)(T.two_adicity - log_rprev), fold_coset ? T.g_lo[0] : (const F29*)nullptr,
-                       fold_coset ? T.g_hi[0] : (const F29*)nullptr, T.fp29);
+                       fold_coset ? T.g_hi[0] : (const F29*)nullptr, (uint64_t)1 << log_coset_mult, T.fp29);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "ntt_gen_plane launch: %s", hipGetErrorString(e)); }
+    T.planes[key] = d;
+    T.plane_bytes += bytes;
+    *out = d;
+    return PLONK_OK;
+}
+
+// Output-factor plane for the distributed row pass (see ntt_gen_epi_plane_kernel), cached per (N, M, batch, q0, dir, coset)
+static int get_epi_plane(NttTables& T, int log_N, int log_M, uint64_t batch, uint64_t q0, int dir, bool fold_coset, Fr** out, hipStream_t stream) {
+    *out = nullptr;
+    const uint64_t key = ((uint64_t)1 << 63) | ((uint64_t)log_N << 56) | ((uint64_t)log_M << 50) | ((uint64_t)ilog2(batch) << 44) | (q0 << 8) |
+                         ((uint64_t)dir << 1) | (uint64_t)fold_coset;
+    auto it = T.planes.find(key);
+    if (it != T.planes.end()) { *out = it->second; return PLONK_OK; }
+    const uint64_t M = (uint64_t)1 << log_M;
+    const size_t bytes = M * batch * sizeof(Fr);
+    if (T.plane_bytes + bytes > T.plane_budget) return PLONK_OK;
+    Fr* d = nullptr;
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipGetLastError(); return PLONK_OK; }
+    hipLaunchKernelGGL(ntt_gen_epi_plane_kernel, dim3((uint32_t)((M * batch + 255) / 256)), dim3(256), 0, stream, d, M, batch, q0, T.tw_lo[dir],
+                       T.tw_hi[dir], (uint32_t)T.lt, (uint32_t)(T.two_adicity - log_N), fold_coset ? T.g_lo[0] : (const F29*)nullptr,
+                       fold_coset ? T.g_hi[0] : (const F29*)nullptr, T.fp29);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "ntt_gen_epi_plane launch: %s", hipGetErrorString(e)); }
     T.planes[key] = d;
     T.plane_bytes += bytes;
     *out = d;
@@ -159,7 +183,6 @@ std::vector<int> ntt_plan_widths(int log_m) {
     return w;
 }
 
-static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
 
 static int pref_log_t(int log_r) {
     static const char* ept_env = getenv("PLONK_NTT_EPT");
@@ -236,6 +259,11 @@ static hipError_t launch_pass(int log_r, const NttPassParams& P, uint64_t grid, 
     return hipErrorInvalidValue;
 }
 
+static bool planes_on_global() {
+    static const bool on = getenv("PLONK_NTT_NO_PLANES") == nullptr;
+    return on;
+}
+
 int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     const int L = c.log_m;
     if (L < 1 || L > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "ntt_run: log size %d outside [1,%d]", L, T.two_adicity);
@@ -252,9 +280,23 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
 
     // forward coset shift of a whole contiguous vector: x[n] * g^n with n = a*r_1 + b splits into a per-row table
     // (g^(a*r_1), applied at load) and g^b folded into the first inter-pass plane
-    const bool simple_coset = c.pro.kind == 1 && c.pro.aq == 0 && c.pro.a0 == 0 && c.pro.bq == 0 && c.pro.b0 == 1 && c.q_offset == 0;
+    // Forward coset shifts handled without per-element exponent arithmetic:  g^(pos*B0 + AQ*(q+q0)),  B0 a power of two,
+    // pos = a*r_1 + b   =>   row table g^(B0*r_1*a) at load,  g^(B0*b) folded into the first plane,  and the per-array
+    // constant g^(q+q0) (AQ = 1: the distributed row pass, worker.rs:75-80) folded into the output-factor plane.
+    const bool pro_pow2 = c.pro.b0 != 0 && (c.pro.b0 & (c.pro.b0 - 1)) == 0;
+    const bool simple_coset = c.pro.kind == 1 && c.pro.a0 == 0 && c.pro.bq == 0 && pro_pow2 && c.pro.aq <= 1;
+    const int log_b0 = simple_coset ? ilog2(c.pro.b0) : 0;
+    // the distributed row pass's output factor w_N^(+-(q+q0)*k)
+    const bool row_twiddle = (c.epi.kind == 3 || c.epi.kind == 4) && c.epi.bq == 1 && c.epi.b0 == 0 && c.epi.aq == 0 && c.epi.a0 == 0;
+    const bool need_q_const = simple_coset && c.pro.aq == 1;      // only foldable into an output-factor plane
+    Fr* epi_plane = nullptr;
+    if (planes_on_global() && row_twiddle && !interleaved && (!need_q_const || NP >= 2)) {
+        int rc = get_epi_plane(T, c.epi.log_order, L, Bt, c.q_offset, c.epi.kind - 3, need_q_const && NP >= 2, &epi_plane, stream);
+        if (rc) return rc;
+    }
+    const bool coset_foldable = simple_coset && (!need_q_const || epi_plane != nullptr);
     bool coset_folded = false;
-    static const bool planes_on = getenv("PLONK_NTT_NO_PLANES") == nullptr;
+    const bool planes_on = planes_on_global();
     uint64_t r_prev = M;
     for (int p = 0; p < NP; p++) {
         const int w = widths[p];
@@ -282,16 +324,16 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
                 P.tw_lo = scaled;
             }
             if (planes_on) {
-                const bool want_coset = (p == 0 && simple_coset && !interleaved);
+                const bool want_coset = (p == 0 && coset_foldable && !interleaved);
                 Fr* plane = nullptr;
-                int rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, want_coset, &plane, stream);
+                int rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, want_coset, want_coset ? log_b0 : 0, &plane, stream);
                 if (rc) return rc;
                 if (plane == nullptr && want_coset) {       // no room for the folded plane: try the plain one, keep the shift in the prologue
-                    rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, false, &plane, stream);
+                    rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, false, 0, &plane, stream);
                     if (rc) return rc;
                 } else if (plane != nullptr && want_coset) {
                     coset_folded = true;
-                    int rc2 = get_rowtab(T, ilog2(r_p), w, const_cast<F29**>(&P.pro_rowtab), stream);
+                    int rc2 = get_rowtab(T, log_b0 + ilog2(r_p), w, const_cast<F29**>(&P.pro_rowtab), stream);
                     if (rc2) return rc2;
                 }
                 P.tw_plane = plane;
@@ -365,7 +407,12 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
             P.split_log = c.split_log;
             P.split_blk = c.split_blk;
             if (c.inverse && NP == 1) { P.scale_const_enabled = 1; P.scale_const = f29_const_from_mont256(T.h_pow2_inv[L], T.fp); }
-            P.epi = make_scale(T, c.epi, c.q_offset);
+            if (epi_plane != nullptr && (!need_q_const || coset_folded)) {
+                P.epi_plane = epi_plane;          // q here is the LOCAL array index: the plane was generated with q0 added
+                P.epi_qstride = M;
+            } else {
+                P.epi = make_scale(T, c.epi, c.q_offset);
+            }
             P.tile_pitch = (uint32_t)((uint64_t)1 << P.log_t);
         }
         if (p == 0 && !coset_folded) P.pro = make_scale(T, c.pro, c.q_offset);

@@ -77,6 +77,8 @@ struct NttPassParams {
     const Fr* tw_plane;                   // non-last pass: precomputed inter-pass factors, index i*r_p + b (nullable)
     uint64_t plane_rp;                    // r_p (row pitch of the plane)
     const F29* pro_rowtab;                // first pass: per-row input scale G[a] (coset shift g^(a*r_1)), nullable
+    const Fr* epi_plane;                  // last pass: precomputed output factors, index q*epi_qstride + k (nullable)
+    uint64_t epi_qstride;
     uint32_t scale_const_enabled;         // multiply outputs by `scale_const` (1/N when P==1)
     F29 scale_const;
     TwoLevelScale pro;                    // prologue (first pass) scale, idx = pos
@@ -304,7 +306,10 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         } else {
             const uint64_t q = q0 + (uint64_t)t * P.tq;
             const uint64_t k = m0 + (uint64_t)t * P.tk + (uint64_t)idx * P.kstride;
-            if (P.epi.enabled) {
+            if (P.epi_plane != nullptr) {
+                v = f29_mul(v, f29_from_sat(load_fr(P.epi_plane + q * P.epi_qstride + k)), P.fp);
+                if (P.scale_const_enabled) v = f29_mul(v, P.scale_const, P.fp);
+            } else if (P.epi.enabled) {
                 v = f29_mul(v, two_level(P.epi, k, q, P.fp), P.fp);
                 if (P.scale_const_enabled) v = f29_mul(v, P.scale_const, P.fp);
             } else if (P.scale_const_enabled) {
@@ -329,15 +334,36 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
 // stored canonical in constant form (c*2^261 mod p) as 8 x u32.
 __global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restrict__ out, uint64_t r_prev, uint64_t r_p, const F29* __restrict__ tw_lo,
                                                             const F29* __restrict__ tw_hi, uint32_t lt, uint32_t shift,
-                                                            const F29* __restrict__ g_lo, const F29* __restrict__ g_hi, const F29Params fp) {
+                                                            const F29* __restrict__ g_lo, const F29* __restrict__ g_hi, uint64_t coset_mult,
+                                                            const F29Params fp) {
     const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= r_prev) return;
     const uint64_t i = pos / r_p, b = pos % r_p;
     const uint64_t ex = (b * i) << shift, mask = ((uint64_t)1 << lt) - 1;
     F29 v = f29_mul(load_f29(tw_lo + (ex & mask)), load_f29(tw_hi + ((ex >> lt) & mask)), fp);
     if (g_lo != nullptr) {
-        const F29 g = f29_mul(load_f29(g_lo + (b & mask)), load_f29(g_hi + ((b >> lt) & mask)), fp);
+        const uint64_t eg = b * coset_mult;           // g^(b * coset_mult): the column half of the coset shift
+        const F29 g = f29_mul(load_f29(g_lo + (eg & mask)), load_f29(g_hi + ((eg >> lt) & mask)), fp);
         v = f29_mul(v, g, fp);
     }
     store_fr(out + pos, f29_to_sat(f29_canon(v, fp)));
+}
+
+
+// Output-factor plane of the distributed row pass (fft1_helper, worker.rs:86-93): plane[q*M + k] =
+// w_N^(+-(q+q0)*k) (direction in the tables), times g^(q+q0) when the forward coset shift's row constant is folded in.
+__global__ void __launch_bounds__(256) ntt_gen_epi_plane_kernel(Fr* __restrict__ out, uint64_t M, uint64_t batch, uint64_t q0,
+                                                                const F29* __restrict__ tw_lo, const F29* __restrict__ tw_hi, uint32_t lt,
+                                                                uint32_t shift, const F29* __restrict__ g_lo, const F29* __restrict__ g_hi,
+                                                                const F29Params fp) {
+    const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= M * batch) return;
+    const uint64_t q = id / M + q0, kk = id % M;
+    const uint64_t ex = (q * kk) << shift, mask = ((uint64_t)1 << lt) - 1;
+    F29 v = f29_mul(load_f29(tw_lo + (ex & mask)), load_f29(tw_hi + ((ex >> lt) & mask)), fp);
+    if (g_lo != nullptr) {
+        const F29 g = f29_mul(load_f29(g_lo + (q & mask)), load_f29(g_hi + ((q >> lt) & mask)), fp);
+        v = f29_mul(v, g, fp);
+    }
+    store_fr(out + id, f29_to_sat(f29_canon(v, fp)));
 }
