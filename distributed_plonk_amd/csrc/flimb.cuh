@@ -17,6 +17,14 @@
 
 template <int NL, int B> struct FL { uint32_t l[NL]; };
 
+// Pins a column accumulator after every v_mad_u64_u32 so the products of a column stay ONE chain; hipcc otherwise
+// reassociates them into parallel partial sums and joins them with 64-bit adds that cost as much as the mads.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FL_CHAIN(acc) asm("" : "+v"(acc))
+#else
+#define FL_CHAIN(acc) ((void)0)
+#endif
+
 template <int NL, int B> struct FLParams {
     uint32_t p[NL];       // modulus, normalised
     uint32_t p2[NL];      // 2p, normalised (zero tests)
@@ -110,21 +118,23 @@ template <int NL, int B> FP_HD FL<NL, B> fl_mul(const FL<NL, B>& x, const FL<NL,
 #pragma unroll
     for (int k = 0; k < NL; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)x.l[i] * y.l[k - i];
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)x.l[i] * y.l[k - i]; FL_CHAIN(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
         m[k] = ((uint32_t)acc * P.inv) & MASK;
-        acc += (uint64_t)m[k] * P.p[0];
+        { acc += (uint64_t)m[k] * P.p[0]; FL_CHAIN(acc); }
         acc >>= B;
+        FL_CHAIN(acc);
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)x.l[i] * y.l[k - i];
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)x.l[i] * y.l[k - i]; FL_CHAIN(acc); }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
         r.l[k - NL] = (uint32_t)acc & MASK;
         acc >>= B;
+        FL_CHAIN(acc);
     }
     r.l[NL - 1] = (uint32_t)acc;
     return r;
@@ -142,23 +152,25 @@ template <int NL, int B> FP_HD FL<NL, B> fl_sqr(const FL<NL, B>& x, const FLPara
 #pragma unroll
     for (int k = 0; k < NL; k++) {
 #pragma unroll
-        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+        for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)x.l[i] * x2[k - i]; FL_CHAIN(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)x.l[k / 2] * x.l[k / 2]; FL_CHAIN(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
         m[k] = ((uint32_t)acc * P.inv) & MASK;
-        acc += (uint64_t)m[k] * P.p[0];
+        { acc += (uint64_t)m[k] * P.p[0]; FL_CHAIN(acc); }
         acc >>= B;
+        FL_CHAIN(acc);
     }
 #pragma unroll
     for (int k = NL; k < 2 * NL - 1; k++) {
 #pragma unroll
-        for (int i = k - NL + 1; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+        for (int i = k - NL + 1; 2 * i < k; i++) { acc += (uint64_t)x.l[i] * x2[k - i]; FL_CHAIN(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)x.l[k / 2] * x.l[k / 2]; FL_CHAIN(acc); }
 #pragma unroll
-        for (int i = k - NL + 1; i < NL; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
         r.l[k - NL] = (uint32_t)acc & MASK;
         acc >>= B;
+        FL_CHAIN(acc);
     }
     r.l[NL - 1] = (uint32_t)acc;
     return r;

@@ -33,6 +33,13 @@ struct F29Params {
 };
 
 #define F29_MASK 0x1fffffffu
+// Pins the carried column accumulator so the next column's v_mad_u64_u32 chain starts FROM it: otherwise hipcc
+// reassociates, starts each column from zero and pays a 64-bit add (v_lshl_add_u64, same issue cost as a mad) to join.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define F29_CHAIN(acc) asm("" : "+v"(acc))
+#else
+#define F29_CHAIN(acc) ((void)0)
+#endif
 
 FP_HD F29 f29_from_sat(const Fp<8>& a) {
     F29 r;
@@ -99,21 +106,23 @@ FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)x.l[i] * w.l[k - i];
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)x.l[i] * w.l[k - i]; F29_CHAIN(acc); }
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
         m[k] = ((uint32_t)acc * P.inv) & F29_MASK;
         acc += (uint64_t)m[k] * P.p[0];
         acc >>= 29;
+        F29_CHAIN(acc);
     }
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)x.l[i] * w.l[k - i];
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)x.l[i] * w.l[k - i]; F29_CHAIN(acc); }
 #pragma unroll
-        for (int i = k - 8; i <= 8; i++) acc += (uint64_t)m[i] * P.p[k - i];
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
         r.l[k - 9] = (uint32_t)acc & F29_MASK;
         acc >>= 29;
+        F29_CHAIN(acc);
     }
     r.l[8] = (uint32_t)acc;
     return r;

@@ -183,7 +183,7 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
                     v[k] = f29_add(x, tt);
                     v[k + span] = f29_sub2p(x, tt, fp);
                 }
-                __builtin_amdgcn_sched_barrier(0);                     // keep one butterfly's temporaries live at a time
+                __builtin_amdgcn_sched_barrier(0);   // one butterfly's temporaries live at a time (interleaving two spills at 128 VGPRs: measured 1.6x slower)
             }
             if (ds == 1 || ds == K - 1) {
 #pragma unroll
