@@ -190,6 +190,31 @@ def main():
 
     dominant = max(roof, key=lambda k: roof[k]["total_ms"]) if roof else None
 
+    # ---- next row, measured on its own, NOT part of `value`: quotient coset evaluations over 8n points
+    next_rows = None
+    if rank == 0 and world == 1:
+        try:
+            vecs = [w.alloc(m * 32) for _ in range(25)]
+            for j, b in enumerate(vecs):
+                w.synth_fr(0xABC + j, b.ptr, m)
+            ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 3
+            ptr = [b.ptr for b in vecs]
+            w.profile_enable(True)
+            for it in range(2):
+                w.profile_reset()
+                w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], buf_m[0][1].ptr)
+                w.sync()
+            qms, _ = w.profile_get("quotient_evals_kernel")
+            w.profile_enable(False)
+            alg = 27.0 * 32 * m                     # 26 vector reads (z twice) + 1 write per point
+            next_rows = {"quotient_evals_kernel": {"points": m, "ms": round(qms, 3), "bound": "hbm", "achieved": round(alg / qms / 1e6, 1),
+                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / qms / 1e6 / HBM_PEAK_GBS, 4),
+                                                   "algorithmic_bytes": alg, "reference": "dispatcher2.rs:435-504"}}
+            for b in vecs:
+                b.free()
+        except Exception as ex:                     # the extra row must never break the headline measurement
+            next_rows = {"error": str(ex)}
+
     # ---- CPU baseline (oracle = C restatement of the reference's arkworks path), bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -230,6 +255,7 @@ def main():
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
                         for k, v in sorted(kernels.items())},
             "cpu_baseline": cpu,
+            "next_rows": next_rows,
         }
         print(json.dumps(out))
     for pair in buf_n + buf_m:

@@ -45,6 +45,11 @@ class MsmWorkload(C.Structure):          # reference src/utils.rs:21-25
         return f"MsmWorkload([{self.start},{self.end}))"
 
 
+class QuotientInputs(C.Structure):   # include/plonk_hip.h plonk_quotient_inputs (device pointers)
+    _fields_ = [("selectors", C.c_void_p * 13), ("sigmas", C.c_void_p * 5), ("wires", C.c_void_p * 5),
+                ("perm", C.c_void_p), ("pub_input", C.c_void_p)]
+
+
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/plonk_hip.h declares
@@ -82,6 +87,7 @@ SIGNATURES = {
     "plonk_synth_bases": (C.c_int, [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p]),
     "plonk_init_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "plonk_debug_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "plonk_quotient_evals_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientInputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plonk_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "plonk_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "plonk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

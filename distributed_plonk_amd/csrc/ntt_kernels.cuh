@@ -332,7 +332,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
 // Inter-pass factor plane for pass p of a size-M transform: plane[i*r_p + b] = w_{r_{p-1}}^{b*i} (times 1/M for the
 // first pass of an inverse transform via the scaled lo table, times g^b when a forward coset shift is folded in),
 // stored canonical in constant form (c*2^261 mod p) as 8 x u32.
-__global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restrict__ out, uint64_t r_prev, uint64_t r_p, const F29* __restrict__ tw_lo,
+static __global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restrict__ out, uint64_t r_prev, uint64_t r_p, const F29* __restrict__ tw_lo,
                                                             const F29* __restrict__ tw_hi, uint32_t lt, uint32_t shift,
                                                             const F29* __restrict__ g_lo, const F29* __restrict__ g_hi, uint64_t coset_mult,
                                                             const F29Params fp) {
@@ -352,7 +352,7 @@ __global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restrict__ out
 
 // Output-factor plane of the distributed row pass (fft1_helper, worker.rs:86-93): plane[q*M + k] =
 // w_N^(+-(q+q0)*k) (direction in the tables), times g^(q+q0) when the forward coset shift's row constant is folded in.
-__global__ void __launch_bounds__(256) ntt_gen_epi_plane_kernel(Fr* __restrict__ out, uint64_t M, uint64_t batch, uint64_t q0,
+static __global__ void __launch_bounds__(256) ntt_gen_epi_plane_kernel(Fr* __restrict__ out, uint64_t M, uint64_t batch, uint64_t q0,
                                                                 const F29* __restrict__ tw_lo, const F29* __restrict__ tw_hi, uint32_t lt,
                                                                 uint32_t shift, const F29* __restrict__ g_lo, const F29* __restrict__ g_hi,
                                                                 const F29Params fp) {

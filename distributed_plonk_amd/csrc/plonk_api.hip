@@ -9,6 +9,9 @@
 #include "plonk_internal.hpp"
 
 void ntt_set_max_log_r(int v);
+int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
+                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream);
+void quotient_tables_destroy(const NttTables* T);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -164,6 +167,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
+    quotient_tables_destroy(&ctx->tables);
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases) hipFree(ctx->d_bases);
     if (ctx->d_wire) hipFree(ctx->d_wire);
@@ -613,6 +617,23 @@ extern "C" int plonk_get_wire(plonk_ctx* ctx, uint64_t* out, size_t n_coeffs) {
     HIP_TRY(hipMemcpyAsync(out, ctx->d_wire, n_coeffs * 32, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- quotient evaluations (§8f rank 1)
+extern "C" int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
+                                        const uint64_t* gamma, const uint64_t* k, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!in || !alpha || !beta || !gamma || !k || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null");
+    for (int j = 0; j < 13; j++) if (!in->selectors[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null selector %d", j);
+    for (int j = 0; j < 5; j++) if (!in->sigmas[j] || !in->wires[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null sigma/wire %d", j);
+    if (!in->perm || !in->pub_input) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null perm/pub_input");
+    if (ctx->domain_size < 2 || ctx->quot_domain_size < ctx->domain_size)
+        return plonk_fail(PLONK_ERR_STATE, "plonk_quotient_evals_dev: domains not initialised (n = %zu, m = %zu)", ctx->domain_size, ctx->quot_domain_size);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = quotient_evals_run(ctx->tables, in, ctx->domain_size, ctx->quot_domain_size, alpha, beta, gamma, k, d_out, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
 }
 
 // ---------------------------------------------------------------------------------------------- memory / synth / debug

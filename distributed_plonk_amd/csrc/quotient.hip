@@ -1,0 +1,257 @@
+// quotient.hip — coset evaluations of the TurboPlonk quotient polynomial, pointwise over the m = 8n points
+// x_i = g * w_m^i  (the kernel that sits between the 25 coset-NTTs and the quotient's
+// coset-iNTT + 5 commitments; keeping it on the device removes a 25 x m x 32 B host round trip).
+//
+// What it replaces: the serial loop of /root/reference/src/dispatcher2.rs:435-504 (gate equation :459-477,
+// permutation argument :479-495, L1 term :497-503, 1/Z_H factor :372-379).  Streaming kernel: 26 loads + 2 table
+// loads and one store of 32 B per point, ~60 modular products (fp29.cuh lazy arithmetic).
+//
+// Representation bookkeeping (mont(a, b) = a*b/2^261): inputs arrive in the reference's R = 2^256 Montgomery form.
+//   wires, z            R  --(* 2^266)-->  R' = 2^261 form        (products of R' values stay in R')
+//   selector * (R' value) -> R form ;  sigma * (beta*2^266) -> R' ;  (R' value) * (alpha*2^256) -> R form
+// so every term of the final sum is back in R form without a dedicated conversion.
+#include <cstring>
+
+#include "constants.h"
+#include "ntt_kernels.cuh"
+#include "plonk_internal.hpp"
+
+struct QuotParams {
+    const Fr* sel[13];
+    const Fr* sig[5];
+    const Fr* wire[5];
+    const Fr* z;
+    const Fr* pi;
+    Fr* out;
+    uint64_t m;
+    uint32_t ratio, lt, x_shift;
+    const F29* x_lo;       // g * w_Nmax^e       (constant form = R' form)
+    const F29* x_hi;       // w_Nmax^(e << lt)
+    const Fr* inv_xm1;     // 1 / (x_i - 1), R' form, canonical, packed
+    F29Params fp;
+    F29 r2fix;             // 2^266            : R  -> R'
+    F29 gamma_rp;          // gamma * 2^261
+    F29 kbeta_rp[5];       // k_j * beta * 2^261
+    F29 beta_fix;          // beta * 2^266     : sigma (R) -> sigma*beta (R')
+    F29 alpha_r;           // alpha * 2^256    : (R') -> R
+    F29 a2n_r;             // alpha^2/n * 2^256
+    F29 zh_inv_rp[8];      // 1/Z_H(x_i) * 2^261, i < m/n
+};
+
+struct LazySum {           // sum of normalised values; limbs re-normalised every third addition
+    F29 v;
+    int pending;
+    __device__ __forceinline__ void init(const F29& a) { v = a; pending = 0; }
+    __device__ __forceinline__ void add(const F29& a) {
+        v = f29_add(v, a);
+        if (++pending == 3) { f29_norm(v); pending = 0; }
+    }
+    __device__ __forceinline__ F29 get() { if (pending) { f29_norm(v); pending = 0; } return v; }
+};
+
+__device__ __forceinline__ F29 ldq(const Fr* p, uint64_t i) { return f29_from_sat(load_fr(p + i)); }
+
+__global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.m) return;
+    const F29Params& fp = P.fp;
+    // wires and z in R' form
+    F29 w5[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) w5[j] = f29_mul(ldq(P.wire[j], i), P.r2fix, fp);
+    const F29 a = w5[0], b = w5[1], c = w5[2], d = w5[3], e = w5[4];
+    const F29 zc = f29_mul(ldq(P.z, i), P.r2fix, fp);
+    const F29 zn = f29_mul(ldq(P.z, (i + P.ratio) & (P.m - 1)), P.r2fix, fp);
+
+    // ---- gate equation (dispatcher2.rs:459-477)
+    const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+    LazySum g;
+    g.init(ldq(P.sel[11], i));                                   // q_c
+    g.add(ldq(P.pi, i));                                         // + pub_input
+    g.add(f29_mul(ldq(P.sel[0], i), a, fp));                     // q_lc
+    g.add(f29_mul(ldq(P.sel[1], i), b, fp));
+    g.add(f29_mul(ldq(P.sel[2], i), c, fp));
+    g.add(f29_mul(ldq(P.sel[3], i), d, fp));
+    g.add(f29_mul(ldq(P.sel[4], i), ab, fp));                    // q_mul
+    g.add(f29_mul(ldq(P.sel[5], i), cd, fp));
+    g.add(f29_mul(ldq(P.sel[12], i), f29_mul(f29_mul(ab, cd, fp), e, fp), fp));      // q_ecc * ab * cd * e
+#pragma unroll
+    for (int j = 0; j < 4; j++) {                                // q_hash[j] * w^5
+        const F29 w2 = f29_mul(w5[j], w5[j], fp);
+        const F29 w4 = f29_mul(w2, w2, fp);
+        g.add(f29_mul(ldq(P.sel[6 + j], i), f29_mul(w4, w5[j], fp), fp));
+    }
+    F29 gate = f29_sub2p(g.get(), f29_mul(ldq(P.sel[10], i), e, fp), fp);           // - q_o * e
+    f29_norm(gate);
+
+    // ---- evaluation point x_i = g * w_m^i and the permutation argument (:479-495)
+    const uint64_t E = i << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
+    const F29 x = f29_mul(load_f29(P.x_lo + (E & mask)), load_f29(P.x_hi + ((E >> P.lt) & mask)), fp);
+    F29 acc1 = zc, acc2 = zn;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const F29 t = f29_add(w5[j], P.gamma_rp);                                    // limbs < 2^30
+        const F29 u = f29_add(t, f29_mul(x, P.kbeta_rp[j], fp));                     // w + gamma + k_j x beta
+        const F29 v = f29_add(t, f29_mul(ldq(P.sig[j], i), P.beta_fix, fp));         // w + gamma + sigma_j beta
+        acc1 = f29_mul(u, acc1, fp);
+        acc2 = f29_mul(v, acc2, fp);
+    }
+    F29 diff = f29_sub2p(acc1, acc2, fp);
+    f29_norm(diff);
+    const F29 perm = f29_mul(diff, P.alpha_r, fp);                                   // alpha * (acc1 - acc2), R form
+
+    // ---- (z(x) - 1) * alpha^2 / (n (x - 1))  (:497-503)
+    F29 one_rp;
+#pragma unroll
+    for (int l = 0; l < 9; l++) one_rp.l[l] = fp.one[l];
+    F29 zm1 = f29_sub2p(zc, one_rp, fp);
+    f29_norm(zm1);
+    const F29 l1 = f29_mul(f29_mul(zm1, ldq(P.inv_xm1, i), fp), P.a2n_r, fp);
+
+    // ---- z_h_inv * (gate + perm) + l1
+    F29 s = f29_add(gate, perm);
+    f29_norm(s);
+    F29 r = f29_add(f29_mul(s, P.zh_inv_rp[i & (P.ratio - 1)], fp), l1);
+    f29_norm(r);                                                                     // < 2.8 p
+    r = f29_canon(f29_canon(r, fp), fp);
+    store_fr(P.out + i, f29_to_sat(r));
+}
+
+// 1/(x_i - 1) for all m points: Montgomery batch inversion over 16 consecutive points per lane, one Fermat
+// inversion per lane.  One-time per domain.
+#define QINV_CH 16
+__global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ out, uint64_t m, const F29* __restrict__ x_lo,
+                                                              const F29* __restrict__ x_hi, uint32_t lt, uint32_t x_shift, const F29Params fp,
+                                                              const F29 pm2_bits /* p - 2 as 29-bit limbs */) {
+    const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * QINV_CH;
+    if (base >= m) return;
+    const uint64_t mask = ((uint64_t)1 << lt) - 1;
+    F29 one_rp;
+#pragma unroll
+    for (int l = 0; l < 9; l++) one_rp.l[l] = fp.one[l];
+    F29 d[QINV_CH], pre[QINV_CH];
+    F29 run = one_rp;
+    for (int k = 0; k < QINV_CH; k++) {
+        const uint64_t E = (base + k) << x_shift;
+        const F29 x = f29_mul(load_f29(x_lo + (E & mask)), load_f29(x_hi + ((E >> lt) & mask)), fp);
+        F29 t = f29_sub2p(x, one_rp, fp);
+        f29_norm(t);
+        d[k] = t;
+        pre[k] = run;                       // product of d[0..k-1]
+        run = f29_mul(t, run, fp);
+    }
+    // run^(p-2)
+    F29 inv = one_rp;
+    for (int bit = 9 * 29 - 1; bit >= 0; bit--) {
+        inv = f29_mul(inv, inv, fp);
+        if ((pm2_bits.l[bit / 29] >> (bit % 29)) & 1) inv = f29_mul(inv, run, fp);
+    }
+    for (int k = QINV_CH - 1; k >= 0; k--) {
+        const F29 r = f29_mul(inv, pre[k], fp);            // 1 / d[k]
+        inv = f29_mul(d[k], inv, fp);
+        store_fr(out + base + k, f29_to_sat(f29_canon(r, fp)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+struct QuotTables {
+    F29* x_lo = nullptr;
+    std::unordered_map<int, Fr*> inv_xm1;      // key log_m
+};
+static std::unordered_map<const NttTables*, QuotTables> g_qt;
+
+void quotient_tables_destroy(const NttTables* T) {
+    auto it = g_qt.find(T);
+    if (it == g_qt.end()) return;
+    if (it->second.x_lo) (void)hipFree(it->second.x_lo);
+    for (auto& kv : it->second.inv_xm1) (void)hipFree(kv.second);
+    g_qt.erase(it);
+}
+
+static F29 host_const(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }
+
+int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
+                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    int log_n = 0, log_m = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    while (((size_t)1 << log_m) < m) log_m++;
+    if (((size_t)1 << log_n) != n || ((size_t)1 << log_m) != m || m < n || m / n > 8 || m / n < 1)
+        return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: n = %zu, m = %zu (m/n must be a power of two <= 8)", n, m);
+    if (log_m > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: 2^%d exceeds the two-adicity", log_m);
+    QuotTables& Q = g_qt[&T];
+    const uint32_t* g_l = T.curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
+    const Fr g_mont = fp_from_limbs<8>(g_l);
+    if (!Q.x_lo) {          // g * w_Nmax^e, e < 2^lt, constant form
+        const size_t cnt = (size_t)1 << T.lt;
+        std::vector<F29> h(cnt);
+        Fr acc = g_mont;
+        for (size_t i = 0; i < cnt; i++) { h[i] = host_const(acc, P); acc = fp_mul(acc, T.h_root[0], P); }
+        HIP_TRY(hipMalloc((void**)&Q.x_lo, cnt * sizeof(F29)));
+        HIP_TRY(hipMemcpyAsync(Q.x_lo, h.data(), cnt * sizeof(F29), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+    }
+    QuotParams q;
+    memset(&q, 0, sizeof q);
+    q.fp = T.fp29;
+    q.m = m;
+    q.ratio = (uint32_t)(m / n);
+    q.lt = T.lt;
+    q.x_shift = T.two_adicity - log_m;
+    q.x_lo = Q.x_lo;
+    q.x_hi = T.tw_hi[0];
+    // 1/(x_i - 1) table
+    auto it = Q.inv_xm1.find(log_m);
+    if (it == Q.inv_xm1.end()) {
+        Fr* d = nullptr;
+        HIP_TRY(hipMalloc((void**)&d, m * sizeof(Fr)));
+        Fr pm2;                                         // p - 2
+        uint64_t br = 2;
+        for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
+        const uint64_t lanes = (m + QINV_CH - 1) / QINV_CH;
+        hipLaunchKernelGGL(quotient_gen_inv_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, stream, d, (uint64_t)m, q.x_lo, q.x_hi, q.lt,
+                           q.x_shift, q.fp, f29_from_sat(pm2));
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "quotient_gen_inv launch: %s", hipGetErrorString(e)); }
+        Q.inv_xm1[log_m] = d;
+        q.inv_xm1 = d;
+    } else {
+        q.inv_xm1 = it->second;
+    }
+    // challenge-dependent constants (host; a few dozen field operations)
+    const Fr one = fp_one(P);
+    const Fr al = fp_from_limbs<8>((const uint32_t*)alpha), be = fp_from_limbs<8>((const uint32_t*)beta), ga = fp_from_limbs<8>((const uint32_t*)gamma);
+    Fr r266 = one;                                      // 2^256 mod p (plain residue) doubled ten times = 2^266
+    for (int i = 0; i < 10; i++) r266 = fp_add(r266, r266, P);
+    q.r2fix = f29_from_sat(r266);
+    q.gamma_rp = host_const(ga, P);
+    for (int j = 0; j < 5; j++) q.kbeta_rp[j] = host_const(fp_mul(fp_from_limbs<8>((const uint32_t*)k + 8 * j), be, P), P);
+    Fr b32 = be;                                        // (32 beta) in Montgomery form -> constant form = beta * 2^266
+    for (int i = 0; i < 5; i++) b32 = fp_add(b32, b32, P);
+    q.beta_fix = host_const(b32, P);
+    q.alpha_r = f29_from_sat(al);                       // alpha * 2^256 as a plain residue
+    Fr nm = fp_zero<8>();
+    nm.l[0] = (uint32_t)n; nm.l[1] = (uint32_t)((uint64_t)n >> 32);
+    nm = fp_to_mont(nm, P);
+    q.a2n_r = f29_from_sat(fp_mul(fp_sqr(al, P), fp_inv(nm, P), P));
+    Fr wm = T.h_root[0];                                // w_m = w_Nmax^(2^(s - log m))
+    for (int i = 0; i < T.two_adicity - log_m; i++) wm = fp_sqr(wm, P);
+    Fr x = g_mont;
+    for (uint32_t i = 0; i < q.ratio; i++) {
+        const Fr zh = fp_sub(fp_pow_u64(x, (uint64_t)n, P), one, P);
+        q.zh_inv_rp[i] = host_const(fp_inv(zh, P), P);
+        x = fp_mul(x, wm, P);
+    }
+    for (int j = 0; j < 13; j++) q.sel[j] = (const Fr*)in->selectors[j];
+    for (int j = 0; j < 5; j++) { q.sig[j] = (const Fr*)in->sigmas[j]; q.wire[j] = (const Fr*)in->wires[j]; }
+    q.z = (const Fr*)in->perm;
+    q.pi = (const Fr*)in->pub_input;
+    q.out = (Fr*)d_out;
+    {
+        ProfScope ps("quotient_evals_kernel", stream);
+        hipLaunchKernelGGL(quotient_evals_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, q);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "quotient_evals launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}

@@ -203,6 +203,20 @@ class PlonkWorker:
         check(self.lib.plonk_g1_to_affine(self.curve, _ptr(_u64(jac)), _ptr(out), C.byref(inf)))
         return out, bool(inf.value)
 
+    # ------------------------------------------------------------------ next row: quotient evaluations (dispatcher2.rs:362-504)
+    def quotient_evals_dev(self, selectors, sigmas, wires, perm, pub_input, alpha, beta, gamma, k, d_out: int):
+        """selectors (13), sigmas (5), wires (5): device pointers to m coset evaluations each; perm / pub_input: device
+        pointers; alpha, beta, gamma (4,) and k (5,4): Montgomery limbs on the host."""
+        q = _ffi.QuotientInputs()
+        for j in range(13):
+            q.selectors[j] = selectors[j]
+        for j in range(5):
+            q.sigmas[j] = sigmas[j]
+            q.wires[j] = wires[j]
+        q.perm, q.pub_input = perm, pub_input
+        al, be, ga, kk = _u64(alpha), _u64(beta), _u64(gamma), _u64(k)
+        check(self.lib.plonk_quotient_evals_dev(self.ctx, C.byref(q), _ptr(al), _ptr(be), _ptr(ga), _ptr(kk), d_out))
+
     # ------------------------------------------------------------------ device memory, synthetic inputs, debug
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

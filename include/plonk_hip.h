@@ -127,6 +127,23 @@ int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows);
 int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layout);
 int plonk_transpose_dev(plonk_ctx* ctx, const void* d_in, void* d_out, size_t rows, size_t cols);
 
+/* ---- next row: quotient polynomial coset evaluations — dispatcher2.rs:362-504 --------------
+ * Device pointers to the m = quot_domain_size coset evaluations the prover obtained from its 25 coset-FFTs
+ * (dispatcher2.rs:382-432), in the selector order of :443-456: q_lc[0..3], q_mul[0..1], q_hash[0..3], q_o, q_c, q_ecc. */
+typedef struct {
+    const void* selectors[13];
+    const void* sigmas[5];
+    const void* wires[5];
+    const void* perm;        /* permutation product polynomial z */
+    const void* pub_input;
+} plonk_quotient_inputs;
+/* d_out[i] = 1/Z_H(x_i) * (gate(x_i) + alpha * perm(x_i)) + alpha^2/n * (z(x_i) - 1)/(x_i - 1), x_i = g * w_m^i, exactly as
+ * the loop at dispatcher2.rs:435-504.  alpha, beta, gamma: transcript challenges; k: vk.k[0..5] — all Fr, Montgomery,
+ * host pointers.  Uses the domains fixed by plonk_init.  The quotient's coefficient form is then
+ * plonk_ntt_dev(d_out, ..., m, is_inv = 1, is_coset = 1) (dispatcher2.rs:507). */
+int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
+                             const uint64_t* gamma, const uint64_t* k, void* d_out);
+
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
 int plonk_dev_free(plonk_ctx* ctx, void* p);
@@ -156,7 +173,7 @@ int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms);
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel launch
  * (off by default).  Names: "ntt_pass_kernel", "ntt_pass_kernel<9>" (per in-LDS size),
  * "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_accumulate_redo_kernel", "msm_heavy",
- * "msm_reduce".  total_ms / launches accumulate until reset. */
+ * "msm_reduce", "quotient_evals_kernel".  total_ms / launches accumulate until reset. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_reset(plonk_ctx* ctx);
 int plonk_profile_get(plonk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

@@ -15,6 +15,7 @@ Reference call sites restated here (all under /root/reference/src):
   * dispatcher2.rs:732-787     Prover::fft orchestration
   * dispatcher.rs:218-240      sharded MSM + reduce
   * worker.rs:117-123          commit_polynomial
+  * dispatcher2.rs:362-504     quotient polynomial coset evaluations
 """
 from __future__ import annotations
 
@@ -378,3 +379,31 @@ def from_limbs(l):
 def rand_points(cv: Curve, n: int, rng: random.Random):
     G = (cv.gx, cv.gy)
     return [scalar_mul(cv, rng.randrange(1, cv.fr.p), G) for _ in range(n)]
+
+
+def quotient_evals(f: Field, n: int, sel, sig, wire, z, pi, alpha, beta, gamma, k):
+    """dispatcher2.rs:362-504 on plain residues.  sel[13][m], sig[5][m], wire[5][m], z[m], pi[m]."""
+    p = f.p
+    m = 8 * n
+    dom = Radix2Domain(f, m)
+    a2n = alpha * alpha * pow(n, -1, p) % p
+    xs = [f.generator * pow(dom.group_gen, i, p) % p for i in range(m)]
+    ratio = m // n
+    zh_inv = [pow(pow(xs[i], n, p) - 1, -1, p) for i in range(ratio)]
+    out = []
+    for i in range(m):
+        x = xs[i]
+        a, b, c, d, e = (wire[j][i] for j in range(5))
+        ab, cd = a * b % p, c * d % p
+        gate = (sel[11][i] + pi[i] + sel[0][i] * a + sel[1][i] * b + sel[2][i] * c + sel[3][i] * d + sel[4][i] * ab + sel[5][i] * cd
+                + sel[12][i] * ab * cd * e + sel[6][i] * pow(a, 5, p) + sel[7][i] * pow(b, 5, p) + sel[8][i] * pow(c, 5, p)
+                + sel[9][i] * pow(d, 5, p) - sel[10][i] * e) % p
+        acc1, acc2 = z[i], z[(i + ratio) % m]
+        for j in range(5):
+            t = (wire[j][i] + gamma) % p
+            acc1 = acc1 * (t + k[j] * x * beta) % p
+            acc2 = acc2 * (t + sig[j][i] * beta) % p
+        perm = alpha * (acc1 - acc2) % p
+        l1 = a2n * (z[i] - 1) * pow(x - 1, -1, p) % p
+        out.append((zh_inv[i % ratio] * (gate + perm) + l1) % p)
+    return out

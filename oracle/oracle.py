@@ -220,3 +220,16 @@ def round1(curve, bases, evals, blinders, inf=None, threads=1):
                           _p(poly), _p(out), threads)
     assert rc == 0
     return poly, out
+
+
+def quotient_evals(curve, log_n, sel, sig, wire, z, pi, alpha, beta, gamma, k, threads=1):
+    """dispatcher2.rs:362-504.  sel (13,m,4), sig (5,m,4), wire (5,m,4), z (m,4), pi (m,4); alpha/beta/gamma (4,), k (5,4)."""
+    m = 8 << log_n
+    sel, sig, wire, z, pi = _u64(sel), _u64(sig), _u64(wire), _u64(z), _u64(pi)
+    assert sel.shape == (13, m, 4) and sig.shape == (5, m, 4) and wire.shape == (5, m, 4) and z.shape == (m, 4) and pi.shape == (m, 4)
+    out = np.empty((m, 4), dtype=np.uint64)
+    rc = lib().orc_quotient_evals(curve, log_n, _p(sel), _p(sig), _p(wire), _p(z), _p(pi), _p(_u64(alpha)), _p(_u64(beta)),
+                                  _p(_u64(gamma)), _p(_u64(k)), _p(out), threads)
+    if rc:
+        raise ValueError("DomainCreationError")
+    return out

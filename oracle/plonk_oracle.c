@@ -29,6 +29,7 @@
  *   orc_commit_polynomial worker.rs:117-123
  *   orc_round1            worker.rs:383-408 (blinders supplied explicitly; the reference draws them
  *                         from thread_rng)
+ *   orc_quotient_evals    dispatcher2.rs:362-504 (coset evaluations of the quotient polynomial)
  *
  * Layout contract (utils.rs:27-43): Fr = 4xu64 LE Montgomery; scalars = 4xu64 LE canonical;
  * Fq = 4xu64 (BN254) / 6xu64 (BLS12-381) Montgomery; Jacobian = X||Y||Z.
@@ -634,6 +635,73 @@ int orc_round1(int curve, const uint64_t *bases, const uint8_t *inf, size_t n_ba
     fe_sub4(F, &p[0], &p[0], &b[0]); fe_sub4(F, &p[1], &p[1], &b[1]);
     fe_add4(F, &p[n], &p[n], &b[0]); fe_add4(F, &p[n + 1], &p[n + 1], &b[1]);
     return orc_commit_polynomial(curve, bases, inf, n_bases, poly_out, n + 2, out_jac, threads);
+}
+
+/* dispatcher2.rs:362-504: coset evaluations of the TurboPlonk quotient polynomial, pointwise over the m = 8n
+ * points x_i = g * w_m^i.  Inputs are the coset-FFT outputs the reference computes at :382-432 (Montgomery Fr):
+ * sel[13][m] in the order q_lc[4], q_mul[2], q_hash[4], q_o, q_c, q_ecc (:443-456), sig[5][m], wire[5][m],
+ * z[m] (permutation product polynomial), pi[m] (public input).  alpha/beta/gamma: transcript challenges,
+ * k[5]: vk.k (coset representatives).  The local coset_ifft of :507 is orc_ntt(inv, coset). */
+int orc_quotient_evals(int curve, int log_n, const uint64_t *sel, const uint64_t *sig, const uint64_t *wire, const uint64_t *z_,
+                       const uint64_t *pi_, const uint64_t *alpha_, const uint64_t *beta_, const uint64_t *gamma_, const uint64_t *k_,
+                       uint64_t *out_, int threads) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    const int log_m = log_n + 3;
+    domain_t Dm;
+    if (domain_new(C, log_m, &Dm)) return -1;
+    const size_t n = (size_t)1 << log_n, m = (size_t)1 << log_m, ratio = m / n;
+    const fe4 *S = (const fe4 *)sel, *G = (const fe4 *)sig, *Wv = (const fe4 *)wire, *Z = (const fe4 *)z_, *PI = (const fe4 *)pi_;
+    const fe4 alpha = *(const fe4 *)alpha_, beta = *(const fe4 *)beta_, gamma = *(const fe4 *)gamma_;
+    const fe4 *K = (const fe4 *)k_;
+    fe4 *out = (fe4 *)out_;
+    fe4 nf, ninv, a2n;                                     /* alpha^2 / n  (:363) */
+    fe_from_u644(F, &nf, (uint64_t)n); fe_inv4(F, &ninv, &nf);
+    fe_sqr4(F, &a2n, &alpha); fe_mul4(F, &a2n, &a2n, &ninv);
+    fe4 *xs = (fe4 *)malloc(sizeof(fe4) * m);               /* eval_points (:366-369) */
+    xs[0] = Dm.gen;
+    for (size_t i = 1; i < m; i++) fe_mul4(F, &xs[i], &xs[i - 1], &Dm.group_gen);
+    fe4 zh_inv[8];                                          /* 1 / Z_H(x_i), i < m/n (:372-379) */
+    for (size_t i = 0; i < ratio; i++) {
+        fe4 t; fe_pow_u644(F, &t, &xs[i], (uint64_t)n); fe_sub4(F, &t, &t, &F->one); fe_inv4(F, &zh_inv[i], &t);
+    }
+    if (threads < 1) threads = 1;
+#pragma omp parallel for schedule(static) num_threads(threads)
+    for (size_t i = 0; i < m; i++) {
+        const fe4 x = xs[i];
+        const fe4 a = Wv[0 * m + i], b = Wv[1 * m + i], c = Wv[2 * m + i], d = Wv[3 * m + i], e = Wv[4 * m + i];
+        fe4 ab, cd, t, gate, p5;
+        fe_mul4(F, &ab, &a, &b); fe_mul4(F, &cd, &c, &d);
+        fe_add4(F, &gate, &S[11 * m + i], &PI[i]);                                  /* q_c + pub_input */
+        fe_mul4(F, &t, &S[0 * m + i], &a); fe_add4(F, &gate, &gate, &t);            /* q_lc */
+        fe_mul4(F, &t, &S[1 * m + i], &b); fe_add4(F, &gate, &gate, &t);
+        fe_mul4(F, &t, &S[2 * m + i], &c); fe_add4(F, &gate, &gate, &t);
+        fe_mul4(F, &t, &S[3 * m + i], &d); fe_add4(F, &gate, &gate, &t);
+        fe_mul4(F, &t, &S[4 * m + i], &ab); fe_add4(F, &gate, &gate, &t);           /* q_mul */
+        fe_mul4(F, &t, &S[5 * m + i], &cd); fe_add4(F, &gate, &gate, &t);
+        fe_mul4(F, &t, &S[12 * m + i], &ab); fe_mul4(F, &t, &t, &cd); fe_mul4(F, &t, &t, &e); fe_add4(F, &gate, &gate, &t);  /* q_ecc*ab*cd*e */
+        const fe4 *ws[4] = {&a, &b, &c, &d};
+        for (int j = 0; j < 4; j++) {                                               /* q_hash[j] * w^5 */
+            fe_sqr4(F, &p5, ws[j]); fe_sqr4(F, &p5, &p5); fe_mul4(F, &p5, &p5, ws[j]);
+            fe_mul4(F, &t, &S[(6 + j) * m + i], &p5); fe_add4(F, &gate, &gate, &t);
+        }
+        fe_mul4(F, &t, &S[10 * m + i], &e); fe_sub4(F, &gate, &gate, &t);           /* - q_o*e */
+        /* permutation check (:479-495) */
+        fe4 acc1 = Z[i], acc2 = Z[(i + ratio) % m];
+        for (int j = 0; j < 5; j++) {
+            fe4 tj, u;
+            fe_add4(F, &tj, &Wv[j * m + i], &gamma);
+            fe_mul4(F, &u, &K[j], &x); fe_mul4(F, &u, &u, &beta); fe_add4(F, &u, &tj, &u); fe_mul4(F, &acc1, &acc1, &u);
+            fe_mul4(F, &u, &G[j * m + i], &beta); fe_add4(F, &u, &tj, &u); fe_mul4(F, &acc2, &acc2, &u);
+        }
+        fe4 perm; fe_sub4(F, &perm, &acc1, &acc2); fe_mul4(F, &perm, &alpha, &perm);
+        /* (z(x)-1) * alpha^2 / (n (x-1))  (:497-503) */
+        fe4 l1, den; fe_sub4(F, &l1, &Z[i], &F->one); fe_mul4(F, &l1, &a2n, &l1);
+        fe_sub4(F, &den, &x, &F->one); fe_inv4(F, &den, &den); fe_mul4(F, &l1, &l1, &den);
+        fe4 r; fe_add4(F, &r, &gate, &perm); fe_mul4(F, &r, &zh_inv[i % ratio], &r); fe_add4(F, &r, &r, &l1);
+        out[i] = r;
+    }
+    free(xs);
+    return 0;
 }
 
 int orc_max_threads(void) { return omp_get_max_threads(); }

@@ -1,0 +1,53 @@
+"""Next row: coset evaluations of the quotient polynomial (dispatcher2.rs:362-504) on the
+device vs the oracle restatement, bit-exact Montgomery limbs; then the reference's next step (:507, coset_ifft) on
+the same buffer."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n", [2, 5, 10, 13])
+def test_quotient_evals_match_oracle(gpu_workers, oracle, curve, cid, log_n):
+    w = gpu_workers(curve)
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    vecs = oracle.rand_fr(cid, 4000 + log_n, 25 * m).reshape(25, m, 4)
+    ch = oracle.rand_fr(cid, 77, 8)                         # alpha, beta, gamma, k[5]
+    alpha, beta, gamma, k = ch[0], ch[1], ch[2], ch[3:8]
+    buf = w.alloc(25 * m * 32).upload(vecs)
+    out = w.alloc(m * 32)
+    ptr = [buf.ptr + j * m * 32 for j in range(25)]
+    w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], alpha, beta, gamma, k, out.ptr)
+    want = oracle.quotient_evals(cid, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], alpha, beta, gamma, k, threads=16)
+    got = out.download((m, 4))
+    assert np.array_equal(got, want)
+    # dispatcher2.rs:507: quot_domain.coset_ifft_in_place(&mut quot_poly_coset_evals)
+    coeffs = w.alloc(m * 32)
+    w.ntt_dev(out.ptr, coeffs.ptr, m, True, True)
+    assert np.array_equal(coeffs.download((m, 4)), oracle.ntt(cid, want, True, True, threads=16))
+    for b in (buf, out, coeffs):
+        b.free()
+
+
+def test_quotient_evals_structured_inputs(gpu_workers, oracle):
+    """Zeros / ones / p-1 in the inputs (real selector vectors are sparse) and a second call reusing the cached tables."""
+    w = gpu_workers("bn254")
+    log_n = 6
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    vecs = oracle.rand_fr(0, 9, 25 * m).reshape(25, m, 4)
+    pm1 = oracle.field_const(0, 0, 0) - np.array([1, 0, 0, 0], dtype=np.uint64)
+    vecs[0:13, ::3] = 0
+    vecs[18, ::5] = oracle.field_const(0, 0, 1)            # wire a = 1 (Montgomery one)
+    vecs[23, ::7] = pm1
+    ch = oracle.rand_fr(0, 78, 8)
+    buf = w.alloc(25 * m * 32).upload(vecs)
+    out = w.alloc(m * 32)
+    ptr = [buf.ptr + j * m * 32 for j in range(25)]
+    for _ in range(2):
+        w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
+        want = oracle.quotient_evals(0, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8])
+        assert np.array_equal(out.download((m, 4)), want)
+    buf.free(); out.free()

@@ -167,3 +167,21 @@ def test_rand_fr_is_uniform_montgomery_draw():
         r = ints(O.rand_fr(cid, 9, 2000))
         assert all(x < cv.fr.p for x in r) and len(set(r)) == 2000
         assert np.array_equal(O.rand_fr(cid, 9, 10), O.rand_fr(cid, 9, 2000)[:10])       # per-index streams
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_quotient_evals_vs_bigint(name, cid, cv):
+    """Next row: dispatcher2.rs:362-504 restated in C vs the pure-Python statement."""
+    f = cv.fr
+    rng = random.Random(21)
+    for log_n in (1, 3):
+        n, m = 1 << log_n, 8 << log_n
+        rv = lambda k: [[rng.randrange(f.p) for _ in range(m)] for _ in range(k)]
+        sel, sig, wire, z, pi = rv(13), rv(5), rv(5), rv(1)[0], rv(1)[0]
+        al, be, ga = (rng.randrange(f.p) for _ in range(3))
+        k = [rng.randrange(f.p) for _ in range(5)]
+        ref = B.quotient_evals(f, n, sel, sig, wire, z, pi, al, be, ga, k)
+        M = lambda v: to_limbs([f.to_mont(x) for x in v])
+        got = O.quotient_evals(cid, log_n, np.stack([M(v) for v in sel]), np.stack([M(v) for v in sig]), np.stack([M(v) for v in wire]),
+                               M(z), M(pi), M([al])[0], M([be])[0], M([ga])[0], M(k), threads=2)
+        assert ints(got) == [f.to_mont(x) for x in ref]

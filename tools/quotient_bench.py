@@ -1,0 +1,25 @@
+"""Time the quotient-evaluation kernel on HBM-resident inputs (next row)."""
+import sys
+sys.path.insert(0, '/root/repo')
+import numpy as np
+from distributed_plonk_amd.worker import PlonkWorker
+w = PlonkWorker(0, 0, "bn254")
+for log_n in [int(a) for a in sys.argv[1:]]:
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    bufs = [w.alloc(m * 32) for _ in range(25)]
+    for j, b in enumerate(bufs):
+        w.synth_fr(100 + j, b.ptr, m)
+    out = w.alloc(m * 32)
+    ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 5
+    ptr = [b.ptr for b in bufs]
+    w.profile_enable(True)
+    for it in range(3):
+        w.profile_reset()
+        w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
+        w.sync()
+    ms, cnt = w.profile_get("quotient_evals_kernel")
+    alg = 27 * 32 * m          # 26 input reads (z twice) + 1 write of 32 B per point
+    print(log_n, "quotient ms", round(ms, 3), "algorithmic GB/s", round(alg / ms / 1e6, 1), "frac of 8 TB/s", round(alg / ms / 1e6 / 8000, 4), flush=True)
+    for b in bufs + [out]:
+        b.free()
