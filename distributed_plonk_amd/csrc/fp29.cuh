@@ -33,9 +33,12 @@ struct F29Params {
 };
 
 #define F29_MASK 0x1fffffffu
-// Pins the carried column accumulator so the next column's v_mad_u64_u32 chain starts FROM it: otherwise hipcc
-// reassociates, starts each column from zero and pays a 64-bit add (v_lshl_add_u64, same issue cost as a mad) to join.
-#if defined(__HIP_DEVICE_COMPILE__)
+// Pins a column accumulator after every v_mad_u64_u32 so a column's products stay ONE chain: otherwise hipcc
+// reassociates them into parallel partial sums and joins them with 64-bit adds that cost as much as the mads
+// (229 -> 213 VALU instructions per product).  F29_NO_PINS (set by ntt_engine.hip) turns the pins off: the NTT pass
+// kernel runs at a 128-VGPR budget (1024 lanes per tile) and the pinned form spills there (measured: 7.9 -> 12.6-22 ms
+// per 2^27-element pass); the quotient and MSM kernels have register headroom and keep them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(F29_NO_PINS)
 #define F29_CHAIN(acc) asm("" : "+v"(acc))
 #else
 #define F29_CHAIN(acc) ((void)0)
