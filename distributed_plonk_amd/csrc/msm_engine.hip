@@ -127,25 +127,62 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restri
     }
 }
 
+// Level-1 scatter.  A wave's 64 entries go to 64 different partitions, so storing them straight to HBM costs one
+// write transaction per 4-byte entry (measured WRITE_SIZE 7x the payload).  Instead the slice is first ordered by
+// partition in LDS (counts -> exclusive scan -> ranks), then copied out with consecutive lanes writing consecutive
+// addresses of each partition's run.
 __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                            uint32_t* __restrict__ tmp) {
-    extern __shared__ uint32_t h[];
-    const uint32_t np = (1u << g.lp) + 1;
+    extern __shared__ uint32_t sm[];
+    const uint32_t np = (1u << g.lp) + 1;                 // last bin: zero digits (dropped)
+    uint32_t* cnt = sm;                                   // [np]   counts, then running cursors
+    uint32_t* loc = sm + np;                              // [np+1] exclusive local offsets
+    uint32_t* buf = sm + 2 * np + 1;                      // [SORT_SLICE] entries ordered by partition
     const uint32_t w = blockIdx.y, blk = blockIdx.x;
-    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) {
-        const uint64_t pid = (k == np - 1) ? (uint64_t)g.nreal + w : ((uint64_t)w << g.lp) + k;
-        h[k] = blk_off[pid * g.nblk + blk];
-    }
+    for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) cnt[k] = 0;
     __syncthreads();
     const uint64_t beg = (uint64_t)blk * SORT_SLICE, end = beg + SORT_SLICE < g.n ? beg + SORT_SLICE : g.n;
     const uint32_t* d = dig + (uint64_t)w * g.n;
+    for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
+        const uint32_t mag = d[i] & 0x7fffffffu;
+        atomicAdd(&cnt[mag ? ((mag - 1) >> g.low_bits) : (np - 1)], 1u);
+    }
+    __syncthreads();
+    // exclusive scan of the np counts (np <= 8193): 256 lanes, each a contiguous strip, then a strip-sum scan
+    __shared__ uint32_t strip[256];
+    const uint32_t per = (np + blockDim.x - 1) / blockDim.x;
+    const uint32_t s0 = threadIdx.x * per, s1 = s0 + per < np ? s0 + per : np;
+    uint32_t acc = 0;
+    for (uint32_t k = s0; k < s1; k++) acc += cnt[k];
+    strip[threadIdx.x] = acc;
+    __syncthreads();
+    for (int dd = 1; dd < 256; dd <<= 1) {
+        const uint32_t t = (int)threadIdx.x >= dd ? strip[threadIdx.x - dd] : 0;
+        __syncthreads();
+        strip[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = strip[threadIdx.x] - acc;
+    for (uint32_t k = s0; k < s1; k++) { const uint32_t v = cnt[k]; loc[k] = run; cnt[k] = run; run += v; }
+    if (threadIdx.x == blockDim.x - 1) loc[np] = strip[blockDim.x - 1];
+    __syncthreads();
+    // rank into LDS
     const uint32_t low_mask = (1u << g.low_bits) - 1;
     for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
         const uint32_t e = d[i], mag = e & 0x7fffffffu;
-        if (!mag) continue;                                    // zero digits are counted (their partitions sit last) but never stored
+        if (!mag) continue;
         const uint32_t key = mag - 1;
-        const uint32_t pos = atomicAdd(&h[key >> g.low_bits], 1u);
-        tmp[pos] = ((key & low_mask) << (g.idx_bits + 1)) | ((e >> 31) << g.idx_bits) | (uint32_t)i;
+        const uint32_t pos = atomicAdd(&cnt[key >> g.low_bits], 1u);
+        buf[pos] = ((key & low_mask) << (g.idx_bits + 1)) | ((e >> 31) << g.idx_bits) | (uint32_t)i;
+    }
+    __syncthreads();
+    // copy out: position j of the ordered slice belongs to the partition whose [loc[k], loc[k+1]) contains it
+    const uint32_t nreal_local = loc[np - 1];             // entries with a non-zero digit
+    for (uint32_t j = threadIdx.x; j < nreal_local; j += blockDim.x) {
+        uint32_t lo = 0, hi = np - 1;                     // largest k with loc[k] <= j
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (loc[mid] <= j) lo = mid; else hi = mid; }
+        const uint64_t pid = ((uint64_t)w << g.lp) + lo;
+        tmp[blk_off[pid * g.nblk + blk] + (j - loc[lo])] = buf[j];
     }
 }
 
@@ -703,7 +740,15 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums);
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsums, nscan_blocks, blk_off + nhist);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums, blk_off);
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_off, tmp);
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(256), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
+                       blk_off, tmp);
     hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), ((size_t)1 << g.low_bits) * 4, stream, tmp, g, blk_off, sorted, offsets); }
     { ProfScope ps("msm_bucket_order", stream);
     HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
