@@ -15,7 +15,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(LIBDIR, "libplonk_hip.so")
-UNITS = ["plonk_api.hip", "ntt_engine.hip", "msm_engine.hip", "synth.hip", "quotient.hip"]
+UNITS = ["plonk_api.hip", "ntt_engine.hip", "msm_engine.hip", "synth.hip", "quotient.hip", "poly_ops.hip"]
 HEADERS = ["fp.cuh", "fp29.cuh", "flimb.cuh", "ec.cuh", "ec_lazy.cuh", "constants.h", "ntt_kernels.cuh", "plonk_internal.hpp",
            "../../include/plonk_hip.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

@@ -89,6 +89,9 @@ void ntt_tables_destroy(NttTables& T) {
     for (auto& kv : T.rowtabs) hipFree(kv.second);
     T.rowtabs.clear();
     T.plane_bytes = 0;
+    if (T.quot_x_lo) { hipFree(T.quot_x_lo); T.quot_x_lo = nullptr; }
+    for (auto& kv : T.quot_inv_xm1) hipFree(kv.second);
+    T.quot_inv_xm1.clear();
 }
 
 // w^-e * 2^-log_m for e < 2^lt (inverse transforms of size 2^log_m fold their 1/M here)

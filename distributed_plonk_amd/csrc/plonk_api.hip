@@ -9,9 +9,6 @@
 #include "plonk_internal.hpp"
 
 void ntt_set_max_log_r(int v);
-int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
-                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream);
-void quotient_tables_destroy(const NttTables* T);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -167,7 +164,6 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
-    quotient_tables_destroy(&ctx->tables);
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases) hipFree(ctx->d_bases);
     if (ctx->d_wire) hipFree(ctx->d_wire);
@@ -634,6 +630,49 @@ extern "C" int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inp
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- permutation product (§8f rank 2)
+extern "C" int plonk_perm_product_dev(plonk_ctx* ctx, const void* const d_wires[5], const void* d_id_perm, const void* d_perm_idx,
+                                      const uint64_t* beta, const uint64_t* gamma, size_t n, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_wires || !d_id_perm || !d_perm_idx || !beta || !gamma || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_dev: null");
+    for (int j = 0; j < 5; j++) if (!d_wires[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_dev: null wire %d", j);
+    if (n < 2 || n >= ((size_t)1 << 32)) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_dev: n = %zu", n);
+    int rc = ensure_scratch2(ctx, perm_product_scratch_bytes(n));
+    if (rc) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    rc = perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, d_out, ctx->d_scratch2, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
+}
+
+// ---------------------------------------------------------------------------------------------- round 4/5 polynomial ops (§8f rank 3)
+extern "C" int plonk_poly_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out) {
+    CHECK_CTX(ctx);
+    if ((!d_poly && len) || !point || !out) return plonk_fail(PLONK_ERR_ARG, "plonk_poly_eval_dev: null");
+    int rc = ensure_scratch2(ctx, poly_scratch_bytes(len));
+    if (rc) return rc;
+    return poly_eval_run(ctx->tables, d_poly, len, point, out, ctx->d_scratch2, ctx->stream);
+}
+extern "C" int plonk_poly_lincomb_dev(plonk_ctx* ctx, size_t k, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs,
+                                      void* d_out, size_t out_len) {
+    CHECK_CTX(ctx);
+    if (!d_polys || !lens || !coeffs || (!d_out && out_len)) return plonk_fail(PLONK_ERR_ARG, "plonk_poly_lincomb_dev: null");
+    return poly_lincomb_run(ctx->tables, k, d_polys, lens, coeffs, d_out, out_len, ctx->stream);
+}
+extern "C" int plonk_poly_div_linear_dev(plonk_ctx* ctx, const void* d_poly, size_t len, const uint64_t* point, void* d_out) {
+    CHECK_CTX(ctx);
+    if ((!d_poly && len) || !point || (!d_out && len > 1)) return plonk_fail(PLONK_ERR_ARG, "plonk_poly_div_linear_dev: null");
+    int rc = ensure_scratch2(ctx, poly_scratch_bytes(len));
+    if (rc) return rc;
+    return poly_div_linear_run(ctx->tables, d_poly, len, point, d_out, ctx->d_scratch2, ctx->stream);
+}
+extern "C" int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k) {
+    CHECK_CTX(ctx);
+    if (!d_poly || (!blinders && k)) return plonk_fail(PLONK_ERR_ARG, "plonk_blind_dev: null");
+    return blind_run(ctx->tables, d_poly, n, blinders, k, ctx->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- memory / synth / debug

@@ -67,6 +67,9 @@ struct NttTables {
     std::unordered_map<uint64_t, F29*> rowtabs;   // coset row tables g^(a*r_1)
     size_t plane_bytes = 0;                       // HBM currently held by planes
     size_t plane_budget = (size_t)48 << 30;       // stop creating planes beyond this (fall back to on-the-fly factors)
+    // quotient.hip: g * w_Nmax^e (constant form) and 1/(x_i - 1) per quotient-domain size (key = log m)
+    F29* quot_x_lo = nullptr;
+    std::unordered_map<int, Fr*> quot_inv_xm1;
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };
@@ -107,10 +110,6 @@ struct MsmWorkspace {
     void* d_buf = nullptr;
     size_t bytes = 0;
 };
-struct MsmConfig {
-    int curve;
-    int window_bits;     // 0 = auto
-};
 // bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point).
 // scalars: device, canonical 8xu32.  out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac,
@@ -130,3 +129,16 @@ int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hi
 int blind_add_dev(int curve, Fr* poly, size_t n, const Fr* d_blind2, hipStream_t stream);
 
 const FrParams& fr_params(int curve);
+
+// ----------------------------------------------------------------------------------------------- O(n) prover steps (poly_ops.hip, quotient.hip)
+int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
+                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream);
+size_t perm_product_scratch_bytes(size_t n);
+int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
+                     size_t n, void* d_out, void* scratch, hipStream_t stream);
+size_t poly_scratch_bytes(size_t len);
+int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out_host, void* scratch, hipStream_t stream);
+int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const size_t* lens, const uint64_t* coeffs, void* d_out, size_t out_len,
+                     hipStream_t stream);
+int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, void* d_out, void* scratch, hipStream_t stream);
+int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, size_t k, hipStream_t stream);

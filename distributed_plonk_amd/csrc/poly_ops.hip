@@ -1,0 +1,568 @@
+// poly_ops.hip — the O(n) prover steps either side of the MSM/NTT hot path, device-resident:
+//
+//   rank 2  permutation grand product                      /root/reference/src/dispatcher2.rs:329-344
+//           (per-gate numerator/denominator, division, running product — a serial host loop with one field
+//           inversion per gate in the reference; here: one streaming kernel + two multiplicative scans and a
+//           single inversion:  z[j] = prod_{k<j} num_k * prod_{k>=j} den_k / prod_all den_k)
+//   rank 3  DensePolynomial::evaluate (Horner at zeta)     dispatcher2.rs:545-555
+//           scalar * polynomial sums (lin_poly, batch_poly) dispatcher2.rs:566-633,646-649
+//           synthetic division by (X - z)                   dispatcher2.rs:651-666,672-688
+//           (q_{i-1} = z^-i * sum_{k>=i} c_k z^k : an additive suffix scan of scaled coefficients)
+//           blinding (rand(k-1) * Z_H + poly)               dispatcher2.rs:311-312,347-348
+//
+// Arithmetic: HBM keeps the reference's R = 2^256 Montgomery form, fully reduced.  Products run on 9 x 29-bit limbs
+// (fp29.cuh, mont(a, b) = a*b/2^261).  rep(x) = x*2^261 is the form in which products of DATA close under mont();
+// an R-form datum is rep(x * 2^-5) and the stray powers of two cancel where noted.  Every value stored is
+// canonical, so results are bit-identical to ark-ff's.
+//
+// Scans: block tile = 256 lanes x 8 consecutive elements per lane; phase 1 tile totals, phase 2 one workgroup scans
+// the totals, phase 3 re-reads the tile, scans it through LDS and applies an epilogue.  All streaming; none of this
+// is on the critical path of the proof-equivalent mix (a few ms at n = 2^24 against ~1 s of NTT + MSM).
+#include <cstring>
+#include <vector>
+
+#include "constants.h"
+#include "ntt_kernels.cuh"
+#include "plonk_internal.hpp"
+
+#define PO_LANES 256
+#define PO_CH 8
+#define PO_TILE (PO_LANES * PO_CH)
+#define PO_TOP 1024          // lanes of the single-workgroup phase-2 kernel
+
+struct PoCtx {
+    F29Params f29;
+    FrParams fp;
+};
+
+// ---------------------------------------------------------------------------------------------- scan operators
+struct OpMul {               // values: rep-form field elements as F29, normalised, < 1.4 p
+    typedef F29 V;
+    static constexpr int WORDS = 9;
+    static __device__ __forceinline__ V load(const Fr* p, const PoCtx&) { return f29_from_sat(load_fr(p)); }
+    static __device__ __forceinline__ void store(Fr* p, const V& v, const PoCtx& c) { store_fr(p, f29_to_sat(f29_canon(v, c.f29))); }
+    static __device__ __forceinline__ V comb(const V& a, const V& b, const PoCtx& c) { return f29_mul(a, b, c.f29); }
+    static __device__ __forceinline__ V ident(const PoCtx& c) { return params_one(c.f29); }
+    static __device__ __forceinline__ void to_words(uint32_t* w, const V& v) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) w[i] = v.l[i];
+    }
+    static __device__ __forceinline__ V from_words(const uint32_t* w) {
+        V v;
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.l[i] = w[i];
+        return v;
+    }
+};
+struct OpAdd {               // values: canonical Fr
+    typedef Fr V;
+    static constexpr int WORDS = 8;
+    static __device__ __forceinline__ V load(const Fr* p, const PoCtx&) { return load_fr(p); }
+    static __device__ __forceinline__ void store(Fr* p, const V& v, const PoCtx&) { store_fr(p, v); }
+    static __device__ __forceinline__ V comb(const V& a, const V& b, const PoCtx& c) { return fp_add(a, b, c.fp); }
+    static __device__ __forceinline__ V ident(const PoCtx&) { return fp_zero<8>(); }
+    static __device__ __forceinline__ void to_words(uint32_t* w, const V& v) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = v.l[i];
+    }
+    static __device__ __forceinline__ V from_words(const uint32_t* w) {
+        V v;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v.l[i] = w[i];
+        return v;
+    }
+};
+
+// LDS rows are 9 words (odd pitch: consecutive lanes fall on distinct banks for both operators)
+template <class Op, int LANES>
+__device__ __forceinline__ typename Op::V block_total(const typename Op::V& mine, uint32_t (*sh)[9], const PoCtx& c) {
+    const int t = threadIdx.x;
+    typename Op::V v = mine;
+    Op::to_words(sh[t], v);
+    __syncthreads();
+    for (int s = LANES / 2; s > 0; s >>= 1) {
+        if (t < s) {
+            v = Op::comb(v, Op::from_words(sh[t + s]), c);
+            Op::to_words(sh[t], v);
+        }
+        __syncthreads();
+    }
+    v = Op::from_words(sh[0]);
+    __syncthreads();
+    return v;
+}
+
+// inclusive Hillis-Steele scan over the lanes of a workgroup; returns the exclusive value of this lane
+template <class Op, int LANES>
+__device__ __forceinline__ typename Op::V block_exclusive(const typename Op::V& mine, uint32_t (*sh)[9], const PoCtx& c, typename Op::V* total) {
+    const int t = threadIdx.x;
+    typename Op::V v = mine;
+    Op::to_words(sh[t], v);
+    __syncthreads();
+    for (int d = 1; d < LANES; d <<= 1) {
+        typename Op::V o;
+        const bool on = t >= d;
+        if (on) o = Op::from_words(sh[t - d]);
+        __syncthreads();
+        if (on) {
+            v = Op::comb(o, v, c);
+            Op::to_words(sh[t], v);
+        }
+        __syncthreads();
+    }
+    typename Op::V ex = t > 0 ? Op::from_words(sh[t - 1]) : Op::ident(c);
+    if (total) *total = Op::from_words(sh[LANES - 1]);
+    __syncthreads();
+    return ex;
+}
+
+// logical position q of a scan <-> physical index (suffix scans run over the reversed array)
+__device__ __forceinline__ uint64_t phys_index(uint64_t q, uint64_t n, bool reverse) { return reverse ? n - 1 - q : q; }
+
+template <class Op>
+__global__ void __launch_bounds__(PO_LANES) scan_totals_kernel(const Fr* __restrict__ in, Fr* __restrict__ btot, uint64_t n, int reverse, const PoCtx c) {
+    __shared__ uint32_t sh[PO_LANES][9];
+    const uint64_t q0 = (uint64_t)blockIdx.x * PO_TILE + (uint64_t)threadIdx.x * PO_CH;
+    typename Op::V acc = Op::ident(c);
+    bool first = true;
+#pragma unroll
+    for (int k = 0; k < PO_CH; k++) {
+        const uint64_t q = q0 + k;
+        if (q < n) {
+            const typename Op::V x = Op::load(in + phys_index(q, n, reverse), c);
+            acc = first ? x : Op::comb(acc, x, c);
+            first = false;
+        }
+    }
+    const typename Op::V tot = block_total<Op, PO_LANES>(acc, sh, c);
+    if (threadIdx.x == 0) Op::store(btot + blockIdx.x, tot, c);
+}
+
+// one workgroup: exclusive scan of the nb tile totals -> boff[b]; grand total -> *total
+template <class Op>
+__global__ void __launch_bounds__(PO_TOP) scan_top_kernel(const Fr* __restrict__ btot, Fr* __restrict__ boff, Fr* __restrict__ total, uint64_t nb,
+                                                          const PoCtx c) {
+    __shared__ uint32_t sh[PO_TOP][9];
+    const uint64_t per = (nb + PO_TOP - 1) / PO_TOP;
+    const uint64_t lo = (uint64_t)threadIdx.x * per, hi = lo + per < nb ? lo + per : nb;
+    typename Op::V acc = Op::ident(c);
+    for (uint64_t b = lo; b < hi; b++) acc = (b == lo) ? Op::load(btot + b, c) : Op::comb(acc, Op::load(btot + b, c), c);
+    typename Op::V tot;
+    typename Op::V run = block_exclusive<Op, PO_TOP>(acc, sh, c, &tot);
+    for (uint64_t b = lo; b < hi; b++) {
+        Op::store(boff + b, run, c);
+        run = Op::comb(run, Op::load(btot + b, c), c);
+    }
+    if (threadIdx.x == 0 && total) Op::store(total, tot, c);
+}
+
+// phase 3: out(q) = boff[tile] o (elements before q in the tile) [o x_q if inclusive], handed to the epilogue
+template <class Op, class Epi>
+__global__ void __launch_bounds__(PO_LANES) scan_apply_kernel(const Fr* __restrict__ in, const Fr* __restrict__ boff, uint64_t n, int reverse, int inclusive,
+                                                              const PoCtx c, const Epi epi) {
+    __shared__ uint32_t sh[PO_LANES][9];
+    const uint64_t q0 = (uint64_t)blockIdx.x * PO_TILE + (uint64_t)threadIdx.x * PO_CH;
+    typename Op::V x[PO_CH];
+    typename Op::V acc = Op::ident(c);
+#pragma unroll
+    for (int k = 0; k < PO_CH; k++) {
+        const uint64_t q = q0 + k;
+        x[k] = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
+        acc = k == 0 ? x[0] : Op::comb(acc, x[k], c);
+    }
+    const typename Op::V ex = block_exclusive<Op, PO_LANES>(acc, sh, c, nullptr);
+    typename Op::V run = Op::comb(Op::load(boff + blockIdx.x, c), ex, c);
+#pragma unroll
+    for (int k = 0; k < PO_CH; k++) {
+        const uint64_t q = q0 + k;
+        if (inclusive) run = Op::comb(run, x[k], c);
+        if (q < n) epi(run, phys_index(q, n, reverse), c);
+        if (!inclusive) run = Op::comb(run, x[k], c);
+    }
+}
+
+template <class Op>
+struct EpiStore {
+    Fr* out;
+    __device__ __forceinline__ void operator()(const typename Op::V& v, uint64_t i, const PoCtx& c) const { Op::store(out + i, v, c); }
+};
+
+template <class Op, class Epi>
+static int scan_run(const Fr* in, uint64_t n, bool reverse, bool inclusive, Fr* btot, Fr* boff, Fr* total, const PoCtx& c, const Epi& epi,
+                    const char* name, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    const uint64_t nb = (n + PO_TILE - 1) / PO_TILE;
+    ProfScope ps(name, stream);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_totals_kernel<Op>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, in, btot, n, (int)reverse, c);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_top_kernel<Op>), dim3(1), dim3(PO_TOP), 0, stream, (const Fr*)btot, boff, total, nb, c);
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_apply_kernel<Op, Epi>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, in, (const Fr*)boff, n, (int)reverse,
+                       (int)inclusive, c, epi);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "%s launch: %s", name, hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+static PoCtx make_ctx(const NttTables& T) {
+    PoCtx c;
+    c.f29 = T.fp29;
+    c.fp = T.fp;
+    return c;
+}
+static F29 host_rep(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }   // rep(v) = v * 2^261
+static Fr fr_arg(const uint64_t* p) { return fp_from_limbs<8>((const uint32_t*)p); }
+static bool fr_arg_ok(const uint64_t* p, const FrParams& P) {     // canonical (< p)?
+    const uint32_t* l = (const uint32_t*)p;
+    for (int i = 7; i >= 0; i--) {
+        if (l[i] < P.p[i]) return true;
+        if (l[i] > P.p[i]) return false;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------------------------------------- powers of a point
+// z^i = t0[i & 1023] * t1[(i >> 10) & 1023] * t2[i >> 20]   (rep form; i < 2^30)
+struct PowTab {
+    const F29* t0;
+    const F29* t1;
+    const F29* t2;
+    int levels;
+};
+__device__ __forceinline__ F29 pow_at(const PowTab& T, uint64_t i, const F29Params& fp) {
+    F29 r = load_f29(T.t0 + (i & 1023));
+    if (T.levels > 1) r = f29_mul(r, load_f29(T.t1 + ((i >> 10) & 1023)), fp);
+    if (T.levels > 2) r = f29_mul(r, load_f29(T.t2 + (i >> 20)), fp);
+    return r;
+}
+#define POWTAB_BYTES (3 * 1024 * sizeof(F29))
+static int build_pow_tab(const FrParams& P, const Fr& z_mont, uint64_t len, F29* d_tab, PowTab* out, hipStream_t stream) {
+    const int levels = len <= 1024 ? 1 : (len <= (1u << 20) ? 2 : 3);
+    std::vector<F29> h((size_t)levels * 1024);
+    Fr base = z_mont;
+    for (int l = 0; l < levels; l++) {
+        Fr acc = fp_one(P);
+        for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(acc, P); acc = fp_mul(acc, base, P); }
+        base = acc;                       // base^1024
+    }
+    HIP_TRY(hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    out->t0 = d_tab; out->t1 = d_tab + 1024; out->t2 = d_tab + 2048; out->levels = levels;
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- rank 2: permutation product
+struct PermParams {
+    const Fr* wire[5];
+    const Fr* id;             // extended_id_permutation, 5n
+    const uint64_t* idx;      // perm_i * n + perm_j, 5n
+    Fr* num;                  // rep(A_j * 2^-25)
+    Fr* den;                  // rep(B_j * 2^-25); den[n-1] = rep(1)
+    uint64_t n;
+    F29 gamma_r;              // gamma * 2^256 (plain limbs of the Montgomery form)
+    F29 beta_c;               // rep(beta)
+    uint32_t* flag;           // bit 0: zero denominator, bit 1: permutation index out of range
+    PoCtx c;
+};
+
+__global__ void __launch_bounds__(256) perm_terms_kernel(const PermParams P) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    const F29Params& fp = P.c.f29;
+    if (j == P.n - 1) {                       // the reference's loop stops at n-2 (dispatcher2.rs:331)
+        const Fr one = f29_to_sat(f29_canon(params_one(fp), fp));
+        store_fr(P.num + j, one);
+        store_fr(P.den + j, one);
+        return;
+    }
+    F29 a, b;
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const uint64_t e = (uint64_t)i * P.n + j;
+        uint64_t pe = P.idx[e];
+        if (pe >= 5 * P.n) { atomicOr(P.flag, 2u); pe = 0; }
+        const F29 t = f29_add(f29_from_sat(load_fr(P.wire[i] + j)), P.gamma_r);                       // w + gamma, limbs < 2^30
+        F29 s = f29_add(t, f29_mul(f29_from_sat(load_fr(P.id + e)), P.beta_c, fp));                   // + beta * id      (:337)
+        F29 d = f29_add(t, f29_mul(f29_from_sat(load_fr(P.id + pe)), P.beta_c, fp));                  // + beta * id[perm] (:339-340)
+        f29_norm(s);
+        f29_norm(d);
+        a = i == 0 ? s : f29_mul(s, a, fp);
+        b = i == 0 ? d : f29_mul(d, b, fp);
+    }
+    const Fr ac = f29_to_sat(f29_canon(a, fp)), bc = f29_to_sat(f29_canon(b, fp));
+    if (fp_is_zero(bc)) atomicOr(P.flag, 1u);
+    store_fr(P.num + j, ac);
+    store_fr(P.den + j, bc);
+}
+
+// kconst = (1 / D) * 2^256 as plain limbs, D given in rep form: one lane, Fermat
+__global__ void fr_inv_kernel(const Fr* __restrict__ total, Fr* __restrict__ kconst, uint32_t* flag, const PoCtx c, const F29 pm2_bits, const F29 r256) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const F29Params& fp = c.f29;
+    const Fr tv = load_fr(total);
+    if (fp_is_zero(tv)) atomicOr(flag, 1u);
+    const F29 x = f29_from_sat(tv);
+    F29 inv = params_one(fp);
+    for (int bit = 9 * 29 - 1; bit >= 0; bit--) {
+        inv = f29_mul(inv, inv, fp);
+        if ((pm2_bits.l[bit / 29] >> (bit % 29)) & 1) inv = f29_mul(inv, x, fp);
+    }
+    store_fr(kconst, f29_to_sat(f29_canon(f29_mul(inv, r256, fp), fp)));
+}
+
+struct EpiPermFinal {        // z[i] = PN[i] * SD[i] * kconst  -> R form, canonical
+    const Fr* pn;
+    const Fr* kconst;
+    Fr* out;
+    __device__ __forceinline__ void operator()(const F29& sd, uint64_t i, const PoCtx& c) const {
+        const F29 t = f29_mul(sd, f29_from_sat(load_fr(pn + i)), c.f29);
+        const F29 r = f29_mul(t, f29_from_sat(load_fr(kconst)), c.f29);
+        store_fr(out + i, f29_to_sat(f29_canon(r, c.f29)));
+    }
+};
+
+static size_t align256(size_t b) { return (b + 255) & ~(size_t)255; }
+static uint64_t tiles_of(uint64_t n) { return (n + PO_TILE - 1) / PO_TILE; }
+
+size_t perm_product_scratch_bytes(size_t n) { return 3 * align256(n * 32) + 2 * align256(tiles_of(n) * 32) + 1024; }
+
+int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
+                     size_t n, void* d_out, void* scratch, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    if (n < 2) return plonk_fail(PLONK_ERR_ARG, "perm_product: n = %zu", n);
+    if (!fr_arg_ok(beta, P) || !fr_arg_ok(gamma, P)) return plonk_fail(PLONK_ERR_ARG, "perm_product: challenge not reduced");
+    char* s = (char*)scratch;
+    Fr* A = (Fr*)s; s += align256(n * 32);
+    Fr* B = (Fr*)s; s += align256(n * 32);
+    Fr* PN = (Fr*)s; s += align256(n * 32);
+    Fr* btot = (Fr*)s; s += align256(tiles_of(n) * 32);
+    Fr* boff = (Fr*)s; s += align256(tiles_of(n) * 32);
+    Fr* total = (Fr*)s; s += 64;
+    Fr* kconst = (Fr*)s; s += 64;
+    uint32_t* flag = (uint32_t*)s;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, stream));
+    const PoCtx c = make_ctx(T);
+    PermParams q;
+    memset(&q, 0, sizeof q);
+    for (int i = 0; i < 5; i++) q.wire[i] = (const Fr*)wires[i];
+    q.id = (const Fr*)id_perm; q.idx = (const uint64_t*)perm_idx;
+    q.num = A; q.den = B; q.n = n;
+    q.gamma_r = f29_from_sat(fr_arg(gamma));
+    q.beta_c = host_rep(fr_arg(beta), P);
+    q.flag = flag; q.c = c;
+    {
+        ProfScope ps("perm_terms_kernel", stream);
+        hipLaunchKernelGGL(perm_terms_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, q);
+    }
+    int rc = scan_run<OpMul>(A, n, false, false, btot, boff, (Fr*)nullptr, c, EpiStore<OpMul>{PN}, "perm_scan_num", stream);       // PN[j] = prod_{k<j} num
+    if (rc) return rc;
+    // total of the denominators, its inverse, then the suffix scan fused with the final product
+    {
+        const uint64_t nb = tiles_of(n);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_totals_kernel<OpMul>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)B, btot, (uint64_t)n, 1, c);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_top_kernel<OpMul>), dim3(1), dim3(PO_TOP), 0, stream, (const Fr*)btot, boff, total, nb, c);
+        Fr pm2;
+        uint64_t br = 2;
+        for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
+        Fr r256;
+        for (int i = 0; i < 8; i++) r256.l[i] = P.one[i];
+        hipLaunchKernelGGL(fr_inv_kernel, dim3(1), dim3(64), 0, stream, (const Fr*)total, kconst, flag, c, f29_from_sat(pm2), f29_from_sat(r256));
+        ProfScope ps("perm_scan_den_final", stream);
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_apply_kernel<OpMul, EpiPermFinal>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)B, (const Fr*)boff,
+                           (uint64_t)n, 1, 1, c, EpiPermFinal{PN, kconst, (Fr*)d_out});
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "perm_product launch: %s", hipGetErrorString(e));
+    uint32_t h_flag = 0;
+    HIP_TRY(hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h_flag & 2) return plonk_fail(PLONK_ERR_ARG, "perm_product: permutation index out of range (>= 5n)");
+    if (h_flag & 1) return plonk_fail(PLONK_ERR_ARG, "perm_product: zero denominator (the reference panics on this division, dispatcher2.rs:343)");
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- rank 3: evaluate
+__global__ void __launch_bounds__(PO_LANES) poly_eval_kernel(const Fr* __restrict__ poly, uint64_t len, const PowTab pw, Fr* __restrict__ partial, const PoCtx c) {
+    __shared__ uint32_t sh[PO_LANES][9];
+    const F29Params& fp = c.f29;
+    const uint64_t base = (uint64_t)blockIdx.x * PO_TILE + threadIdx.x;
+    F29 sum;
+#pragma unroll
+    for (int l = 0; l < 9; l++) sum.l[l] = 0;
+#pragma unroll
+    for (int k = 0; k < PO_CH; k++) {
+        const uint64_t i = base + (uint64_t)k * PO_LANES;        // coalesced
+        if (i < len) {
+            sum = f29_add(sum, f29_mul(f29_from_sat(load_fr(poly + i)), pow_at(pw, i, fp), fp));   // c_i z^i, R form
+            if ((k & 1) == 1) f29_norm(sum);
+        }
+    }
+    f29_norm(sum);                                                // < 11 p
+    const Fr mine = f29_to_sat(f29_canon(f29_mul(sum, params_one(fp), fp), fp));
+    const Fr tot = block_total<OpAdd, PO_LANES>(mine, sh, c);
+    if (threadIdx.x == 0) store_fr(partial + blockIdx.x, tot);
+}
+__global__ void __launch_bounds__(PO_LANES) fr_sum_kernel(const Fr* __restrict__ v, uint64_t n, Fr* __restrict__ out, const PoCtx c) {
+    __shared__ uint32_t sh[PO_LANES][9];
+    Fr acc = fp_zero<8>();
+    for (uint64_t i = threadIdx.x; i < n; i += PO_LANES) acc = fp_add(acc, load_fr(v + i), c.fp);
+    const Fr tot = block_total<OpAdd, PO_LANES>(acc, sh, c);
+    if (threadIdx.x == 0) store_fr(out, tot);
+}
+
+size_t poly_scratch_bytes(size_t len) { return align256(len * 32) + 2 * align256(tiles_of(len) * 32) + 2 * align256(POWTAB_BYTES) + 1024; }
+
+int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out_host, void* scratch, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    if (len >= ((size_t)1 << 30)) return plonk_fail(PLONK_ERR_ARG, "poly_eval: %zu coefficients (limit 2^30)", len);
+    if (!fr_arg_ok(point, P)) return plonk_fail(PLONK_ERR_ARG, "poly_eval: point not reduced");
+    if (len == 0) { memset(out_host, 0, 32); return PLONK_OK; }
+    char* s = (char*)scratch;
+    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
+    Fr* partial = (Fr*)s; s += align256(tiles_of(len) * 32);
+    Fr* res = (Fr*)s;
+    PowTab pw;
+    int rc = build_pow_tab(P, fr_arg(point), len, tab, &pw, stream);
+    if (rc) return rc;
+    const PoCtx c = make_ctx(T);
+    const uint64_t nb = tiles_of(len);
+    {
+        ProfScope ps("poly_eval_kernel", stream);
+        hipLaunchKernelGGL(poly_eval_kernel, dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)d_poly, (uint64_t)len, pw, partial, c);
+        hipLaunchKernelGGL(fr_sum_kernel, dim3(1), dim3(PO_LANES), 0, stream, (const Fr*)partial, nb, res, c);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "poly_eval launch: %s", hipGetErrorString(e));
+    HIP_TRY(hipMemcpyAsync(out_host, res, 32, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- rank 3: linear combination
+#define LINCOMB_MAX 32
+struct LincombParams {
+    const Fr* poly[LINCOMB_MAX];
+    uint64_t len[LINCOMB_MAX];
+    F29 coef[LINCOMB_MAX];     // rep(c_k)
+    Fr* out;
+    uint64_t out_len;
+    int k;
+    PoCtx c;
+};
+__global__ void __launch_bounds__(256) poly_lincomb_kernel(const LincombParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.out_len) return;
+    const F29Params& fp = P.c.f29;
+    F29 sum;
+#pragma unroll
+    for (int l = 0; l < 9; l++) sum.l[l] = 0;
+    int pending = 0;
+    for (int t = 0; t < P.k; t++) {
+        if (i < P.len[t]) {
+            sum = f29_add(sum, f29_mul(f29_from_sat(load_fr(P.poly[t] + i)), P.coef[t], fp));
+            if (++pending == 3) { f29_norm(sum); pending = 0; }
+        }
+    }
+    f29_norm(sum);                                                // < 44 p < 2^259.4
+    store_fr(P.out + i, f29_to_sat(f29_canon(f29_mul(sum, params_one(fp), fp), fp)));
+}
+
+int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const size_t* lens, const uint64_t* coeffs, void* d_out, size_t out_len,
+                     hipStream_t stream) {
+    const FrParams& P = T.fp;
+    if (k == 0 || k > LINCOMB_MAX) return plonk_fail(PLONK_ERR_ARG, "poly_lincomb: %zu terms (1..%d)", k, LINCOMB_MAX);
+    if (out_len == 0) return PLONK_OK;
+    LincombParams q;
+    memset(&q, 0, sizeof q);
+    for (size_t t = 0; t < k; t++) {
+        if (!polys[t] && lens[t]) return plonk_fail(PLONK_ERR_ARG, "poly_lincomb: null polynomial %zu", t);
+        if (!fr_arg_ok(coeffs + 4 * t, P)) return plonk_fail(PLONK_ERR_ARG, "poly_lincomb: coefficient %zu not reduced", t);
+        if (polys[t] == d_out) return plonk_fail(PLONK_ERR_ARG, "poly_lincomb: output aliases input %zu", t);
+        q.poly[t] = (const Fr*)polys[t];
+        q.len[t] = lens[t];
+        q.coef[t] = host_rep(fr_arg(coeffs + 4 * t), P);
+    }
+    q.out = (Fr*)d_out; q.out_len = out_len; q.k = (int)k; q.c = make_ctx(T);
+    {
+        ProfScope ps("poly_lincomb_kernel", stream);
+        hipLaunchKernelGGL(poly_lincomb_kernel, dim3((uint32_t)((out_len + 255) / 256)), dim3(256), 0, stream, q);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "poly_lincomb launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- rank 3: division by (X - z)
+__global__ void __launch_bounds__(256) poly_scale_kernel(const Fr* __restrict__ poly, uint64_t len, const PowTab pw, Fr* __restrict__ out, const PoCtx c) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    store_fr(out + i, f29_to_sat(f29_canon(f29_mul(f29_from_sat(load_fr(poly + i)), pow_at(pw, i, c.f29), c.f29), c.f29)));     // c_i z^i
+}
+struct EpiDivFinal {         // q[i-1] = z^-i * s_i
+    PowTab zinv;
+    Fr* out;
+    __device__ __forceinline__ void operator()(const Fr& s, uint64_t i, const PoCtx& c) const {
+        if (i == 0) return;                                       // s_0 = poly(z): the dropped remainder
+        store_fr(out + i - 1, f29_to_sat(f29_canon(f29_mul(f29_from_sat(s), pow_at(zinv, i, c.f29), c.f29), c.f29)));
+    }
+};
+__global__ void __launch_bounds__(256) poly_shift_down_kernel(const Fr* __restrict__ poly, uint64_t len, Fr* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i + 1 < len) store_fr(out + i, load_fr(poly + i + 1));
+}
+
+int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, void* d_out, void* scratch, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    if (len >= ((size_t)1 << 30)) return plonk_fail(PLONK_ERR_ARG, "poly_div_linear: %zu coefficients (limit 2^30)", len);
+    if (!fr_arg_ok(point, P)) return plonk_fail(PLONK_ERR_ARG, "poly_div_linear: point not reduced");
+    if (len < 2) return PLONK_OK;
+    if (d_poly == d_out) return plonk_fail(PLONK_ERR_ARG, "poly_div_linear: in-place not supported");
+    const Fr z = fr_arg(point);
+    if (fp_is_zero(z)) {                                          // q_{i-1} = c_i
+        hipLaunchKernelGGL(poly_shift_down_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, (Fr*)d_out);
+        return PLONK_OK;
+    }
+    char* s = (char*)scratch;
+    F29* tab_z = (F29*)s; s += align256(POWTAB_BYTES);
+    F29* tab_zi = (F29*)s; s += align256(POWTAB_BYTES);
+    Fr* S = (Fr*)s; s += align256(len * 32);
+    Fr* btot = (Fr*)s; s += align256(tiles_of(len) * 32);
+    Fr* boff = (Fr*)s;
+    PowTab pz, pzi;
+    int rc = build_pow_tab(P, z, len, tab_z, &pz, stream);
+    if (!rc) rc = build_pow_tab(P, fp_inv(z, P), len, tab_zi, &pzi, stream);
+    if (rc) return rc;
+    const PoCtx c = make_ctx(T);
+    {
+        ProfScope ps("poly_scale_kernel", stream);
+        hipLaunchKernelGGL(poly_scale_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, pz, S, c);
+    }
+    return scan_run<OpAdd>(S, len, true, true, btot, boff, (Fr*)nullptr, c, EpiDivFinal{pzi, (Fr*)d_out}, "poly_div_scan", stream);
+}
+
+// ---------------------------------------------------------------------------------------------- blinding
+struct BlindParams {
+    Fr b[4];
+    int k;
+};
+// poly[i] -= b_i ; poly[n+i] += b_i   ((sum b_i X^i)(X^n - 1) + poly), dispatcher2.rs:311-312,347-348 / worker.rs:400-401
+__global__ void blind_kernel(Fr* poly, uint64_t n, const BlindParams B, const FrParams P) {
+    const int i = threadIdx.x;
+    if (i < B.k) {
+        store_fr(poly + i, fp_sub(load_fr(poly + i), B.b[i], P));
+        store_fr(poly + n + i, fp_add(load_fr(poly + n + i), B.b[i], P));
+    }
+}
+int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, size_t k, hipStream_t stream) {
+    if (k == 0) return PLONK_OK;
+    if (k > 4 || n < k) return plonk_fail(PLONK_ERR_ARG, "blind: %zu blinders for n = %zu (1..4)", k, n);
+    BlindParams B;
+    memset(&B, 0, sizeof B);
+    for (size_t i = 0; i < k; i++) {
+        if (!fr_arg_ok(blinders + 4 * i, T.fp)) return plonk_fail(PLONK_ERR_ARG, "blind: blinder %zu not reduced", i);
+        B.b[i] = fr_arg(blinders + 4 * i);
+    }
+    B.k = (int)k;
+    hipLaunchKernelGGL(blind_kernel, dim3(1), dim3(64), 0, stream, (Fr*)d_poly, (uint64_t)n, B, T.fp);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "blind launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}

@@ -154,20 +154,6 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------- host
-struct QuotTables {
-    F29* x_lo = nullptr;
-    std::unordered_map<int, Fr*> inv_xm1;      // key log_m
-};
-static std::unordered_map<const NttTables*, QuotTables> g_qt;
-
-void quotient_tables_destroy(const NttTables* T) {
-    auto it = g_qt.find(T);
-    if (it == g_qt.end()) return;
-    if (it->second.x_lo) (void)hipFree(it->second.x_lo);
-    for (auto& kv : it->second.inv_xm1) (void)hipFree(kv.second);
-    g_qt.erase(it);
-}
-
 static F29 host_const(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }
 
 int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
@@ -179,16 +165,15 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     if (((size_t)1 << log_n) != n || ((size_t)1 << log_m) != m || m < n || m / n > 8 || m / n < 1)
         return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: n = %zu, m = %zu (m/n must be a power of two <= 8)", n, m);
     if (log_m > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: 2^%d exceeds the two-adicity", log_m);
-    QuotTables& Q = g_qt[&T];
     const uint32_t* g_l = T.curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
     const Fr g_mont = fp_from_limbs<8>(g_l);
-    if (!Q.x_lo) {          // g * w_Nmax^e, e < 2^lt, constant form
+    if (!T.quot_x_lo) {          // g * w_Nmax^e, e < 2^lt, constant form
         const size_t cnt = (size_t)1 << T.lt;
         std::vector<F29> h(cnt);
         Fr acc = g_mont;
         for (size_t i = 0; i < cnt; i++) { h[i] = host_const(acc, P); acc = fp_mul(acc, T.h_root[0], P); }
-        HIP_TRY(hipMalloc((void**)&Q.x_lo, cnt * sizeof(F29)));
-        HIP_TRY(hipMemcpyAsync(Q.x_lo, h.data(), cnt * sizeof(F29), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMalloc((void**)&T.quot_x_lo, cnt * sizeof(F29)));
+        HIP_TRY(hipMemcpyAsync(T.quot_x_lo, h.data(), cnt * sizeof(F29), hipMemcpyHostToDevice, stream));
         HIP_TRY(hipStreamSynchronize(stream));
     }
     QuotParams q;
@@ -198,11 +183,11 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.ratio = (uint32_t)(m / n);
     q.lt = T.lt;
     q.x_shift = T.two_adicity - log_m;
-    q.x_lo = Q.x_lo;
+    q.x_lo = T.quot_x_lo;
     q.x_hi = T.tw_hi[0];
     // 1/(x_i - 1) table
-    auto it = Q.inv_xm1.find(log_m);
-    if (it == Q.inv_xm1.end()) {
+    auto it = T.quot_inv_xm1.find(log_m);
+    if (it == T.quot_inv_xm1.end()) {
         Fr* d = nullptr;
         HIP_TRY(hipMalloc((void**)&d, m * sizeof(Fr)));
         Fr pm2;                                         // p - 2
@@ -213,7 +198,7 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
                            q.x_shift, q.fp, f29_from_sat(pm2));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "quotient_gen_inv launch: %s", hipGetErrorString(e)); }
-        Q.inv_xm1[log_m] = d;
+        T.quot_inv_xm1[log_m] = d;
         q.inv_xm1 = d;
     } else {
         q.inv_xm1 = it->second;

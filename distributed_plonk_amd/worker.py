@@ -217,6 +217,39 @@ class PlonkWorker:
         al, be, ga, kk = _u64(alpha), _u64(beta), _u64(gamma), _u64(k)
         check(self.lib.plonk_quotient_evals_dev(self.ctx, C.byref(q), _ptr(al), _ptr(be), _ptr(ga), _ptr(kk), d_out))
 
+    # ------------------------------------------------------------------ next rows: permutation product, round 4/5 polynomial ops
+    def perm_product_dev(self, wires, d_id_perm: int, d_perm_idx: int, beta, gamma, n: int, d_out: int):
+        """dispatcher2.rs:329-344.  wires: 5 device pointers to n wire values; d_id_perm: 5n Fr; d_perm_idx: 5n u64."""
+        arr = (C.c_void_p * 5)(*[int(w) for w in wires])
+        be, ga = _u64(beta), _u64(gamma)
+        check(self.lib.plonk_perm_product_dev(self.ctx, C.byref(arr), d_id_perm, d_perm_idx, _ptr(be), _ptr(ga), n, d_out))
+
+    def poly_eval_dev(self, d_poly: int, length: int, point) -> np.ndarray:
+        """DensePolynomial::evaluate (dispatcher2.rs:545-555) -> Fr Montgomery limbs (4,)."""
+        out = np.empty(4, dtype=np.uint64)
+        z = _u64(point)
+        check(self.lib.plonk_poly_eval_dev(self.ctx, d_poly, length, _ptr(z), _ptr(out)))
+        return out
+
+    def poly_lincomb_dev(self, polys, coeffs, d_out: int, out_len: int):
+        """d_out = sum_t coeffs[t] * polys[t]; polys: sequence of (device pointer, length); coeffs (k,4) (dispatcher2.rs:566-633)."""
+        k = len(polys)
+        ptrs = (C.c_void_p * k)(*[int(q[0]) for q in polys])
+        lens = (C.c_size_t * k)(*[int(q[1]) for q in polys])
+        cf = _u64(coeffs)
+        assert cf.shape == (k, 4)
+        check(self.lib.plonk_poly_lincomb_dev(self.ctx, k, ptrs, lens, _ptr(cf), d_out, out_len))
+
+    def poly_div_linear_dev(self, d_poly: int, length: int, point, d_out: int):
+        """quotient of poly / (X - point), remainder dropped (dispatcher2.rs:651-666): length-1 coefficients."""
+        z = _u64(point)
+        check(self.lib.plonk_poly_div_linear_dev(self.ctx, d_poly, length, _ptr(z), d_out))
+
+    def blind_dev(self, d_poly: int, n: int, blinders):
+        """d_poly[0..n+k) += (sum b_i X^i)(X^n - 1) (dispatcher2.rs:311-312,347-348)."""
+        b = _u64(blinders).reshape(-1, 4)
+        check(self.lib.plonk_blind_dev(self.ctx, d_poly, n, _ptr(b), b.shape[0]))
+
     # ------------------------------------------------------------------ device memory, synthetic inputs, debug
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)

@@ -144,6 +144,29 @@ typedef struct {
 int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
                              const uint64_t* gamma, const uint64_t* k, void* d_out);
 
+/* ---- next row: permutation grand product — dispatcher2.rs:329-344 ---------------------------
+ * d_out[0] = 1, d_out[j+1] = d_out[j] * prod_i (w_i[j] + gamma + beta*id[i*n+j]) / prod_i (w_i[j] + gamma + beta*id[perm[i*n+j]]),
+ * j < n-1: the `product_vec` the reference builds gate by gate on the host.  d_wires[i]: n wire values
+ * witness[wire_variables[i][j]] (Fr, Montgomery); d_id_perm: the 5n values of extended_id_permutation; d_perm_idx: 5n u64,
+ * perm_i * n + perm_j of wire_permutation[i*n+j]; beta, gamma: host.  PLONK_ERR_ARG if an index is >= 5n or a denominator
+ * is zero (the reference panics: Fp division unwraps the inverse).  Synchronises the context's stream. */
+int plonk_perm_product_dev(plonk_ctx* ctx, const void* const d_wires[5], const void* d_id_perm, const void* d_perm_idx,
+                           const uint64_t* beta, const uint64_t* gamma, size_t n, void* d_out);
+
+/* ---- next row: round 4/5 polynomial operations — dispatcher2.rs:545-555,566-633,646-688 ------
+ * Coefficient vectors are device pointers to Fr (Montgomery); scalars (points, coefficients, blinders) are host Fr. */
+/* out = poly(point): DensePolynomial::evaluate (:545-555).  len < 2^30.  Synchronises. */
+int plonk_poly_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out);
+/* d_out[i] = sum_{t<k} coeffs[t] * d_polys[t][i] over the terms with i < lens[t], i < out_len (k <= 32): the scalar*poly sums
+ * that build lin_poly and batch_poly (:566-633,646-649).  d_out must not alias an input. */
+int plonk_poly_lincomb_dev(plonk_ctx* ctx, size_t k, const void* const* d_polys, const size_t* lens, const uint64_t* coeffs,
+                           void* d_out, size_t out_len);
+/* d_out[0..len-1) = quotient of poly / (X - point), remainder dropped: the synthetic-division loops of :651-666,672-688. */
+int plonk_poly_div_linear_dev(plonk_ctx* ctx, const void* d_poly, size_t len, const uint64_t* point, void* d_out);
+/* d_poly (n + k coefficients, the top k already valid, normally zero) += (sum_{i<k} blinders[i] X^i) * (X^n - 1):
+ * DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly (:311-312 k = 2, :347-348 k = 3).  k <= 4. */
+int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k);
+
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
 int plonk_dev_free(plonk_ctx* ctx, void* p);
@@ -173,7 +196,8 @@ int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms);
 /* Per-kernel timing with HIP events recorded on the context's stream around every kernel launch
  * (off by default).  Names: "ntt_pass_kernel", "ntt_pass_kernel<9>" (per in-LDS size),
  * "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_accumulate_redo_kernel", "msm_heavy",
- * "msm_reduce", "quotient_evals_kernel".  total_ms / launches accumulate until reset. */
+ * "msm_reduce", "quotient_evals_kernel", "perm_terms_kernel", "perm_scan_num", "perm_scan_den_final",
+ * "poly_eval_kernel", "poly_lincomb_kernel", "poly_scale_kernel", "poly_div_scan".  total_ms / launches accumulate until reset. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_reset(plonk_ctx* ctx);
 int plonk_profile_get(plonk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

@@ -407,3 +407,189 @@ def quotient_evals(f: Field, n: int, sel, sig, wire, z, pi, alpha, beta, gamma, 
         l1 = a2n * (z[i] - 1) * pow(x - 1, -1, p) % p
         out.append((zh_inv[i % ratio] * (gate + perm) + l1) % p)
     return out
+
+
+# --------------------------------------------------------------------------- permutation grand product
+def perm_product(f: Field, n: int, wires, id_perm, perm_idx, beta: int, gamma: int):
+    """dispatcher2.rs:329-344 on plain residues.  wires[5][n] = witness[wire_variables[i][j]],
+    id_perm[5n] = extended_id_permutation, perm_idx[5n] = perm_i*n + perm_j of wire_permutation[i*n+j].
+    Returns product_vec (n evaluations, product_vec[0] = 1).  A zero denominator panics in the reference
+    (Fp Div unwraps the inverse); here it raises ZeroDivisionError/ValueError from pow()."""
+    p = f.p
+    out = [1]
+    for j in range(n - 1):
+        a = b = 1
+        for i in range(len(wires)):
+            t = (wires[i][j] + gamma) % p
+            a = a * (t + beta * id_perm[i * n + j]) % p
+            b = b * (t + beta * id_perm[perm_idx[i * n + j]]) % p
+        out.append(out[j] * a % p * pow(b, -1, p) % p)
+    return out
+
+
+# --------------------------------------------------------------------------- SURVEY §8f rank 3: round 4/5 polynomial ops
+def poly_eval(f: Field, coeffs, z: int) -> int:
+    """DensePolynomial::evaluate (Horner), dispatcher2.rs:545-555."""
+    acc = 0
+    for c in reversed(coeffs):
+        acc = (acc * z + c) % f.p
+    return acc
+
+
+def poly_lincomb(f: Field, polys, coeffs):
+    """sum_k coeffs[k] * polys[k]  (DensePolynomial Mul<Fr> / Add), dispatcher2.rs:566-633,646-649."""
+    out = [0] * max((len(q) for q in polys), default=0)
+    for q, c in zip(polys, coeffs):
+        for i, v in enumerate(q):
+            out[i] = (out[i] + c * v) % f.p
+    return out
+
+
+def poly_div_linear(f: Field, coeffs, z: int):
+    """The synthetic-division loop of dispatcher2.rs:651-666 / :672-688: quotient of poly / (X - z), remainder dropped.
+    Restated literally (remainder vector, pop of trailing zeros) so the trimmed-degree behaviour is the reference's."""
+    p = f.p
+    rem = list(coeffs)
+    while rem and rem[-1] == 0:
+        rem.pop()
+    if len(rem) <= 1:
+        return []
+    quot = [0] * (len(rem) - 1)
+    while rem and len(rem) - 1 >= 1:
+        cq = rem[-1]
+        d = len(rem) - 2
+        quot[d] = cq
+        rem[d] = (rem[d] + cq * z) % p
+        rem[d + 1] = (rem[d + 1] - cq) % p
+        while rem and rem[-1] == 0:
+            rem.pop()
+    return quot
+
+
+def blind(f: Field, coeffs, n: int, blinders):
+    """DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly  (dispatcher2.rs:311-312,347-348):
+    (sum b_i X^i)(X^n - 1) + poly."""
+    out = list(coeffs) + [0] * (n + len(blinders) - len(coeffs))
+    for i, b in enumerate(blinders):
+        out[i] = (out[i] - b) % f.p
+        out[n + i] = (out[n + i] + b) % f.p
+    return out
+
+
+def prove_rounds(cv: Curve, n: int, ck, circuit: dict, blinders: dict, ch: dict):
+    """Rounds 1-5 of dispatcher2.rs::Prover::prove (:296-712) on plain residues, with the transcript challenges
+    (beta, gamma, alpha, zeta, v) and the blinding polynomials supplied by the caller.
+    circuit: wires[5][n] evaluations, selectors[13] / sigmas[5] coefficient vectors (ProvingKey polys), id_perm[5n],
+    perm_idx[5n], pub_input[n] evaluations, k[5].  ck: affine points (None = infinity), already padded (:207-208).
+    Returns a dict with every commitment (affine) and evaluation of `Proof` plus intermediate polynomials."""
+    f = cv.fr
+    p = f.p
+    dom, qdom = Radix2Domain(f, n), Radix2Domain(f, 6 * n + 7)
+    m = qdom.size
+    assert m == 8 * n
+
+    def commit(coeffs):
+        return commit_polynomial(cv, ck, [f.to_mont(c) for c in coeffs])
+
+    # Round 1 (:296-322)
+    wire_polys = [blind(f, dom.ifft(circuit["wires"][i]), n, blinders["wires"][i]) for i in range(5)]
+    wires_poly_comms = [commit(q) for q in wire_polys]
+    # Round 2 (:325-357)
+    beta, gamma = ch["beta"], ch["gamma"]
+    prod = perm_product(f, n, circuit["wires"], circuit["id_perm"], circuit["perm_idx"], beta, gamma)
+    perm_poly = blind(f, dom.ifft(prod), n, blinders["perm"])
+    prod_perm_poly_comm = commit(perm_poly)
+    # Round 3 (:360-533)
+    alpha = ch["alpha"]
+
+    def cfft(coeffs):
+        return qdom.coset_fft(list(coeffs) + [0] * (m - len(coeffs)))
+
+    pi_poly = dom.ifft(circuit["pub_input"])
+    evals = quotient_evals(f, n, [cfft(q) for q in circuit["selectors"]], [cfft(q) for q in circuit["sigmas"]],
+                           [cfft(q) for q in wire_polys], cfft(perm_poly), cfft(pi_poly), alpha, beta, gamma, circuit["k"])
+    quot = qdom.coset_ifft(evals)
+    while quot and quot[-1] == 0:
+        quot.pop()
+    expected_degree = 5 * (n + 1) + 2
+    if len(quot) - 1 != expected_degree:
+        raise ValueError(f"WrongQuotientPolyDegree({len(quot) - 1}, {expected_degree})")
+    split = [quot[i:i + n + 2] for i in range(0, len(quot), n + 2)]
+    split_quot_poly_comms = [commit(q) for q in split]
+    # Round 4 (:536-555)
+    zeta = ch["zeta"]
+    wires_evals = [poly_eval(f, q, zeta) for q in wire_polys]
+    wire_sigma_evals = [poly_eval(f, q, zeta) for q in circuit["sigmas"][:4]]
+    perm_next_eval = poly_eval(f, perm_poly, zeta * dom.group_gen % p)
+    # Round 5 (:558-690)
+    vanish = (pow(zeta, n, p) - 1) % p
+    a, b, c, d, e = wires_evals
+    ab, cd = a * b % p, c * d % p
+    sel = circuit["selectors"]
+    polys = list(sel[:13])
+    coeffs = [a, b, c, d, ab, cd, pow(a, 5, p), pow(b, 5, p), pow(c, 5, p), pow(d, 5, p), (-e) % p, 1, ab * cd % p * e % p]
+    l1 = vanish * pow(n * (zeta - 1) % p, -1, p) % p
+    acc = alpha
+    for w, k in zip(wires_evals, circuit["k"]):
+        acc = acc * ((w + beta * k % p * zeta + gamma) % p) % p
+    polys.append(perm_poly)
+    coeffs.append((acc + alpha * alpha % p * l1) % p)
+    acc = alpha * beta % p * perm_next_eval % p
+    for w, s in zip(wires_evals[:4], wire_sigma_evals):
+        acc = acc * ((w + beta * s + gamma) % p) % p
+    polys.append(circuit["sigmas"][4])
+    coeffs.append((-acc) % p)
+    z_n2 = (vanish + 1) * zeta % p * zeta % p
+    cq = 1
+    for q in split:
+        polys.append(q)
+        coeffs.append((-vanish) * cq % p)
+        cq = cq * z_n2 % p
+    lin_poly = poly_lincomb(f, polys, coeffs)
+    v = ch["v"]
+    bp = [lin_poly] + wire_polys + list(circuit["sigmas"][:4])
+    batch_poly = poly_lincomb(f, bp, [pow(v, i, p) for i in range(len(bp))])
+    opening_proof = commit(poly_div_linear(f, batch_poly, zeta))
+    shifted_opening_proof = commit(poly_div_linear(f, perm_poly, zeta * dom.group_gen % p))
+    return dict(wires_poly_comms=wires_poly_comms, prod_perm_poly_comm=prod_perm_poly_comm,
+                split_quot_poly_comms=split_quot_poly_comms, opening_proof=opening_proof,
+                shifted_opening_proof=shifted_opening_proof, wires_evals=wires_evals, wire_sigma_evals=wire_sigma_evals,
+                perm_next_eval=perm_next_eval, wire_polys=wire_polys, perm_poly=perm_poly, quot_poly=quot, lin_poly=lin_poly,
+                batch_poly=batch_poly)
+
+
+def make_circuit(f: Field, n: int, rng: random.Random, num_inputs: int = 2):
+    """A random SATISFIED TurboPlonk instance with non-trivial copy constraints (test input; the reference takes
+    its circuit from jf-plonk's PlonkCircuit, which is not part of this path).  Gate j:
+      q_c + pi + sum q_lc_i w_i + q_mul0 ab + q_mul1 cd + q_ecc abcde + sum q_hash_i w_i^5 - q_o e = 0
+    a..d reference a pool of free variables or outputs of earlier gates; e is the gate's output variable."""
+    p = f.p
+    dom = Radix2Domain(f, n)
+    witness = [rng.randrange(p) for _ in range(max(2, n // 2))]
+    wire_vars = [[0] * n for _ in range(5)]
+    sel_ev = [[rng.randrange(p) for _ in range(n)] for _ in range(13)]
+    pi = [rng.randrange(p) if j < num_inputs else 0 for j in range(n)]
+    for j in range(n):
+        for i in range(4):
+            wire_vars[i][j] = rng.randrange(len(witness))
+        a, b, c, d = (witness[wire_vars[i][j]] for i in range(4))
+        s = [sel_ev[t][j] for t in range(13)]
+        rest = (s[11] + pi[j] + s[0] * a + s[1] * b + s[2] * c + s[3] * d + s[4] * a * b + s[5] * c * d
+                + s[6] * pow(a, 5, p) + s[7] * pow(b, 5, p) + s[8] * pow(c, 5, p) + s[9] * pow(d, 5, p)) % p
+        den = (s[10] - s[12] * a * b % p * c % p * d) % p
+        witness.append(rest * pow(den, -1, p) % p)
+        wire_vars[4][j] = len(witness) - 1
+    wires = [[witness[wire_vars[i][j]] for j in range(n)] for i in range(5)]
+    k = [1] + [rng.randrange(2, p) for _ in range(4)]
+    id_perm = [k[i] * pow(dom.group_gen, j, p) % p for i in range(5) for j in range(n)]
+    occ = {}
+    for i in range(5):
+        for j in range(n):
+            occ.setdefault(wire_vars[i][j], []).append(i * n + j)
+    perm_idx = [0] * (5 * n)
+    for positions in occ.values():
+        for t, pos in enumerate(positions):
+            perm_idx[pos] = positions[(t + 1) % len(positions)]
+    sigmas = [dom.ifft([id_perm[perm_idx[i * n + j]] for j in range(n)]) for i in range(5)]
+    selectors = [dom.ifft(ev) for ev in sel_ev]
+    return dict(wires=wires, selectors=selectors, sigmas=sigmas, id_perm=id_perm, perm_idx=perm_idx, pub_input=pi, k=k)

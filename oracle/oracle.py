@@ -233,3 +233,56 @@ def quotient_evals(curve, log_n, sel, sig, wire, z, pi, alpha, beta, gamma, k, t
     if rc:
         raise ValueError("DomainCreationError")
     return out
+
+
+def perm_product(curve, wires, id_perm, perm_idx, beta, gamma):
+    """dispatcher2.rs:329-344.  wires (5,n,4), id_perm (5n,4), perm_idx (5n,) u64 flattened perm_i*n+perm_j -> (n,4)."""
+    wires, id_perm, perm_idx = _u64(wires), _u64(id_perm), _u64(perm_idx)
+    n = wires.shape[1]
+    assert wires.shape == (5, n, 4) and id_perm.shape == (5 * n, 4) and perm_idx.shape == (5 * n,)
+    out = np.empty((n, 4), dtype=np.uint64)
+    rc = lib().orc_perm_product(curve, C.c_size_t(n), _p(wires), _p(id_perm), _p(perm_idx), _p(_u64(beta)), _p(_u64(gamma)), _p(out))
+    if rc:
+        raise ZeroDivisionError("permutation product: zero denominator (the reference panics)")
+    return out
+
+
+def poly_eval(curve, coeffs, z):
+    """DensePolynomial::evaluate, dispatcher2.rs:545-555 -> (4,)"""
+    coeffs = _u64(coeffs)
+    out = np.empty(4, dtype=np.uint64)
+    lib().orc_poly_eval(curve, _p(coeffs), C.c_size_t(coeffs.shape[0]), _p(_u64(z)), _p(out))
+    return out
+
+
+def poly_lincomb(curve, polys, coeffs):
+    """sum_k coeffs[k] * polys[k]; polys: list of (len_k,4); coeffs (k,4) -> (max len, 4)"""
+    polys = [_u64(q) for q in polys]
+    coeffs = _u64(coeffs)
+    k = len(polys)
+    out_len = max(q.shape[0] for q in polys)
+    ptrs = (C.c_void_p * k)(*[q.ctypes.data for q in polys])
+    lens = (C.c_size_t * k)(*[q.shape[0] for q in polys])
+    out = np.empty((out_len, 4), dtype=np.uint64)
+    lib().orc_poly_lincomb(curve, C.c_size_t(k), ptrs, lens, _p(coeffs), _p(out), C.c_size_t(out_len))
+    return out
+
+
+def poly_div_linear(curve, coeffs, z):
+    """quotient of poly / (X - z), dispatcher2.rs:651-666 -> (len-1, 4)"""
+    coeffs = _u64(coeffs)
+    n = coeffs.shape[0]
+    out = np.empty((max(n - 1, 0), 4), dtype=np.uint64)
+    lib().orc_poly_div_linear(curve, _p(coeffs), C.c_size_t(n), _p(_u64(z)), _p(out))
+    return out
+
+
+def blind(curve, coeffs, n, blinders):
+    """(sum b_i X^i)(X^n - 1) + poly -> (n + k, 4)"""
+    bl = _u64(blinders)
+    k = bl.shape[0]
+    out = np.zeros((n + k, 4), dtype=np.uint64)
+    c = _u64(coeffs)
+    out[:c.shape[0]] = c
+    lib().orc_blind(curve, _p(out), C.c_size_t(n), _p(bl), C.c_size_t(k))
+    return out

@@ -704,4 +704,97 @@ int orc_quotient_evals(int curve, int log_n, const uint64_t *sel, const uint64_t
     return 0;
 }
 
+/* ---- permutation grand product, dispatcher2.rs:329-344.
+ * wires[5][n] (= witness[wire_variables[i][j]]), id_perm[5n] (extended_id_permutation), perm_idx[5n] (perm_i*n+perm_j),
+ * all Fr Montgomery; out[n], out[0] = 1.  Returns -2 on a zero denominator (the reference panics there). */
+int orc_perm_product(int curve, size_t n, const uint64_t *wires_, const uint64_t *id_perm_, const uint64_t *perm_idx,
+                     const uint64_t *beta_, const uint64_t *gamma_, uint64_t *out_) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    const fe4 *W = (const fe4 *)wires_, *ID = (const fe4 *)id_perm_;
+    const fe4 beta = *(const fe4 *)beta_, gamma = *(const fe4 *)gamma_;
+    fe4 *out = (fe4 *)out_;
+    fe4 zero; memset(&zero, 0, sizeof zero);
+    out[0] = F->one;
+    if (n < 2) return 0;
+    /* a[j] / b[j] per gate; the divisions use Montgomery's batch-inversion trick per 1024-gate chunk (field
+     * arithmetic is exact, so the quotients are the reference's a / b) */
+    fe4 *A = (fe4 *)malloc(sizeof(fe4) * n), *Bv = (fe4 *)malloc(sizeof(fe4) * n);
+    int bad = 0;
+#pragma omp parallel for schedule(static)
+    for (size_t j = 0; j < n - 1; j++) {
+        fe4 a = F->one, b = F->one, t, u;
+        for (int i = 0; i < 5; i++) {
+            fe_add4(F, &t, &W[i * n + j], &gamma);
+            fe_mul4(F, &u, &beta, &ID[i * n + j]); fe_add4(F, &u, &t, &u); fe_mul4(F, &a, &a, &u);
+            fe_mul4(F, &u, &beta, &ID[perm_idx[i * n + j]]); fe_add4(F, &u, &t, &u); fe_mul4(F, &b, &b, &u);
+        }
+        A[j] = a; Bv[j] = b;
+        if (!memcmp(&b, &zero, sizeof b)) {
+#pragma omp atomic write
+            bad = 1;
+        }
+    }
+    if (bad) { free(A); free(Bv); return -2; }
+    const size_t CH = 1024, nch = (n - 1 + CH - 1) / CH;
+#pragma omp parallel for schedule(static)
+    for (size_t c = 0; c < nch; c++) {
+        size_t lo = c * CH, hi = lo + CH < n - 1 ? lo + CH : n - 1;
+        fe4 pre[1024], run = F->one, inv, t;
+        for (size_t j = lo; j < hi; j++) { pre[j - lo] = run; fe_mul4(F, &run, &run, &Bv[j]); }
+        fe_inv4(F, &inv, &run);
+        for (size_t j = hi; j-- > lo;) {
+            fe_mul4(F, &t, &inv, &pre[j - lo]);      /* 1 / b[j] */
+            fe_mul4(F, &inv, &inv, &Bv[j]);
+            fe_mul4(F, &A[j], &A[j], &t);            /* a[j] / b[j] */
+        }
+    }
+    for (size_t j = 0; j + 1 < n; j++) fe_mul4(F, &out[j + 1], &out[j], &A[j]);
+    free(A); free(Bv);
+    return 0;
+}
+
+/* ---- round 4/5 polynomial ops (coefficients Fr Montgomery) */
+/* DensePolynomial::evaluate, dispatcher2.rs:545-555 */
+int orc_poly_eval(int curve, const uint64_t *coeffs_, size_t len, const uint64_t *z_, uint64_t *out_) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    const fe4 *c = (const fe4 *)coeffs_; const fe4 z = *(const fe4 *)z_;
+    fe4 acc; memset(&acc, 0, sizeof acc);
+    for (size_t i = len; i-- > 0;) { fe_mul4(F, &acc, &acc, &z); fe_add4(F, &acc, &acc, &c[i]); }
+    memcpy(out_, &acc, 32);
+    return 0;
+}
+/* out[i] = sum_k coeff[k] * polys[k][i]  (i < lens[k]); out_len = max lens.  dispatcher2.rs:566-633,646-649 */
+int orc_poly_lincomb(int curve, size_t k, const uint64_t *const *polys, const size_t *lens, const uint64_t *coeffs_, uint64_t *out_, size_t out_len) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    fe4 *out = (fe4 *)out_;
+    memset(out, 0, 32 * out_len);
+    for (size_t t = 0; t < k; t++) {
+        const fe4 *q = (const fe4 *)polys[t]; const fe4 cf = ((const fe4 *)coeffs_)[t];
+        size_t L = lens[t] < out_len ? lens[t] : out_len;
+#pragma omp parallel for schedule(static)
+        for (size_t i = 0; i < L; i++) { fe4 u; fe_mul4(F, &u, &q[i], &cf); fe_add4(F, &out[i], &out[i], &u); }
+    }
+    return 0;
+}
+/* quotient of poly / (X - z), remainder dropped: dispatcher2.rs:651-666 (q_{i-1} = c_i + z q_i).  out: len-1 coefficients. */
+int orc_poly_div_linear(int curve, const uint64_t *coeffs_, size_t len, const uint64_t *z_, uint64_t *out_) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    const fe4 *c = (const fe4 *)coeffs_; const fe4 z = *(const fe4 *)z_;
+    fe4 *q = (fe4 *)out_;
+    if (len < 2) return 0;
+    fe4 carry; memset(&carry, 0, sizeof carry);
+    for (size_t i = len - 1; i >= 1; i--) {
+        fe4 t; fe_mul4(F, &t, &carry, &z); fe_add4(F, &carry, &c[i], &t);
+        q[i - 1] = carry;
+    }
+    return 0;
+}
+/* (sum_i b_i X^i)(X^n - 1) + poly, in place; poly has n + k coefficients.  dispatcher2.rs:311-312,347-348 */
+int orc_blind(int curve, uint64_t *poly_, size_t n, const uint64_t *blinders_, size_t k) {
+    curve_t *C = get_curve(curve); const fctx4 *F = &C->fr;
+    fe4 *p = (fe4 *)poly_; const fe4 *b = (const fe4 *)blinders_;
+    for (size_t i = 0; i < k; i++) { fe_sub4(F, &p[i], &p[i], &b[i]); fe_add4(F, &p[n + i], &p[n + i], &b[i]); }
+    return 0;
+}
+
 int orc_max_threads(void) { return omp_get_max_threads(); }
