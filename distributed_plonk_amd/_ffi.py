@@ -92,6 +92,8 @@ SIGNATURES = {
     "plonk_poly_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "plonk_poly_lincomb_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plonk_poly_div_linear_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "plonk_poly_degree_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
+    "plonk_memset_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
     "plonk_blind_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     "plonk_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "plonk_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

@@ -669,6 +669,13 @@ extern "C" int plonk_poly_div_linear_dev(plonk_ctx* ctx, const void* d_poly, siz
     if (rc) return rc;
     return poly_div_linear_run(ctx->tables, d_poly, len, point, d_out, ctx->d_scratch2, ctx->stream);
 }
+extern "C" int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t len, int64_t* degree) {
+    CHECK_CTX(ctx);
+    if ((!d_poly && len) || !degree) return plonk_fail(PLONK_ERR_ARG, "plonk_poly_degree_dev: null");
+    int rc = ensure_scratch2(ctx, 256);
+    if (rc) return rc;
+    return poly_degree_run(d_poly, len, degree, ctx->d_scratch2, ctx->stream);
+}
 extern "C" int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k) {
     CHECK_CTX(ctx);
     if (!d_poly || (!blinders && k)) return plonk_fail(PLONK_ERR_ARG, "plonk_blind_dev: null");
@@ -698,6 +705,12 @@ extern "C" int plonk_memcpy_d2h(plonk_ctx* ctx, void* h, const void* d, size_t b
     CHECK_CTX(ctx);
     HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+extern "C" int plonk_memset_dev(plonk_ctx* ctx, void* d, int byte, size_t bytes) {
+    CHECK_CTX(ctx);
+    if (!d && bytes) return plonk_fail(PLONK_ERR_ARG, "plonk_memset_dev: null");
+    if (bytes) HIP_TRY(hipMemsetAsync(d, byte, bytes, ctx->stream));
     return PLONK_OK;
 }
 extern "C" int plonk_memcpy_d2d(plonk_ctx* ctx, void* dst, const void* src, size_t bytes) {

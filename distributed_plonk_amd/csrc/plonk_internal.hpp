@@ -142,3 +142,4 @@ int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const siz
                      hipStream_t stream);
 int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, void* d_out, void* scratch, hipStream_t stream);
 int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, size_t k, hipStream_t stream);
+int poly_degree_run(const void* d_poly, size_t len, int64_t* degree, void* scratch, hipStream_t stream);

@@ -566,3 +566,24 @@ int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, si
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "blind launch: %s", hipGetErrorString(e));
     return PLONK_OK;
 }
+
+// ---------------------------------------------------------------------------------------------- degree (DensePolynomial trimming)
+// index of the highest non-zero coefficient + 1 (0 for the zero polynomial): what DensePolynomial::from_coefficients_vec
+// leaves after trimming, used for the WrongQuotientPolyDegree check of dispatcher2.rs:511-518
+__global__ void __launch_bounds__(256) poly_degree_kernel(const Fr* __restrict__ poly, uint64_t len, unsigned long long* __restrict__ top) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    if (!fp_is_zero(load_fr(poly + i))) atomicMax(top, (unsigned long long)(i + 1));
+}
+int poly_degree_run(const void* d_poly, size_t len, int64_t* degree, void* scratch, hipStream_t stream) {
+    unsigned long long* top = (unsigned long long*)scratch;
+    HIP_TRY(hipMemsetAsync(top, 0, 8, stream));
+    if (len) hipLaunchKernelGGL(poly_degree_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, top);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "poly_degree launch: %s", hipGetErrorString(e));
+    unsigned long long h = 0;
+    HIP_TRY(hipMemcpyAsync(&h, top, 8, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *degree = (int64_t)h - 1;
+    return PLONK_OK;
+}

@@ -245,6 +245,12 @@ class PlonkWorker:
         z = _u64(point)
         check(self.lib.plonk_poly_div_linear_dev(self.ctx, d_poly, length, _ptr(z), d_out))
 
+    def poly_degree_dev(self, d_poly: int, length: int) -> int:
+        """DensePolynomial::degree() after trimming (-1 = zero polynomial), dispatcher2.rs:511-518."""
+        d = C.c_int64(0)
+        check(self.lib.plonk_poly_degree_dev(self.ctx, d_poly, length, C.byref(d)))
+        return d.value
+
     def blind_dev(self, d_poly: int, n: int, blinders):
         """d_poly[0..n+k) += (sum b_i X^i)(X^n - 1) (dispatcher2.rs:311-312,347-348)."""
         b = _u64(blinders).reshape(-1, 4)
@@ -253,6 +259,9 @@ class PlonkWorker:
     # ------------------------------------------------------------------ device memory, synthetic inputs, debug
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
+
+    def memset_dev(self, dst: int, byte: int, nbytes: int):
+        check(self.lib.plonk_memset_dev(self.ctx, dst, byte, nbytes))
 
     def memcpy_d2d(self, dst: int, src: int, nbytes: int):
         check(self.lib.plonk_memcpy_d2d(self.ctx, dst, src, nbytes))

@@ -163,6 +163,9 @@ int plonk_poly_lincomb_dev(plonk_ctx* ctx, size_t k, const void* const* d_polys,
                            void* d_out, size_t out_len);
 /* d_out[0..len-1) = quotient of poly / (X - point), remainder dropped: the synthetic-division loops of :651-666,672-688. */
 int plonk_poly_div_linear_dev(plonk_ctx* ctx, const void* d_poly, size_t len, const uint64_t* point, void* d_out);
+/* *degree = index of the highest non-zero coefficient, -1 for the zero polynomial: DensePolynomial::degree() after the
+ * trimming of from_coefficients_vec — the WrongQuotientPolyDegree check of :511-518 without a host copy.  Synchronises. */
+int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t len, int64_t* degree);
 /* d_poly (n + k coefficients, the top k already valid, normally zero) += (sum_{i<k} blinders[i] X^i) * (X^n - 1):
  * DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly (:311-312 k = 2, :347-348 k = 3).  k <= 4. */
 int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k);
@@ -173,6 +176,7 @@ int plonk_dev_free(plonk_ctx* ctx, void* p);
 int plonk_memcpy_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int plonk_memcpy_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int plonk_memcpy_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int plonk_memset_dev(plonk_ctx* ctx, void* d_dst, int byte, size_t bytes);
 /* n uniform Fr (Montgomery limbs drawn like ark-ff's Fp::rand: mask + rejection), element i from
  * stream (seed, i). */
 int plonk_synth_fr(plonk_ctx* ctx, uint64_t seed, void* d_out, size_t n);

@@ -1,0 +1,73 @@
+"""Rounds 1-5 of the reference prover (dispatcher2.rs:296-712) with every vector on the device, against the oracle's
+restatement of the same rounds on the same satisfied circuit, challenges and blinders: every commitment (affine limbs),
+every evaluation and the intermediate polynomials must be bit-identical."""
+import numpy as np
+import pytest
+
+from distributed_plonk_amd.prover import Prover, WrongQuotientPolyDegree
+
+pytestmark = pytest.mark.gpu
+
+
+def _instance(oracle, cid, log_n, seed):
+    from oracle import prover_ref as P
+    n = 1 << log_n
+    circ = P.make_circuit(cid, log_n, seed=seed)
+    ck, inf = P.make_ck(cid, n, seed=seed + 1, unique=min(64, n))
+    bl = dict(wires=oracle.rand_fr(cid, seed + 2, 10).reshape(5, 2, 4), perm=oracle.rand_fr(cid, seed + 3, 3))
+    ch = {k: oracle.rand_fr(cid, seed + 10 + i, 1)[0] for i, k in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
+    return P, circ, ck, inf, bl, ch
+
+
+def _same_point(got, want):
+    return got[1] == want[1] and np.array_equal(got[0], want[0])
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,cache", [(3, False), (6, True), (10, False), (12, True)])
+def test_prover_rounds_match_oracle(gpu_workers, oracle, curve, cid, log_n, cache):
+    P, circ, ck, inf, bl, ch = _instance(oracle, cid, log_n, 40 + log_n)
+    n = 1 << log_n
+    w = gpu_workers(curve)
+    w.init(ck, n, 8 * n)                                   # (0,0) rows = the zero points of dispatcher2.rs:207-208
+    pv = Prover(w, log_n, cache_key_cosets=cache)
+    try:
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        for _ in range(2 if cache else 1):                 # a second proof reuses the cached key cosets
+            got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+        want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=16)
+        for key in ("wires_poly_comms", "split_quot_poly_comms"):
+            assert len(got[key]) == len(want[key]) == 5
+            for g, x in zip(got[key], want[key]):
+                assert _same_point(g, x), key
+        for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+            assert _same_point(got[key], want[key]), key
+        for key in ("wires_evals", "wire_sigma_evals"):
+            assert np.array_equal(np.stack(got[key]), np.stack(want[key])), key
+        assert np.array_equal(got["perm_next_eval"], want["perm_next_eval"])
+        for key in ("perm_product", "perm_poly", "quot_poly", "lin_poly", "batch_poly"):
+            assert np.array_equal(got["_debug"][key], want[key]), key
+        assert set(pv.timings) >= {"round1", "round2", "round3_coset_ffts", "round3_quotient", "round3_commit", "round4", "round5"}
+    finally:
+        pv.close()
+
+
+def test_prover_rejects_unsatisfied_circuit(gpu_workers, oracle):
+    """dispatcher2.rs:511-518: a witness that violates one gate makes the quotient's degree wrong."""
+    P, circ, ck, inf, bl, ch = _instance(oracle, 0, 5, 77)
+    n = 32
+    w = gpu_workers("bn254")
+    w.init(ck, n, 8 * n)
+    pv = Prover(w, 5)
+    try:
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        wires = circ["wires"].copy()
+        wires[4, 7] = oracle.rand_fr(0, 1234, 1)[0]
+        with pytest.raises(WrongQuotientPolyDegree):
+            pv.prove(wires, circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
+        with pytest.raises(ValueError, match="WrongQuotientPolyDegree"):
+            P.prove_rounds(0, 5, ck, inf, dict(circ, wires=wires), bl, ch)
+        # the same prover object still produces a valid proof afterwards (no leaked state)
+        pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
+    finally:
+        pv.close()
