@@ -39,6 +39,7 @@ class Prover:
         self.cache_key_cosets = cache_key_cosets
         self._key = None
         self._bufs = []
+        self._ws: Dict[str, object] = {}      # named work buffers, allocated by the first proof and reused (hipMalloc of ~100 GiB takes seconds)
         self.timings: Dict[str, float] = {}
 
     # ------------------------------------------------------------------ device buffers
@@ -53,18 +54,33 @@ class Prover:
                 self._bufs.remove(b)
             b.free()
 
+    def _work(self, name: str, n_fr: int):
+        b = self._ws.get(name)
+        if b is None or b.nbytes < max(n_fr, 1) * 32:
+            if b is not None:
+                self._free([b])
+            b = self._ws[name] = self._alloc(n_fr)
+        return b
+
     def close(self):
         self._free(list(self._bufs))
+        self._ws.clear()
         self._key = None
 
     def load_key(self, selectors: np.ndarray, sigmas: np.ndarray, k: np.ndarray):
         """ProvingKey polynomials in coefficient form: selectors (13,n,4), sigmas (5,n,4); k = vk.k (5,4)."""
-        n, m = self.n, self.m
-        assert selectors.shape == (NUM_SELECTORS, n, 4) and sigmas.shape == (NUM_WIRE_TYPES, n, 4) and k.shape == (NUM_WIRE_TYPES, 4)
+        n = self.n
+        assert selectors.shape == (NUM_SELECTORS, n, 4) and sigmas.shape == (NUM_WIRE_TYPES, n, 4)
         sel = self._alloc(NUM_SELECTORS * n).upload(selectors)
         sig = self._alloc(NUM_WIRE_TYPES * n).upload(sigmas)
-        self._key = dict(sel=[sel.ptr + i * n * 32 for i in range(NUM_SELECTORS)], sig=[sig.ptr + i * n * 32 for i in range(NUM_WIRE_TYPES)],
-                         k=np.ascontiguousarray(k, dtype=np.uint64), cos=None)
+        self.load_key_dev([sel.ptr + i * n * 32 for i in range(NUM_SELECTORS)], [sig.ptr + i * n * 32 for i in range(NUM_WIRE_TYPES)], k)
+
+    def load_key_dev(self, sel_ptrs, sig_ptrs, k: np.ndarray):
+        """Same with the 13 + 5 coefficient vectors (n Fr each) already in HBM; the caller keeps them alive."""
+        n, m = self.n, self.m
+        k = np.ascontiguousarray(k, dtype=np.uint64)
+        assert len(sel_ptrs) == NUM_SELECTORS and len(sig_ptrs) == NUM_WIRE_TYPES and k.shape == (NUM_WIRE_TYPES, 4)
+        self._key = dict(sel=[int(x) for x in sel_ptrs], sig=[int(x) for x in sig_ptrs], k=k, cos=None)
         if self.cache_key_cosets:
             cos = self._alloc(18 * m)
             tmp = self._alloc(m)
@@ -92,6 +108,22 @@ class Prover:
         """wires (5,n,4): witness[wire_variables[i][j]]; id_perm (5n,4): extended_id_permutation; perm_idx (5n,) u64:
         perm_i*n+perm_j; pub_input (n,4) evaluations (zero-padded); blinders {"wires": (5,2,4), "perm": (3,4)}.
         Returns the fields of `Proof` (dispatcher2.rs:699-710) with commitments as (xy, is_inf)."""
+        n = self.n
+        up = []
+        try:
+            d_wev = self._alloc(5 * n).upload(np.ascontiguousarray(wires, dtype=np.uint64)); up.append(d_wev)
+            d_id = self._alloc(5 * n).upload(np.ascontiguousarray(id_perm, dtype=np.uint64)); up.append(d_id)
+            d_idx = self._alloc((5 * n + 3) // 4).upload(np.ascontiguousarray(perm_idx, dtype=np.uint64)); up.append(d_idx)
+            d_pi = self._alloc(n).upload(np.ascontiguousarray(pub_input, dtype=np.uint64)); up.append(d_pi)
+            return self.prove_dev([d_wev.ptr + i * n * 32 for i in range(5)], d_id.ptr, d_idx.ptr, d_pi.ptr, blinders, challenge,
+                                  check_degree=check_degree, keep=keep)
+        finally:
+            self._free(up)
+
+    def prove_dev(self, wev, d_id: int, d_idx: int, d_pi: int, blinders: dict, challenge: Callable[[str, dict], np.ndarray],
+                  check_degree: bool = True, keep: bool = False) -> dict:
+        """Same as prove() with the circuit data already in HBM: wev = 5 device pointers (n Fr each), d_id (5n Fr),
+        d_idx (5n u64), d_pi (n Fr); none of them is modified."""
         assert self._key is not None, "load_key first"
         w, f, n, m, key = self.w, self.f, self.n, self.m, self._key
         p = f.p
@@ -99,139 +131,130 @@ class Prover:
         T = self.timings
         T.clear()
         proof: dict = {}
-        own = []
+        counter = [0]
 
         def alloc(cnt):
-            b = self._alloc(cnt)
-            own.append(b)
-            return b
+            counter[0] += 1
+            return self._work(f"prove{counter[0]}", cnt)
 
         def tick(name, t0):
             w.sync()
             T[name] = T.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
-        try:
-            # ---- Round 1 (:296-322): wire polynomials and their commitments
-            t0 = time.perf_counter()
-            d_wev = alloc(5 * n).upload(np.ascontiguousarray(wires, dtype=np.uint64))
-            wev = [d_wev.ptr + i * n * 32 for i in range(5)]
-            WP = n + 2
-            d_wp = alloc(5 * WP)
-            wp = [d_wp.ptr + i * WP * 32 for i in range(5)]
-            w.memset_dev(d_wp.ptr, 0, 5 * WP * 32)
-            d_tmp_n = alloc(n)
-            for i in range(5):
-                w.memcpy_d2d(d_tmp_n.ptr, wev[i], n * 32)
-                w.ntt_dev(d_tmp_n.ptr, wp[i], n, True, False)
-                w.blind_dev(wp[i], n, blinders["wires"][i])
-            proof["wires_poly_comms"] = [self._commit(wp[i], WP) for i in range(5)]
-            tick("round1", t0)
-            # ---- Round 2 (:325-357): permutation product polynomial
-            t0 = time.perf_counter()
-            beta, gamma = challenge("beta", proof), challenge("gamma", proof)
-            d_id = alloc(5 * n).upload(np.ascontiguousarray(id_perm, dtype=np.uint64))
-            d_idx = self._alloc((5 * n + 3) // 4)
-            own.append(d_idx)
-            d_idx.upload(np.ascontiguousarray(perm_idx, dtype=np.uint64))
-            d_prod = alloc(n)
-            w.perm_product_dev(wev, d_id.ptr, d_idx.ptr, beta, gamma, n, d_prod.ptr)
-            dbg_prod = d_prod.download((n, 4)) if keep else None              # the iNTT below consumes d_prod
-            PP = n + 3
-            d_pp = alloc(PP)
-            w.memset_dev(d_pp.ptr, 0, PP * 32)
-            w.ntt_dev(d_prod.ptr, d_pp.ptr, n, True, False)
-            w.blind_dev(d_pp.ptr, n, blinders["perm"])
-            proof["prod_perm_poly_comm"] = self._commit(d_pp.ptr, PP)
-            tick("round2", t0)
-            # ---- Round 3 (:360-533): quotient polynomial
-            t0 = time.perf_counter()
-            alpha = challenge("alpha", proof)
-            d_tmp = alloc(m)
-            if key["cos"] is None:
-                d_kc = alloc(18 * m)
-                kc = [d_kc.ptr + j * m * 32 for j in range(18)]
-                for j, src in enumerate(key["sel"] + key["sig"]):
-                    self._coset_fft(src, n, d_tmp.ptr, kc[j])
-            else:
-                kc = key["cos"]
-            d_c = alloc(7 * m)
-            cw = [d_c.ptr + j * m * 32 for j in range(7)]
-            for i in range(5):
-                self._coset_fft(wp[i], WP, d_tmp.ptr, cw[i])
-            self._coset_fft(d_pp.ptr, PP, d_tmp.ptr, cw[5])
-            d_pi = alloc(n).upload(np.ascontiguousarray(pub_input, dtype=np.uint64))
-            w.ntt_dev(d_pi.ptr, d_tmp_n.ptr, n, True, False)                  # :426
-            self._coset_fft(d_tmp_n.ptr, n, d_tmp.ptr, cw[6])               # :428
-            tick("round3_coset_ffts", t0)
-            t0 = time.perf_counter()
-            d_qev = alloc(m)
-            w.quotient_evals_dev(kc[0:13], kc[13:18], cw[0:5], cw[5], cw[6], alpha, beta, gamma, key["k"], d_qev.ptr)
-            d_quot = alloc(m)
-            w.ntt_dev(d_qev.ptr, d_quot.ptr, m, True, True)                 # :507
-            tick("round3_quotient", t0)
-            t0 = time.perf_counter()
-            expected = NUM_WIRE_TYPES * (n + 1) + 2
-            if check_degree:
-                deg = w.poly_degree_dev(d_quot.ptr, m)
-                if deg != expected:
-                    raise WrongQuotientPolyDegree(deg, expected)
-            split = []
-            for off in range(0, expected + 1, n + 2):                       # coeffs.chunks(n + 2)  (:519-523)
-                split.append((d_quot.ptr + off * 32, min(n + 2, expected + 1 - off)))
-            proof["split_quot_poly_comms"] = [self._commit(ptr, ln) for ptr, ln in split]
-            tick("round3_commit", t0)
-            # ---- Round 4 (:536-555): evaluations at zeta
-            t0 = time.perf_counter()
-            zeta = challenge("zeta", proof)
-            z = I(zeta)
-            zeta_w = L(z * f.root_of_unity(n))
-            proof["wires_evals"] = [w.poly_eval_dev(wp[i], WP, zeta) for i in range(5)]
-            proof["wire_sigma_evals"] = [w.poly_eval_dev(key["sig"][i], n, zeta) for i in range(4)]
-            proof["perm_next_eval"] = w.poly_eval_dev(d_pp.ptr, PP, zeta_w)
-            tick("round4", t0)
-            # ---- Round 5 (:558-690): linearisation polynomial, batched opening, shifted opening
-            t0 = time.perf_counter()
-            al, be, ga = I(alpha), I(beta), I(gamma)
-            a, b, c, d, e = (I(x) for x in proof["wires_evals"])
-            sg = [I(x) for x in proof["wire_sigma_evals"]]
-            kk = [I(x) for x in key["k"]]
-            vanish = (pow(z, n, p) - 1) % p
-            ab, cd = a * b % p, c * d % p
-            polys = [(ptr, n) for ptr in key["sel"]]
-            coeffs = [a, b, c, d, ab, cd, pow(a, 5, p), pow(b, 5, p), pow(c, 5, p), pow(d, 5, p), (-e) % p, 1, ab * cd % p * e % p]
-            l1 = vanish * f.inv(n * (z - 1) % p) % p
-            acc = al
-            for wv, k_ in zip((a, b, c, d, e), kk):
-                acc = acc * ((wv + be * k_ % p * z + ga) % p) % p
-            polys.append((d_pp.ptr, PP))
-            coeffs.append((acc + al * al % p * l1) % p)
-            acc = al * be % p * I(proof["perm_next_eval"]) % p
-            for wv, s in zip((a, b, c, d), sg):
-                acc = acc * ((wv + be * s + ga) % p) % p
-            polys.append((key["sig"][4], n))
-            coeffs.append((-acc) % p)
-            z_n2 = (vanish + 1) * z % p * z % p
-            cq = 1
-            for ptr, ln in split:
-                polys.append((ptr, ln))
-                coeffs.append((-vanish) * cq % p)
-                cq = cq * z_n2 % p
-            d_lin = alloc(PP)
-            w.poly_lincomb_dev(polys, f.vec_to_limbs(coeffs), d_lin.ptr, PP)
-            v = I(challenge("v", proof))
-            bp = [(d_lin.ptr, PP)] + [(wp[i], WP) for i in range(5)] + [(key["sig"][i], n) for i in range(4)]
-            d_batch = alloc(PP)
-            w.poly_lincomb_dev(bp, f.vec_to_limbs([pow(v, i, p) for i in range(len(bp))]), d_batch.ptr, PP)
-            d_wit = alloc(PP)
-            w.poly_div_linear_dev(d_batch.ptr, PP, zeta, d_wit.ptr)
-            proof["opening_proof"] = self._commit(d_wit.ptr, PP - 1)
-            w.poly_div_linear_dev(d_pp.ptr, PP, zeta_w, d_wit.ptr)
-            proof["shifted_opening_proof"] = self._commit(d_wit.ptr, PP - 1)
-            tick("round5", t0)
-            if keep:
-                proof["_debug"] = dict(perm_product=dbg_prod, perm_poly=d_pp.download((PP, 4)),
-                                       quot_poly=d_quot.download((expected + 1, 4)), lin_poly=d_lin.download((PP, 4)),
-                                       batch_poly=d_batch.download((PP, 4)))
-            return proof
-        finally:
-            self._free(own)
+        # ---- Round 1 (:296-322): wire polynomials and their commitments
+        t0 = time.perf_counter()
+        WP = n + 2
+        d_wp = alloc(5 * WP)
+        wp = [d_wp.ptr + i * WP * 32 for i in range(5)]
+        w.memset_dev(d_wp.ptr, 0, 5 * WP * 32)
+        d_tmp_n = alloc(n)
+        for i in range(5):
+            w.memcpy_d2d(d_tmp_n.ptr, wev[i], n * 32)
+            w.ntt_dev(d_tmp_n.ptr, wp[i], n, True, False)
+            w.blind_dev(wp[i], n, blinders["wires"][i])
+        proof["wires_poly_comms"] = [self._commit(wp[i], WP) for i in range(5)]
+        tick("round1", t0)
+        # ---- Round 2 (:325-357): permutation product polynomial
+        t0 = time.perf_counter()
+        beta, gamma = challenge("beta", proof), challenge("gamma", proof)
+        d_prod = alloc(n)
+        w.perm_product_dev(wev, d_id, d_idx, beta, gamma, n, d_prod.ptr)
+        dbg_prod = d_prod.download((n, 4)) if keep else None              # the iNTT below consumes d_prod
+        PP = n + 3
+        d_pp = alloc(PP)
+        w.memset_dev(d_pp.ptr, 0, PP * 32)
+        w.ntt_dev(d_prod.ptr, d_pp.ptr, n, True, False)
+        w.blind_dev(d_pp.ptr, n, blinders["perm"])
+        proof["prod_perm_poly_comm"] = self._commit(d_pp.ptr, PP)
+        tick("round2", t0)
+        # ---- Round 3 (:360-533): quotient polynomial
+        t0 = time.perf_counter()
+        alpha = challenge("alpha", proof)
+        d_tmp = alloc(m)
+        if key["cos"] is None:
+            d_kc = alloc(18 * m)
+            kc = [d_kc.ptr + j * m * 32 for j in range(18)]
+            for j, src in enumerate(key["sel"] + key["sig"]):
+                self._coset_fft(src, n, d_tmp.ptr, kc[j])
+        else:
+            kc = key["cos"]
+        d_c = alloc(7 * m)
+        cw = [d_c.ptr + j * m * 32 for j in range(7)]
+        for i in range(5):
+            self._coset_fft(wp[i], WP, d_tmp.ptr, cw[i])
+        self._coset_fft(d_pp.ptr, PP, d_tmp.ptr, cw[5])
+        d_pi_poly = alloc(n)
+        w.memcpy_d2d(d_tmp_n.ptr, d_pi, n * 32)
+        w.ntt_dev(d_tmp_n.ptr, d_pi_poly.ptr, n, True, False)             # :426
+        self._coset_fft(d_pi_poly.ptr, n, d_tmp.ptr, cw[6])               # :428
+        tick("round3_coset_ffts", t0)
+        t0 = time.perf_counter()
+        d_qev = alloc(m)
+        w.quotient_evals_dev(kc[0:13], kc[13:18], cw[0:5], cw[5], cw[6], alpha, beta, gamma, key["k"], d_qev.ptr)
+        d_quot = alloc(m)
+        w.ntt_dev(d_qev.ptr, d_quot.ptr, m, True, True)                 # :507
+        tick("round3_quotient", t0)
+        t0 = time.perf_counter()
+        expected = NUM_WIRE_TYPES * (n + 1) + 2
+        if check_degree:
+            deg = w.poly_degree_dev(d_quot.ptr, m)
+            if deg != expected:
+                raise WrongQuotientPolyDegree(deg, expected)
+        split = []
+        for off in range(0, expected + 1, n + 2):                       # coeffs.chunks(n + 2)  (:519-523)
+            split.append((d_quot.ptr + off * 32, min(n + 2, expected + 1 - off)))
+        proof["split_quot_poly_comms"] = [self._commit(ptr, ln) for ptr, ln in split]
+        tick("round3_commit", t0)
+        # ---- Round 4 (:536-555): evaluations at zeta
+        t0 = time.perf_counter()
+        zeta = challenge("zeta", proof)
+        z = I(zeta)
+        zeta_w = L(z * f.root_of_unity(n))
+        proof["wires_evals"] = [w.poly_eval_dev(wp[i], WP, zeta) for i in range(5)]
+        proof["wire_sigma_evals"] = [w.poly_eval_dev(key["sig"][i], n, zeta) for i in range(4)]
+        proof["perm_next_eval"] = w.poly_eval_dev(d_pp.ptr, PP, zeta_w)
+        tick("round4", t0)
+        # ---- Round 5 (:558-690): linearisation polynomial, batched opening, shifted opening
+        t0 = time.perf_counter()
+        al, be, ga = I(alpha), I(beta), I(gamma)
+        a, b, c, d, e = (I(x) for x in proof["wires_evals"])
+        sg = [I(x) for x in proof["wire_sigma_evals"]]
+        kk = [I(x) for x in key["k"]]
+        vanish = (pow(z, n, p) - 1) % p
+        ab, cd = a * b % p, c * d % p
+        polys = [(ptr, n) for ptr in key["sel"]]
+        coeffs = [a, b, c, d, ab, cd, pow(a, 5, p), pow(b, 5, p), pow(c, 5, p), pow(d, 5, p), (-e) % p, 1, ab * cd % p * e % p]
+        l1 = vanish * f.inv(n * (z - 1) % p) % p
+        acc = al
+        for wv, k_ in zip((a, b, c, d, e), kk):
+            acc = acc * ((wv + be * k_ % p * z + ga) % p) % p
+        polys.append((d_pp.ptr, PP))
+        coeffs.append((acc + al * al % p * l1) % p)
+        acc = al * be % p * I(proof["perm_next_eval"]) % p
+        for wv, s in zip((a, b, c, d), sg):
+            acc = acc * ((wv + be * s + ga) % p) % p
+        polys.append((key["sig"][4], n))
+        coeffs.append((-acc) % p)
+        z_n2 = (vanish + 1) * z % p * z % p
+        cq = 1
+        for ptr, ln in split:
+            polys.append((ptr, ln))
+            coeffs.append((-vanish) * cq % p)
+            cq = cq * z_n2 % p
+        d_lin = alloc(PP)
+        w.poly_lincomb_dev(polys, f.vec_to_limbs(coeffs), d_lin.ptr, PP)
+        v = I(challenge("v", proof))
+        bp = [(d_lin.ptr, PP)] + [(wp[i], WP) for i in range(5)] + [(key["sig"][i], n) for i in range(4)]
+        d_batch = alloc(PP)
+        w.poly_lincomb_dev(bp, f.vec_to_limbs([pow(v, i, p) for i in range(len(bp))]), d_batch.ptr, PP)
+        d_wit = alloc(PP)
+        w.poly_div_linear_dev(d_batch.ptr, PP, zeta, d_wit.ptr)
+        proof["opening_proof"] = self._commit(d_wit.ptr, PP - 1)
+        w.poly_div_linear_dev(d_pp.ptr, PP, zeta_w, d_wit.ptr)
+        proof["shifted_opening_proof"] = self._commit(d_wit.ptr, PP - 1)
+        tick("round5", t0)
+        if keep:
+            proof["_debug"] = dict(perm_product=dbg_prod, perm_poly=d_pp.download((PP, 4)),
+                                   quot_poly=d_quot.download((expected + 1, 4)), lin_poly=d_lin.download((PP, 4)),
+                                   batch_poly=d_batch.download((PP, 4)))
+        return proof
