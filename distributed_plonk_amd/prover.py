@@ -17,6 +17,7 @@ from typing import Callable, Dict, Optional
 import numpy as np
 
 from . import fr as _fr
+from .transcript import PlonkTranscript
 from .worker import PlonkWorker
 
 NUM_WIRE_TYPES = 5
@@ -27,6 +28,29 @@ class WrongQuotientPolyDegree(Exception):        # SnarkError::WrongQuotientPoly
     def __init__(self, got: int, expected: int):
         super().__init__(f"WrongQuotientPolyDegree({got}, {expected})")
         self.got, self.expected = got, expected
+
+
+class FiatShamir:
+    """Challenge source backed by the reference's transcript: appends what `Prover::prove` appends before each challenge
+    (dispatcher2.rs:323, 327-328, 356, 361, 533, 543, 555, 634).  Use as the `challenge` argument of Prover.prove*."""
+
+    def __init__(self, transcript: PlonkTranscript):
+        self.t = transcript
+        self.drawn: Dict[str, np.ndarray] = {}
+
+    def __call__(self, label: str, proof: dict) -> np.ndarray:
+        t = self.t
+        if label == "beta":
+            t.append_commitments(b"witness_poly_comms", proof["wires_poly_comms"])
+        elif label == "alpha":
+            t.append_commitment(b"perm_poly_comms", proof["prod_perm_poly_comm"])
+        elif label == "zeta":
+            t.append_commitments(b"quot_poly_comms", proof["split_quot_poly_comms"])
+        elif label == "v":
+            t.append_proof_evaluations(proof["wires_evals"], proof["wire_sigma_evals"], proof["perm_next_eval"])
+        c = t.get_and_append_challenge(label.encode())
+        self.drawn[label] = c
+        return c
 
 
 class Prover:
@@ -80,7 +104,7 @@ class Prover:
         n, m = self.n, self.m
         k = np.ascontiguousarray(k, dtype=np.uint64)
         assert len(sel_ptrs) == NUM_SELECTORS and len(sig_ptrs) == NUM_WIRE_TYPES and k.shape == (NUM_WIRE_TYPES, 4)
-        self._key = dict(sel=[int(x) for x in sel_ptrs], sig=[int(x) for x in sig_ptrs], k=k, cos=None)
+        self._key = dict(sel=[int(x) for x in sel_ptrs], sig=[int(x) for x in sig_ptrs], k=k, cos=None, vk=None)
         if self.cache_key_cosets:
             cos = self._alloc(18 * m)
             tmp = self._alloc(m)
@@ -89,6 +113,24 @@ class Prover:
                 self._coset_fft(src, n, tmp.ptr, ptrs[j])
             self._free([tmp])
             self._key["cos"] = ptrs
+
+    def verifying_key(self) -> dict:
+        """The parts of jf-plonk's VerifyingKey the transcript absorbs (dispatcher2.rs:56-91): commitments of the 13 selector
+        and 5 sigma polynomials (18 MSMs, computed once per key)."""
+        key = self._key
+        if key["vk"] is None:
+            key["vk"] = dict(domain_size=self.n, k=key["k"], selector_comms=[self._commit(ptr, self.n) for ptr in key["sel"]],
+                             sigma_comms=[self._commit(ptr, self.n) for ptr in key["sig"]])
+        return key["vk"]
+
+    def fiat_shamir(self, public_inputs: np.ndarray) -> FiatShamir:
+        """A fresh transcript with the verifying key and the public inputs absorbed (dispatcher2.rs:238-241).
+        public_inputs: (num_inputs, 4) — `circuit.public_input()`, NOT padded to n."""
+        vk = self.verifying_key()
+        t = PlonkTranscript(self.w.curve_name)
+        pi = np.ascontiguousarray(public_inputs, dtype=np.uint64).reshape(-1, 4)
+        t.append_vk_and_pub_input(vk["domain_size"], pi.shape[0], list(vk["k"]), vk["selector_comms"], vk["sigma_comms"], list(pi))
+        return FiatShamir(t)
 
     # ------------------------------------------------------------------ building blocks
     def _coset_fft(self, d_src: int, length: int, d_tmp: int, d_dst: int):

@@ -71,3 +71,45 @@ def test_prover_rejects_unsatisfied_circuit(gpu_workers, oracle):
         pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
     finally:
         pv.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_prover_with_real_transcript(gpu_workers, oracle, curve, cid):
+    """challenges drawn from the merlin transcript exactly where dispatcher2.rs draws them.  The proof
+    must be reproducible, and the oracle prover fed with the drawn challenges must agree on every output (so the
+    transcript absorbed identical bytes on both sides)."""
+    from distributed_plonk_amd.prover import FiatShamir
+    log_n = 7
+    P, circ, ck, inf, bl, _ = _instance(oracle, cid, log_n, 300)
+    n = 1 << log_n
+    w = gpu_workers(curve)
+    w.init(ck, n, 8 * n)
+    pv = Prover(w, log_n)
+    try:
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        runs = []
+        for _ in range(2):
+            fs = pv.fiat_shamir(circ["pub_input"][:2])
+            runs.append((pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs), fs.drawn))
+        (got, ch), (got2, ch2) = runs
+        assert set(ch) == {"beta", "gamma", "alpha", "zeta", "v"}
+        for k in ch:
+            assert np.array_equal(ch[k], ch2[k])
+        assert _same_point(got["opening_proof"], got2["opening_proof"])
+        # verifying-key commitments the transcript absorbed == oracle commitments of the same polynomials
+        vk = pv.verifying_key()
+        for j in (0, 12):
+            want = oracle.jac_to_affine(cid, oracle.commit_polynomial(cid, ck, circ["selectors"][j], inf=inf, threads=8))
+            assert _same_point(vk["selector_comms"][j], want)
+        want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=8)
+        for key in ("wires_poly_comms", "split_quot_poly_comms"):
+            for g, x in zip(got[key], want[key]):
+                assert _same_point(g, x), key
+        for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+            assert _same_point(got[key], want[key]), key
+        assert np.array_equal(np.stack(got["wires_evals"]), np.stack(want["wires_evals"]))
+        # a different public input changes every challenge
+        fs3 = pv.fiat_shamir(circ["pub_input"][:1])
+        assert not np.array_equal(fs3("beta", got), ch["beta"])
+    finally:
+        pv.close()
