@@ -218,16 +218,24 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
 // One lane owns one bucket, so a wave runs as long as its fullest bucket.  A counting sort of the bucket
 // ids by (clamped) size, largest first, puts equally loaded buckets in the same wave.
 #define SIZE_BINS 256
-__device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint64_t b) {
-    const uint32_t sz = offsets[b + 1] - offsets[b];
+// Merged mode (fixed-base window table, see msm_table_kernel): bucket b collects the segments (w, b) of all Wm windows.
+__device__ __forceinline__ uint32_t bucket_entries(const uint32_t* offsets, uint64_t b, uint64_t nb, uint32_t Wm) {
+    uint32_t sz = 0;
+    for (uint32_t w = 0; w < Wm; w++) sz += offsets[w * nb + b + 1] - offsets[w * nb + b];
+    return sz;
+}
+__device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint64_t b, uint64_t nb, uint32_t Wm) {
+    // merged buckets hold ~Wm times more entries: bin by entries / 4 so the 256 bins still resolve them
+    const uint32_t sz = Wm > 1 ? bucket_entries(offsets, b, nb, Wm) >> 2 : offsets[b + 1] - offsets[b];
     return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
 }
-__global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint32_t* __restrict__ ghist) {
+__global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint64_t nb, uint32_t Wm,
+                                                               uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[SIZE_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbuckets) atomicAdd(&h[size_bin(offsets, b)], 1u);
+    if (b < nbuckets) atomicAdd(&h[size_bin(offsets, b, nb, Wm)], 1u);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
@@ -244,15 +252,15 @@ __global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint3
     }
     bin_cursor[threadIdx.x] = buf[threadIdx.x] - v;
 }
-__global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint32_t* __restrict__ bin_cursor,
-                                                                uint32_t* __restrict__ order) {
+__global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint64_t nb, uint32_t Wm,
+                                                                uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order) {
     __shared__ uint32_t h[SIZE_BINS];
     __shared__ uint32_t base[SIZE_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bin = 0, rank = 0;
-    if (b < nbuckets) { bin = size_bin(offsets, b); rank = atomicAdd(&h[bin], 1u); }
+    if (b < nbuckets) { bin = size_bin(offsets, b, nb, Wm); rank = atomicAdd(&h[bin], 1u); }
     __syncthreads();
     if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
@@ -387,8 +395,8 @@ __device__ __forceinline__ void store_std(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ order, uint64_t nbuckets,
-                                                             XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
+                                                             const uint32_t* __restrict__ order, uint64_t nbuckets, uint64_t nb, uint32_t Wm, uint64_t tab_stride,
+                                                             uint32_t heavy_thresh, XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
                                                              uint32_t* __restrict__ redo_list, uint32_t* __restrict__ heavy_count,
                                                              uint32_t* __restrict__ heavy_list,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
@@ -396,19 +404,22 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nbuckets) return;
     const uint32_t b = order[i];
-    const uint32_t beg = offsets[b], end = offsets[b + 1];
-    if (end - beg > HEAVY_BUCKET) {              // skewed scalars / a nearly empty top window: one lane must not walk it alone
+    if (bucket_entries(offsets, b, nb, Wm) > heavy_thresh) {   // skewed scalars / a nearly empty top window: one lane must not walk it alone
         heavy_list[atomicAdd(heavy_count, 1u)] = b;
         return;
     }
     XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
     bool ok = true;
-    for (uint32_t j = beg; j < end; j++) {
-        const uint32_t e = sorted[j];
-        AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
-        if (affl_is_inf(q)) continue;
-        if (e >> 31) q = affl_neg(q, P);
-        if (!xyzzl_madd_fast(acc, q, P)) { ok = false; break; }
+    for (uint32_t w = 0; w < Wm && ok; w++) {                    // Wm == 1 unless the fixed-base table is in use
+        const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
+        const AffL<NL, B>* tb = bases + w * tab_stride;          // 2^(c*w) * P_i
+        for (uint32_t j = beg; j < end; j++) {
+            const uint32_t e = sorted[j];
+            AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+            if (affl_is_inf(q)) continue;
+            if (e >> 31) q = affl_neg(q, P);
+            if (!xyzzl_madd_fast(acc, q, P)) { ok = false; break; }
+        }
     }
     if (ok) store8(buckets + b, acc);
     else redo_list[atomicAdd(redo_count, 1u)] = b;
@@ -419,6 +430,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                         const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                        uint64_t nb, uint32_t Wm, uint64_t tab_stride,
                                                         const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
                                                         XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
                                                         const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
@@ -428,14 +440,17 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>:
     const uint32_t total = *heavy_count, seg = blockIdx.y;
     for (uint32_t h = blockIdx.x; h < total; h += gridDim.x) {
         const uint32_t b = heavy_list[h];
-        const uint32_t beg = offsets[b], end = offsets[b + 1];
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-        for (uint32_t j = beg + seg * blockDim.x + threadIdx.x; j < end; j += HEAVY_SEGS * blockDim.x) {
-            const uint32_t e = sorted[j];
-            AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
-            if (affl_is_inf(q)) continue;                // before negating: affl_neg would turn (0,0) into (0, 2p)
-            if (e >> 31) q = affl_neg(q, P);
-            acc = xyzzl_madd(acc, q, P);
+        for (uint32_t w = 0; w < Wm; w++) {
+            const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
+            const AffL<NL, B>* tb = bases + w * tab_stride;
+            for (uint32_t j = beg + seg * blockDim.x + threadIdx.x; j < end; j += HEAVY_SEGS * blockDim.x) {
+                const uint32_t e = sorted[j];
+                AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                if (affl_is_inf(q)) continue;            // before negating: affl_neg would turn (0,0) into (0, 2p)
+                if (e >> 31) q = affl_neg(q, P);
+                acc = xyzzl_madd(acc, q, P);
+            }
         }
         __syncthreads();
         sh[threadIdx.x] = acc;
@@ -468,6 +483,7 @@ __global__ void __launch_bounds__(64) msm_heavy_finish_kernel(const uint32_t* __
 template <int NQ>
 __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
+                                                                 uint64_t nb, uint32_t Wm, uint64_t tab_stride,
                                                                  XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
                                                                  const uint32_t* __restrict__ redo_list,
                                                                  const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
@@ -475,14 +491,17 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
     const uint32_t total = *redo_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t b = redo_list[i];
-        const uint32_t beg = offsets[b], end = offsets[b + 1];
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-        for (uint32_t j = beg; j < end; j++) {
-            const uint32_t e = sorted[j];
-            AffL<NL, B> q = load8(bases + (e & 0x7fffffffu));
-            if (affl_is_inf(q)) continue;
-            if (e >> 31) q = affl_neg(q, P);
-            acc = xyzzl_madd(acc, q, P);
+        for (uint32_t w = 0; w < Wm; w++) {
+            const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
+            const AffL<NL, B>* tb = bases + w * tab_stride;
+            for (uint32_t j = beg; j < end; j++) {
+                const uint32_t e = sorted[j];
+                AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                if (affl_is_inf(q)) continue;
+                if (e >> 31) q = affl_neg(q, P);
+                acc = xyzzl_madd(acc, q, P);
+            }
         }
         store8(buckets + b, acc);
     }
@@ -621,6 +640,39 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
     return PLONK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- fixed-base window table
+// The SRS is fixed between `init` calls (worker.rs:141), so the shifted copies T[w][i] = 2^(c*w) * P_i can be built once
+// and kept resident (W x 72 B per point: 15.7 GB for 2^24 BN254 points at c = 20 — 288 GB of HBM make this cheap).
+// With them every (point, window) digit lands in ONE bucket set of 2^(c-1) buckets instead of one set per window: the
+// window reduction shrinks W-fold, which moves the optimum to a wider window (c = 20, W = 13 instead of c = 16, W = 16
+// at 2^24) and removes ~19 % of the mixed additions and of the sort.  Lane i walks its point through the W-1 shifts:
+// c doublings (lazy XYZZ), one Fermat inversion, back to the canonical affine limb form the accumulate kernel reads.
+template <int NQ>
+__global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ table, uint64_t n, uint64_t stride, int c, int W,
+                                                       const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
+                                                       const FL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> pm2 /* p - 2, limb form */) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    AffL<NL, B> q = load8(table + i);
+    for (int w = 1; w < W; w++) {
+        if (!affl_is_inf(q)) {
+            XyzzL<NL, B> a = xyzzl_dbl_affine(q, P);
+            for (int k = 1; k < c; k++) a = xyzzl_dbl(a, P);
+            // 1 / ZZZ by Fermat; 1/Z = ZZ / ZZZ; x = X / Z^2, y = Y / ZZZ   (an infinity gives 0 -> (0, 0) = infinity)
+            FL<NL, B> inv = fl_load_const<NL, B>(P.one);
+            for (int bit = NL * B - 1; bit >= 0; bit--) {
+                inv = fl_sqr(inv, P);
+                if ((pm2.l[bit / B] >> (bit % B)) & 1) inv = fl_mul(inv, a.zzz, P);
+            }
+            const FL<NL, B> u = fl_mul(a.zz, inv, P);
+            q.x = fl_canon_lt2p(fl_mul(a.x, fl_sqr(u, P), P), P);
+            q.y = fl_canon_lt2p(fl_mul(a.y, inv, P), P);
+        }
+        store8(table + (uint64_t)w * stride + i, q);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host orchestration
 // level-1 partition bits of the sort for (cb, n); returns false when the packed 32-bit entry cannot hold it
 static bool sort_geometry(int cb, size_t n, int* lp_out, int* idx_bits_out) {
@@ -634,21 +686,64 @@ static bool sort_geometry(int cb, size_t n, int* lp_out, int* idx_bits_out) {
 }
 
 static double g_reduce_cost = 2.7 * 3300.0 * 2.0;     // VALU instructions per bucket in the reduction pyramid (x2: it runs at lower occupancy)
-static int choose_window(size_t n, int bits) {
-    // measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
-    // addition; the reduction pyramid does ~2.7 full additions per bucket
+// measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
+// addition; the reduction pyramid does ~2.7 full additions per bucket
+static bool window_usable(size_t n, int bits, int c) {
+    int lp, ib;
+    if (!sort_geometry(c - 1, n, &lp, &ib)) return false;
+    const int W = (bits + 1 + c - 1) / c;
+    const int top_bits = bits - (W - 1) * c;                   // entropy of the last window's digit
+    return !(W > 1 && top_bits < std::min(c - 3, 8));          // a near-empty top window puts every point in a few buckets
+}
+static double window_cost(size_t n, int bits, int c, bool table) {
+    const int W = (bits + 1 + c - 1) / c;
+    return (double)W * (double)n * 2480.0 + (table ? 1.0 : (double)W) * (double)((size_t)1 << (c - 1)) * g_reduce_cost;
+}
+static int choose_window(size_t n, int bits, bool table = false, double* cost_out = nullptr) {
     double best = 1e300;
     int bc = 4;
-    for (int c = 4; c <= 20; c++) {
-        int lp, ib;
-        if (!sort_geometry(c - 1, n, &lp, &ib)) continue;
-        const int W = (bits + 1 + c - 1) / c;
-        const int top_bits = bits - (W - 1) * c;               // entropy of the last window's digit
-        if (W > 1 && top_bits < std::min(c - 3, 8)) continue;  // a near-empty top window puts every point in a few buckets
-        const double cost = (double)W * ((double)n * 2480.0 + (double)((size_t)1 << (c - 1)) * g_reduce_cost);
+    for (int c = 4; c <= (table ? 21 : 20); c++) {
+        if (!window_usable(n, bits, c)) continue;
+        const double cost = window_cost(n, bits, c, table);
         if (cost < best) { best = cost; bc = c; }
     }
+    if (cost_out) *cost_out = best;
     return bc;
+}
+
+// Window width of the fixed-base table for an SRS of n points, 0 = no table (too small to pay off, or over budget)
+int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out) {
+    *W_out = 1;
+    if (mode == 0 || n == 0) return 0;
+    const int bits = fr_params(curve).bits;
+    double plain = 0, tab = 0;
+    choose_window(n, bits, false, &plain);
+    const int c = choose_window(n, bits, true, &tab);
+    const int W = (bits + 1 + c - 1) / c;
+    if (W < 2) return 0;
+    if (mode == 1 && (n < ((size_t)1 << 16) || tab > 0.93 * plain)) return 0;
+    if ((double)W * (double)n * (double)msm_limb_base_bytes(curve) > (double)budget_bytes) return 0;
+    *W_out = W;
+    return c;
+}
+
+template <int NQ> static int msm_table_build_t(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    Fp<NQ> pm2;
+    uint64_t br = 2;
+    for (int i = 0; i < NQ; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
+    hipLaunchKernelGGL(msm_table_kernel<NQ>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, stream, (AffL<NL, B>*)d_table, (uint64_t)n, (uint64_t)stride, c, W,
+                       fl_params<NQ>(curve), fl_from_sat<NL, B, NQ>(pm2));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm_table launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+// d_table: W planes of `stride` points, plane 0 already holds the bases (bases_to_limbs)
+int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream) {
+    if (n == 0 || W < 2) return PLONK_OK;
+    if (curve == PLONK_BN254) return msm_table_build_t<8>(curve, d_table, n, stride, c, W, stream);
+    return msm_table_build_t<12>(curve, d_table, n, stride, c, W, stream);
 }
 
 static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
@@ -664,13 +759,28 @@ static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int NQ>
 static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
-                     int window_bits, hipStream_t stream) {
+                     int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
-    const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits);
+    // fixed-base table: use it when its window beats the best per-window plan for THIS n (small sub-ranges do not)
+    bool merged = false;
+    if (window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
+        double plain = 0;
+        choose_window(n, bits, false, &plain);
+        merged = window_cost(n, bits, tab.c, true) < plain;
+    }
+    const int c = merged ? tab.c : (window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits));
     const int W = (bits + 1 + c - 1) / c;              // signed digits: one spare bit for the last carry
+    if (merged && W != tab.W) return plonk_fail(PLONK_ERR_STATE, "msm: table built for %d windows, plan has %d", tab.W, W);
     const int cb = c - 1;                              // 2^(c-1) buckets per window
-    const uint64_t nb = (uint64_t)1 << cb, nbuckets = (uint64_t)W * nb;
+    const uint64_t nb = (uint64_t)1 << cb;
+    const uint32_t Wm = merged ? (uint32_t)W : 1u;     // windows merged into one bucket set
+    const int Wr = merged ? 1 : W;                     // bucket sets left to reduce
+    const uint64_t nsub = (uint64_t)W * nb;            // (window, bucket) segments the sort produces
+    const uint64_t nbuckets = (uint64_t)Wr * nb;       // accumulators
+    const uint64_t tab_stride = merged ? tab.stride : 0;
+    const uint64_t avg = ((uint64_t)n * W) / nbuckets + 1;
+    const uint32_t heavy_thresh = (uint32_t)std::max<uint64_t>(HEAVY_BUCKET, 4 * avg);
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
     SortGeom g;
     g.n = n; g.W = W; g.cb = cb;
@@ -686,13 +796,13 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_tmp = off; off = align_up(off + (size_t)n * W * 4, 256);
     const size_t o_hist = off; off = align_up(off + (nhist + 1) * 4, 256);
     const size_t o_hoff = off; off = align_up(off + (nhist + 1) * 4, 256);
-    const size_t o_offsets = off; off = align_up(off + (nbuckets + 1) * 4, 256);
+    const size_t o_offsets = off; off = align_up(off + (nsub + 1) * 4, 256);
     const size_t o_bsums = off; off = align_up(off + (nscan_blocks + 1) * 4, 256);
     const size_t o_sorted = off; off = align_up(off + (size_t)n * W * 4, 256);
     const size_t o_order = off; off = align_up(off + nbuckets * 4, 256);
     const size_t o_redo = off; off = align_up(off + (nbuckets + 1) * 4, 256);
     const size_t o_szh = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
-    const uint64_t max_heavy = ((uint64_t)n * W) / HEAVY_BUCKET + 1;     // a bucket is heavy only above HEAVY_BUCKET entries
+    const uint64_t max_heavy = ((uint64_t)n * W) / heavy_thresh + 1;     // a bucket is heavy only above heavy_thresh entries
     const size_t o_heavy = off; off = align_up(off + (max_heavy + 1) * 4, 256);
     typedef XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> BucketL;
     // reduction pyramid geometry
@@ -705,11 +815,11 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         cur = lev_nch[nlev];
     }
     uint64_t pyr = 0;
-    for (int l = 0; l < nlev; l++) pyr += (uint64_t)W * lev_nch[l];
+    for (int l = 0; l < nlev; l++) pyr += (uint64_t)Wr * lev_nch[l];
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(BucketL), 256);
     const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
-    const size_t o_wsum = off; off = align_up(off + (size_t)W * (nlev + 1) * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * sizeof(XyzzPt<NQ>), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
@@ -755,19 +865,19 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
     HIP_TRY(hipMemsetAsync(heavy, 0, 4, stream));
     const uint32_t bgrid = (uint32_t)((nbuckets + 255) / 256);
-    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, ghist);
+    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, ghist);
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
-    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, bin_cursor, order); }
+    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, bin_cursor, order); }
     { ProfScope ps("msm_accumulate_kernel", stream);
     hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                       nbuckets, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
+                       nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_heavy", stream);
-    hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, heavy, heavy + 1,
-                       hpart, fl_params<NQ>(curve));
+    hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, nb, Wm, tab_stride,
+                       heavy, heavy + 1, hpart, fl_params<NQ>(curve));
     hipLaunchKernelGGL(msm_heavy_finish_kernel<NQ>, dim3(16), dim3(64), 0, stream, heavy, heavy + 1, hpart, buckets, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_accumulate_redo_kernel", stream);
-    hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, buckets, redo, redo + 1,
-                       fl_params<NQ>(curve)); }
+    hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, nb, Wm, tab_stride, buckets, redo,
+                       redo + 1, fl_params<NQ>(curve)); }
     {
         ProfScope ps("msm_reduce", stream);
         SumJobs jobs;
@@ -775,7 +885,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         const BucketL* in = buckets;
         uint64_t at = 0;
         for (int l = 0; l < nlev; l++) {
-            const uint64_t total_chunks = (uint64_t)W * lev_nch[l];
+            const uint64_t total_chunks = (uint64_t)Wr * lev_nch[l];
             HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));          // the accumulate redo list is dead by now: reuse it per level
             hipLaunchKernelGGL(msm_reduce_level_kernel<NQ>, dim3((uint32_t)((total_chunks + 255) / 256)), dim3(256), 0, stream, in, lev_n[l],
                                (uint32_t)lev_k[l], lev_nch[l], total_chunks, acc_arr + at, s_arr + at, redo, redo + 1, fl_params<NQ>(curve));
@@ -788,17 +898,17 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         }
         jobs.src[nlev] = in;            // the single entry left per window: Sigma (nb == 1: the bucket itself)
         jobs.count[nlev] = 1;
-        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, W), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
+        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
                            fl_params<NQ>(curve));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
 
-    std::vector<XyzzPt<NQ>> h((size_t)W * (nlev + 1));
+    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1));
     HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     XyzzPt<NQ> total = xyzz_inf<NQ>();
-    for (int w = W - 1; w >= 0; w--) {
+    for (int w = Wr - 1; w >= 0; w--) {
         // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
         const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1);
         XyzzPt<NQ> v = xyzz_inf<NQ>();
@@ -818,14 +928,14 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
 
 template <int NQ>
 static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
-                     hipStream_t stream) {
+                     const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     const size_t SLICE = (size_t)1 << 26;
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
         XyzzPt<NQ> part;
-        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, stream);
+        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, tab, stream);
         if (rc) return rc;
         total = xyzz_add(total, part, P);
     }
@@ -835,9 +945,9 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, 
 }
 
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
-            hipStream_t stream) {
-    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, stream);
-    return msm_run_t<12>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, stream);
+            const MsmTable& tab, hipStream_t stream) {
+    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, tab, stream);
+    return msm_run_t<12>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, tab, stream);
 }
 
 template <int NQ> static void jac_add_host_t(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out) {

@@ -58,8 +58,11 @@ struct plonk_ctx {
     hipStream_t stream = nullptr;
     NttTables tables;
     // SRS (State.bases), kept in the MSM's resident limb form (flimb.cuh)
-    void* d_bases = nullptr;
+    void* d_bases = nullptr;                    // plane 0 of the fixed-base window table (msm_table) when one is built
     size_t n_bases = 0;
+    MsmTable msm_table;
+    int msm_precompute = 1;                     // 0 off, 1 when it pays off (n_bases >= 2^16), 2 always (tests)
+    size_t msm_table_budget = (size_t)64 << 30;
     // domains (State.domain / quot_domain and their r/c splits are derived on demand)
     size_t domain_size = 0, quot_domain_size = 0;
     std::map<uint64_t, FftTask> tasks;          // State.fft_tasks
@@ -186,6 +189,8 @@ extern "C" int plonk_sync(plonk_ctx* ctx) {
 extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
+    if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
+    if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);
 }
@@ -223,6 +228,27 @@ static int set_domains(plonk_ctx* ctx, size_t domain_size, size_t quot_domain_si
     return PLONK_OK;
 }
 
+// SRS -> resident limb form, plus the fixed-base window table when it pays off (one-time work per `init`)
+static int install_bases(plonk_ctx* ctx, const void* d_xy, size_t n_bases) {
+    int W = 1;
+    const int c = msm_table_plan(ctx->curve, n_bases, ctx->msm_precompute, ctx->msm_table_budget, &W);
+    const size_t pb = msm_limb_base_bytes(ctx->curve);
+    if (hipMalloc(&ctx->d_bases, n_bases * pb * (size_t)W) != hipSuccess) {
+        (void)hipGetLastError();
+        W = 1;                                  // no room for the table: plain bases
+        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * pb));
+    }
+    int rc = bases_to_limbs(ctx->curve, d_xy, n_bases, ctx->d_bases, ctx->stream);
+    ctx->msm_table = MsmTable();
+    if (!rc && W > 1) {
+        rc = msm_table_build(ctx->curve, ctx->d_bases, n_bases, n_bases, c, W, ctx->stream);
+        ctx->msm_table.c = c; ctx->msm_table.W = W; ctx->msm_table.stride = n_bases;
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (!rc) ctx->n_bases = n_bases;
+    return rc;
+}
+
 extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int base_layout, size_t domain_size, size_t quot_domain_size) {
     CHECK_CTX(ctx);
     if (n_bases && !bases) return plonk_fail(PLONK_ERR_ARG, "plonk_init: null bases");
@@ -230,7 +256,7 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
     if (ctx->d_bases) hipFree(ctx->d_bases);
-    ctx->d_bases = nullptr; ctx->n_bases = 0;
+    ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
         const size_t ab = aff_bytes(ctx->curve);
         void* d_xy = nullptr;
@@ -243,12 +269,9 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
             HIP_TRY(hipMemcpyAsync(ctx->d_scratch, bases, rb, hipMemcpyHostToDevice, ctx->stream));
             if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy, ctx->stream))) return rc;
         }
-        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * msm_limb_base_bytes(ctx->curve)));
-        rc = bases_to_limbs(ctx->curve, d_xy, n_bases, ctx->d_bases, ctx->stream);
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        rc = install_bases(ctx, d_xy, n_bases);
         (void)hipFree(d_xy);
         if (rc) return rc;
-        ctx->n_bases = n_bases;
     }
     return PLONK_OK;
 }
@@ -259,12 +282,9 @@ extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_b
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
     if (ctx->d_bases) hipFree(ctx->d_bases);
-    ctx->d_bases = nullptr; ctx->n_bases = 0;
+    ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
-        HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * msm_limb_base_bytes(ctx->curve)));
-        if ((rc = bases_to_limbs(ctx->curve, d_bases_xy, n_bases, ctx->d_bases, ctx->stream))) return rc;
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        ctx->n_bases = n_bases;
+        if ((rc = install_bases(ctx, d_bases_xy, n_bases))) return rc;
     }
     return PLONK_OK;
 }
@@ -278,7 +298,7 @@ static int msm_device(plonk_ctx* ctx, size_t start, size_t n, const uint32_t* d_
     }
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * msm_limb_base_bytes(ctx->curve), d_scalars, n, (uint32_t*)out_jac, ctx->msm_ws,
-                     ctx->msm_window, ctx->stream);
+                     ctx->msm_window, ctx->msm_table, ctx->stream);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     return rc;

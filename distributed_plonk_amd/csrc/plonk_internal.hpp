@@ -110,10 +110,19 @@ struct MsmWorkspace {
     void* d_buf = nullptr;
     size_t bytes = 0;
 };
-// bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point).
+// Fixed-base window table (msm_engine.hip: msm_table_kernel): W planes of `stride` points, plane w = 2^(c*w) * bases.
+struct MsmTable {
+    int c = 0;            // 0 = no table (plane 0 only)
+    int W = 1;
+    uint64_t stride = 0;  // points per plane (= n_bases)
+};
+// bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point); with a table,
+// the pointer addresses plane 0 (+ the range start) and the other planes follow at multiples of tab.stride.
 // scalars: device, canonical 8xu32.  out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac,
-            MsmWorkspace& ws, int window_bits, hipStream_t stream);
+            MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream);
+int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out);
+int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream);
 int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);
 int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf);
 int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream);
