@@ -99,10 +99,16 @@ __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restr
 // its exact range).  Level 2 sorts one partition per workgroup with LDS counters; its ~64 KiB of entries stay
 // in L2.  Replaces a histogram + scatter pair that issued one HBM atomic and one 4-byte random store per
 // (point, window) — 16x write amplification once n*W*4 B outgrows the 256 MiB Infinity Cache.
-#define SORT_SLICE 16384          // entries per level-1 workgroup
+#define SORT_SLICE_LOG 14
+#define SORT_SLICE (1 << SORT_SLICE_LOG)      // entries per level-1 workgroup
+// A level-1 entry is  bucket_low << 15 | sign << 14 | (point index - slice start): the slice number is not stored, the
+// level-2 workgroup recovers it from the entry's position (its partition is the concatenation of one run per slice,
+// whose boundaries are the scanned histogram).  This keeps 2^10 level-1 partitions — 16-entry contiguous runs per
+// (slice, partition) — for every window width; packing the full point index used to force 2^12 partitions (4-entry runs,
+// sort 5.7 -> 10 ms) once c reached 20.
 struct SortGeom {
     uint64_t n;
-    int W, cb, lp, low_bits, idx_bits;
+    int W, cb, lp, low_bits;
     uint32_t nblk;               // slices per window
     uint32_t nreal;              // W << lp : real partitions; the W "digit == 0" partitions follow them
 };
@@ -173,7 +179,7 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __res
         if (!mag) continue;
         const uint32_t key = mag - 1;
         const uint32_t pos = atomicAdd(&cnt[key >> g.low_bits], 1u);
-        buf[pos] = ((key & low_mask) << (g.idx_bits + 1)) | ((e >> 31) << g.idx_bits) | (uint32_t)i;
+        buf[pos] = ((key & low_mask) << (SORT_SLICE_LOG + 1)) | ((e >> 31) << SORT_SLICE_LOG) | (uint32_t)(i - beg);
     }
     __syncthreads();
     // copy out: position j of the ordered slice belongs to the partition whose [loc[k], loc[k+1]) contains it
@@ -189,13 +195,17 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __res
 // one workgroup per real partition: final order + bucket offsets
 __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                              uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
-    extern __shared__ uint32_t cnt[];          // [2^low_bits] counts -> cursors
+    extern __shared__ uint32_t lds[];
     const uint32_t nlow = 1u << g.low_bits;
+    uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors
+    uint32_t* run0 = lds + nlow;               // [nblk] start of every slice's run inside this partition
     const uint64_t pid = blockIdx.x;
-    const uint32_t pbeg = blk_off[pid * g.nblk], pend = blk_off[(pid + 1) * g.nblk];
+    const uint32_t* po = blk_off + pid * g.nblk;
+    const uint32_t pbeg = po[0], pend = po[g.nblk];
     for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) cnt[k] = 0;
+    for (uint32_t k = threadIdx.x; k < g.nblk; k += blockDim.x) run0[k] = po[k];
     __syncthreads();
-    const int sh = g.idx_bits + 1;
+    const int sh = SORT_SLICE_LOG + 1;
     for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) atomicAdd(&cnt[tmp[j] >> sh], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {                    // nlow <= 2048: a serial exclusive scan is negligible
@@ -206,11 +216,18 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
     for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) offsets[(pid << g.low_bits) + k] = cnt[k];
     if (pid == g.nreal - 1 && threadIdx.x == 0) offsets[(uint64_t)g.nreal << g.low_bits] = pend;      // end sentinel
     __syncthreads();
-    const uint32_t idx_mask = (1u << g.idx_bits) - 1;
+    const uint32_t in_mask = SORT_SLICE - 1;
+    // Final placement: direct 4-byte scatter into the partition's 2^low_bits bucket runs.  Fine while the open runs of the
+    // workgroups in flight fit the write-combining reach of L1/L2 (c <= 17 at 2^24: 1.5 ms); at c = 20 (512 runs per
+    // partition) it costs 6.3 ms.  Ordering the partition in LDS first was measured and rejected: 64 KiB of staging per
+    // workgroup leaves one workgroup per CU (7.3 ms), and 4096-entry partitions that would stage in 16 KiB double the
+    // level-1 kernels instead (profiles/r01_msm_table_experiment.txt).
     for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
         const uint32_t e = tmp[j];
+        uint32_t lo = 0, hi = g.nblk;          // slice = largest b with run0[b] <= j
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run0[mid] <= j) lo = mid; else hi = mid; }
         const uint32_t pos = atomicAdd(&cnt[e >> sh], 1u);
-        sorted[pos] = (e & idx_mask) | (((e >> g.idx_bits) & 1u) << 31);
+        sorted[pos] = ((lo << SORT_SLICE_LOG) + (e & in_mask)) | (((e >> SORT_SLICE_LOG) & 1u) << 31);
     }
 }
 
@@ -571,17 +588,18 @@ struct SumJobs {
     const void* src[16];
     uint64_t count[16];
 };
+#define SUM_SPLIT 16      // workgroups per (level, window) sum: a merged bucket set has 2^17 level-0 values and only one window
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
-    const uint32_t l = blockIdx.x, w = blockIdx.y;
+    const uint32_t l = blockIdx.x, w = blockIdx.y, z = blockIdx.z;
     const uint64_t cnt = jobs.count[l];
     const XyzzL<NL, B>* src = reinterpret_cast<const XyzzL<NL, B>*>(jobs.src[l]) + (uint64_t)w * cnt;
     XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-    for (uint64_t i = threadIdx.x; i < cnt; i += blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
+    for (uint64_t i = (uint64_t)z * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)SUM_SPLIT * blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int d = blockDim.x / 2; d > 0; d >>= 1) {
@@ -591,7 +609,7 @@ __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzP
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_std<NQ>(out + (uint64_t)w * nlevels + l, sh[0], P);
+    if (threadIdx.x == 0) store_std<NQ>(out + ((uint64_t)w * nlevels + l) * SUM_SPLIT + z, sh[0], P);
 }
 
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
@@ -644,9 +662,14 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 // The SRS is fixed between `init` calls (worker.rs:141), so the shifted copies T[w][i] = 2^(c*w) * P_i can be built once
 // and kept resident (W x 72 B per point: 15.7 GB for 2^24 BN254 points at c = 20 — 288 GB of HBM make this cheap).
 // With them every (point, window) digit lands in ONE bucket set of 2^(c-1) buckets instead of one set per window: the
-// window reduction shrinks W-fold, which moves the optimum to a wider window (c = 20, W = 13 instead of c = 16, W = 16
-// at 2^24) and removes ~19 % of the mixed additions and of the sort.  Lane i walks its point through the W-1 shifts:
-// c doublings (lazy XYZZ), one Fermat inversion, back to the canonical affine limb form the accumulate kernel reads.
+// window reduction shrinks W-fold, which moves the optimum to a wider window (c = 20, W = 13 instead of c = 17, W = 15
+// at 2^24).  Lane i walks its point through the W-1 shifts: c doublings (lazy XYZZ), one Fermat inversion, back to the
+// canonical affine limb form the accumulate kernel reads.
+// MEASURED (MI355X, 2^24 BN254, profiles/r01_msm_table_experiment.txt): OFF by default.  The mixed additions drop as
+// predicted, but gathering 72-byte points from a 15.7 GB table instead of the 1.2 GB one costs more than it saves
+// (accumulate 23.8 ms merged vs 17.8 ms for the same window over plane 0 only: the per-window bucket sets of the plain
+// path keep the gathers of the waves in flight inside one 1.2 GB plane, which the translation/cache hierarchy covers).
+// Kept as an option (`msm_precompute`), exercised by tests/test_gpu_msm_table.py.
 template <int NQ>
 __global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ table, uint64_t n, uint64_t stride, int c, int W,
                                                        const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
@@ -674,14 +697,12 @@ __global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, Li
 }
 
 // ---------------------------------------------------------------------------------------------- host orchestration
-// level-1 partition bits of the sort for (cb, n); returns false when the packed 32-bit entry cannot hold it
-static bool sort_geometry(int cb, size_t n, int* lp_out, int* idx_bits_out) {
-    int idx_bits = 1;
-    while (((uint64_t)1 << idx_bits) < n) idx_bits++;
-    const int lp = std::min(cb, std::max(std::min(cb, 10), cb + idx_bits + 1 - 32));
-    if (lp > 13 || cb - lp > 11) return false;
+// level-1 partition bits of the sort for 2^cb buckets per window: 2^10 partitions (16-entry runs per 16384-entry slice, two
+// level-1 workgroups per CU), more only when a level-2 workgroup would otherwise own more than 2^11 buckets.
+static bool sort_geometry(int cb, size_t n, int* lp_out) {
+    const int lp = std::max(std::min(cb, 10), cb - 11);
+    if (lp > 13 || n > ((size_t)1 << 27)) return false;        // 2^13 + 1 level-1 bins; <= 8192 slice offsets in the level-2 LDS
     *lp_out = lp;
-    *idx_bits_out = idx_bits;
     return true;
 }
 
@@ -689,8 +710,8 @@ static double g_reduce_cost = 2.7 * 3300.0 * 2.0;     // VALU instructions per b
 // measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
 // addition; the reduction pyramid does ~2.7 full additions per bucket
 static bool window_usable(size_t n, int bits, int c) {
-    int lp, ib;
-    if (!sort_geometry(c - 1, n, &lp, &ib)) return false;
+    int lp;
+    if (!sort_geometry(c - 1, n, &lp)) return false;
     const int W = (bits + 1 + c - 1) / c;
     const int top_bits = bits - (W - 1) * c;                   // entropy of the last window's digit
     return !(W > 1 && top_bits < std::min(c - 3, 8));          // a near-empty top window puts every point in a few buckets
@@ -718,7 +739,12 @@ int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_ou
     const int bits = fr_params(curve).bits;
     double plain = 0, tab = 0;
     choose_window(n, bits, false, &plain);
-    const int c = choose_window(n, bits, true, &tab);
+    int c = choose_window(n, bits, true, &tab);
+    if (const char* ov = getenv("PLONK_MSM_TAB_C")) {          // tuning override (experiments)
+        const int oc = atoi(ov);
+        if (oc <= 0) return 0;
+        if (window_usable(n, bits, oc)) { c = oc; tab = 0; }
+    }
     const int W = (bits + 1 + c - 1) / c;
     if (W < 2) return 0;
     if (mode == 1 && (n < ((size_t)1 << 16) || tab > 0.93 * plain)) return 0;
@@ -784,7 +810,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
     SortGeom g;
     g.n = n; g.W = W; g.cb = cb;
-    if (!sort_geometry(cb, n, &g.lp, &g.idx_bits)) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
+    if (!sort_geometry(cb, n, &g.lp)) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
     g.low_bits = cb - g.lp;
     g.nblk = (uint32_t)((n + SORT_SLICE - 1) / SORT_SLICE);
     g.nreal = (uint32_t)W << g.lp;
@@ -819,7 +845,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(BucketL), 256);
     const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
-    const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * SUM_SPLIT * sizeof(XyzzPt<NQ>), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
@@ -859,7 +885,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     }
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(256), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
                        blk_off, tmp);
-    hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), ((size_t)1 << g.low_bits) * 4, stream, tmp, g, blk_off, sorted, offsets); }
+    hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets); }
     { ProfScope ps("msm_bucket_order", stream);
     HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
@@ -898,26 +924,31 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         }
         jobs.src[nlev] = in;            // the single entry left per window: Sigma (nb == 1: the bucket itself)
         jobs.count[nlev] = 1;
-        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
+        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr, SUM_SPLIT), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
                            fl_params<NQ>(curve));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
 
-    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1));
+    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * SUM_SPLIT);
     HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     for (int w = Wr - 1; w >= 0; w--) {
         // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
-        const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1);
+        const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1) * SUM_SPLIT;
+        auto part = [&](int l) {                     // the SUM_SPLIT partial sums of (level l, window w)
+            XyzzPt<NQ> t = xyzz_inf<NQ>();
+            for (int z = 0; z < SUM_SPLIT; z++) t = xyzz_add(t, hw[(size_t)l * SUM_SPLIT + z], P);
+            return t;
+        };
         XyzzPt<NQ> v = xyzz_inf<NQ>();
         for (int l = nlev - 1; l >= 0; l--) {
             if (!xyzz_is_inf(v))
                 for (int k = 0; k < REDUCE_LOGK; k++) v = xyzz_dbl(v, P);
-            v = xyzz_add(v, hw[l], P);
+            v = xyzz_add(v, part(l), P);
         }
-        v = xyzz_add(v, hw[nlev], P);
+        v = xyzz_add(v, part(nlev), P);
         if (!xyzz_is_inf(total))
             for (int k = 0; k < c; k++) total = xyzz_dbl(total, P);
         total = xyzz_add(total, v, P);

@@ -61,7 +61,7 @@ struct plonk_ctx {
     void* d_bases = nullptr;                    // plane 0 of the fixed-base window table (msm_table) when one is built
     size_t n_bases = 0;
     MsmTable msm_table;
-    int msm_precompute = 1;                     // 0 off, 1 when it pays off (n_bases >= 2^16), 2 always (tests)
+    int msm_precompute = 0;                     // 0 off (default: measured slower on MI355X), 1 when the cost model likes it, 2 always
     size_t msm_table_budget = (size_t)64 << 30;
     // domains (State.domain / quot_domain and their r/c splits are derived on demand)
     size_t domain_size = 0, quot_domain_size = 0;

@@ -28,7 +28,7 @@ def forced_table(gpu_workers):
 
     yield get
     for w in used:
-        w.set_option("msm_precompute", 1)
+        w.set_option("msm_precompute", 0)
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
@@ -90,5 +90,8 @@ def test_table_on_off_agree_and_forced_window_bypasses_it(forced_table, oracle):
     w.set_option("msm_precompute", 0)
     w.init(bases, 0, 0)
     c = w.var_msm(MsmWorkload(0, n), sc)
+    w.set_option("msm_precompute", 1)                        # cost-model mode: builds the table only when it predicts a gain
+    w.init(bases, 0, 0)
+    assert _affine_eq(w, oracle, 0, w.var_msm(MsmWorkload(0, n), sc), want)
     for got in (a, b, c):
         assert _affine_eq(w, oracle, 0, got, want)

@@ -1,0 +1,26 @@
+"""Time one MSM (commit) at n = 2^LOGN on the GPU with the per-kernel profiler: python tools/msm_only.py [LOGN]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from distributed_plonk_amd.worker import PlonkWorker
+
+log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 24
+n = 1 << log_n
+w = PlonkWorker(curve=os.environ.get("CURVE", "bn254"))
+q = w.q64
+bases = w.alloc(n * 16 * q)
+w.synth_bases(0x5EED, 0, n, bases.ptr)
+t = time.perf_counter(); w.init_dev(bases.ptr, n, 0, 0); w.sync(); print("init ms", (time.perf_counter() - t) * 1e3)
+if os.environ.get("MSM_WINDOW"):
+    w.set_option("msm_window", int(os.environ["MSM_WINDOW"]))
+sc = w.alloc(n * 32)
+w.synth_fr(7, sc.ptr, n)
+w.commit_dev(sc.ptr, n)
+w.profile_enable(True); w.profile_reset()
+t = time.perf_counter()
+for _ in range(3):
+    w.commit_dev(sc.ptr, n)
+w.sync()
+print("commit ms", (time.perf_counter() - t) / 3 * 1e3)
+for k in ("msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_heavy", "msm_accumulate_redo_kernel", "msm_reduce"):
+    ms, cnt = w.profile_get(k)
+    print(f"  {k:28s} {ms / max(cnt, 1):8.3f} ms x {cnt}")
