@@ -774,7 +774,7 @@ int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, in
 
 static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
     if (ws.bytes >= bytes) return PLONK_OK;
-    if (ws.d_buf) hipFree(ws.d_buf);
+    if (ws.d_buf) (void)hipFree(ws.d_buf);
     ws.d_buf = nullptr; ws.bytes = 0;
     HIP_TRY(hipMalloc(&ws.d_buf, bytes));
     ws.bytes = bytes;

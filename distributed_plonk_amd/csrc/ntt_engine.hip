@@ -79,18 +79,18 @@ int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
 
 void ntt_tables_destroy(NttTables& T) {
     for (int d = 0; d < 2; d++) {
-        hipFree(T.tw_small[d]); hipFree(T.tw_lo[d]); hipFree(T.tw_hi[d]); hipFree(T.g_lo[d]); hipFree(T.g_hi[d]);
+        (void)hipFree(T.tw_small[d]); (void)hipFree(T.tw_lo[d]); (void)hipFree(T.tw_hi[d]); (void)hipFree(T.g_lo[d]); (void)hipFree(T.g_hi[d]);
         T.tw_small[d] = T.tw_lo[d] = T.tw_hi[d] = T.g_lo[d] = T.g_hi[d] = nullptr;
     }
-    for (auto& kv : T.tw_lo_scaled) hipFree(kv.second);
+    for (auto& kv : T.tw_lo_scaled) (void)hipFree(kv.second);
     T.tw_lo_scaled.clear();
-    for (auto& kv : T.planes) hipFree(kv.second);
+    for (auto& kv : T.planes) (void)hipFree(kv.second);
     T.planes.clear();
-    for (auto& kv : T.rowtabs) hipFree(kv.second);
+    for (auto& kv : T.rowtabs) (void)hipFree(kv.second);
     T.rowtabs.clear();
     T.plane_bytes = 0;
-    if (T.quot_x_lo) { hipFree(T.quot_x_lo); T.quot_x_lo = nullptr; }
-    for (auto& kv : T.quot_inv_xm1) hipFree(kv.second);
+    if (T.quot_x_lo) { (void)hipFree(T.quot_x_lo); T.quot_x_lo = nullptr; }
+    for (auto& kv : T.quot_inv_xm1) (void)hipFree(kv.second);
     T.quot_inv_xm1.clear();
 }
 

@@ -113,7 +113,7 @@ static int ilog2_exact(size_t n) {
 
 static int ensure_scratch(plonk_ctx* ctx, size_t bytes) {
     if (ctx->scratch_bytes >= bytes) return PLONK_OK;
-    if (ctx->d_scratch) hipFree(ctx->d_scratch);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     ctx->d_scratch = nullptr; ctx->scratch_bytes = 0;
     HIP_TRY(hipMalloc(&ctx->d_scratch, bytes));
     ctx->scratch_bytes = bytes;
@@ -121,7 +121,7 @@ static int ensure_scratch(plonk_ctx* ctx, size_t bytes) {
 }
 static int ensure_scratch2(plonk_ctx* ctx, size_t bytes) {
     if (ctx->scratch2_bytes >= bytes) return PLONK_OK;
-    if (ctx->d_scratch2) hipFree(ctx->d_scratch2);
+    if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
     ctx->d_scratch2 = nullptr; ctx->scratch2_bytes = 0;
     HIP_TRY(hipMalloc(&ctx->d_scratch2, bytes));
     ctx->scratch2_bytes = bytes;
@@ -163,19 +163,19 @@ extern "C" int plonk_create(plonk_ctx** out, int device, int curve) {
 
 extern "C" void plonk_destroy(plonk_ctx* ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
     ntt_tables_destroy(ctx->tables);
-    if (ctx->d_bases) hipFree(ctx->d_bases);
-    if (ctx->d_wire) hipFree(ctx->d_wire);
-    if (ctx->d_scratch) hipFree(ctx->d_scratch);
-    if (ctx->d_scratch2) hipFree(ctx->d_scratch2);
-    if (ctx->msm_ws.d_buf) hipFree(ctx->msm_ws.d_buf);
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
-    hipStreamDestroy(ctx->stream);
+    if (ctx->d_bases) (void)hipFree(ctx->d_bases);
+    if (ctx->d_wire) (void)hipFree(ctx->d_wire);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
+    if (ctx->msm_ws.d_buf) (void)hipFree(ctx->msm_ws.d_buf);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -255,7 +255,7 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
     if (base_layout != PLONK_BASES_XY && base_layout != PLONK_BASES_ARK) return plonk_fail(PLONK_ERR_ARG, "plonk_init: layout %d", base_layout);
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
-    if (ctx->d_bases) hipFree(ctx->d_bases);
+    if (ctx->d_bases) (void)hipFree(ctx->d_bases);
     ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
         const size_t ab = aff_bytes(ctx->curve);
@@ -281,7 +281,7 @@ extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_b
     if (n_bases && !d_bases_xy) return plonk_fail(PLONK_ERR_ARG, "plonk_init_dev: null bases");
     int rc = set_domains(ctx, domain_size, quot_domain_size);
     if (rc) return rc;
-    if (ctx->d_bases) hipFree(ctx->d_bases);
+    if (ctx->d_bases) (void)hipFree(ctx->d_bases);
     ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
         if ((rc = install_bases(ctx, d_bases_xy, n_bases))) return rc;
@@ -604,26 +604,22 @@ extern "C" int plonk_round1(plonk_ctx* ctx, const uint64_t* evals, size_t n, con
     int rc = ensure_scratch2(ctx, (n + 2) * 32);
     if (rc) return rc;
     if (ctx->wire_len < n + 2) {
-        if (ctx->d_wire) hipFree(ctx->d_wire);
+        if (ctx->d_wire) (void)hipFree(ctx->d_wire);
         ctx->d_wire = nullptr; ctx->wire_len = 0;
         HIP_TRY(hipMalloc((void**)&ctx->d_wire, (n + 2) * 32));
         ctx->wire_len = n + 2;
     }
     Fr* tmp = (Fr*)ctx->d_scratch2;
-    Fr* d_bl = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_bl, 64));
     HIP_TRY(hipMemcpyAsync(tmp, evals, n * 32, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_bl, blinders, 64, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemsetAsync(ctx->d_wire + n, 0, 64, ctx->stream));
     {
         NttCall c;
         c.in = tmp; c.out = ctx->d_wire; c.log_m = ilog2_exact(n); c.batch = 1; c.inverse = true;     // worker.rs:398
         rc = ntt_run(ctx->tables, c, ctx->stream);
     }
-    if (!rc) rc = blind_add_dev(ctx->curve, ctx->d_wire, n, d_bl, ctx->stream);                        // worker.rs:400-401
+    if (!rc) rc = blind_run(ctx->tables, ctx->d_wire, n, blinders, 2, ctx->stream);                    // worker.rs:400-401
     if (!rc) rc = plonk_commit_dev(ctx, ctx->d_wire, n + 2, out_commit);                               // worker.rs:403-405
-    hipStreamSynchronize(ctx->stream);
-    hipFree(d_bl);
+    (void)hipStreamSynchronize(ctx->stream);
     return rc;
 }
 

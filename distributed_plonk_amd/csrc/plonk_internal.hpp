@@ -135,7 +135,6 @@ int field_op_dev(int curve, int field, int op, const void* a, const void* b, voi
 int synth_fr_dev(int curve, uint64_t seed, Fr* out, size_t n, hipStream_t stream);
 int synth_bases_dev(int curve, uint64_t seed, size_t unique, size_t n, void* d_out, hipStream_t stream);
 int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hipStream_t stream);
-int blind_add_dev(int curve, Fr* poly, size_t n, const Fr* d_blind2, hipStream_t stream);
 
 const FrParams& fr_params(int curve);
 

@@ -1,6 +1,5 @@
 // synth.hip — small element-wise device kernels around the hot path:
 //   * into_repr over a coefficient vector (commit_polynomial, worker.rs:118)
-//   * blinding add (worker.rs:400-401)
 //   * element-wise field ops for pinning the arithmetic layer against the oracle
 //   * seeded synthetic inputs (the reference draws from thread_rng: dispatcher.rs:187-200):
 //     uniform Fr, and SRS-like G1 bases (k_j*G tiled, or pairwise-distinct sums A_i + B_j)
@@ -66,22 +65,6 @@ int field_op_dev(int curve, int field, int op, const void* a, const void* b, voi
 
 int fr_from_mont_dev(int curve, const Fr* in, Fr* out, size_t n, hipStream_t stream) {
     return field_op_dev(curve, 0, 4, in, nullptr, out, n, stream);
-}
-
-// poly[0..1] -= b ; poly[n..n+1] += b   ((b0 + b1 X)(X^n - 1) + poly), worker.rs:400-401
-__global__ void blind_add_kernel(Fr* poly, uint64_t n, const Fr* blind2, const FrParams P) {
-    const int i = threadIdx.x;
-    if (i < 2) {
-        Fr b = ld16(blind2 + i);
-        st16(poly + i, fp_sub(ld16(poly + i), b, P));
-        st16(poly + n + i, fp_add(ld16(poly + n + i), b, P));
-    }
-}
-int blind_add_dev(int curve, Fr* poly, size_t n, const Fr* d_blind2, hipStream_t stream) {
-    hipLaunchKernelGGL(blind_add_kernel, dim3(1), dim3(64), 0, stream, poly, (uint64_t)n, d_blind2, fr_params(curve));
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "blind_add launch: %s", hipGetErrorString(e));
-    return PLONK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- synthetic Fr
@@ -207,8 +190,8 @@ static int synth_distinct_t(int curve, uint64_t seed, size_t n, void* d_out, hip
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) rc = plonk_fail(PLONK_ERR_HIP, "synth_sum launch: %s", hipGetErrorString(e));
     }
-    hipStreamSynchronize(stream);
-    hipFree(tmp);
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(tmp);
     return rc;
 }
 
