@@ -94,7 +94,11 @@ SIGNATURES = {
     "plonk_poly_div_linear_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "plonk_poly_degree_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64)]),
     "plonk_memset_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t]),
+    "plonk_coset_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "plonk_coset_interp_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "plonk_blind_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    "plonk_quotient_evals_class_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientInputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32,
+                                                 C.c_uint32, C.c_void_p]),
     "plonk_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int64]),
     "plonk_last_kernel_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
     "plonk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),

@@ -632,20 +632,28 @@ extern "C" int plonk_get_wire(plonk_ctx* ctx, uint64_t* out, size_t n_coeffs) {
 }
 
 // ---------------------------------------------------------------------------------------------- quotient evaluations (§8f rank 1)
-extern "C" int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
-                                        const uint64_t* gamma, const uint64_t* k, void* d_out) {
+static int quotient_common(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta, const uint64_t* gamma,
+                           const uint64_t* k, uint32_t cls_stride, uint32_t cls_offset, void* d_out, const char* who) {
     CHECK_CTX(ctx);
-    if (!in || !alpha || !beta || !gamma || !k || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null");
-    for (int j = 0; j < 13; j++) if (!in->selectors[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null selector %d", j);
-    for (int j = 0; j < 5; j++) if (!in->sigmas[j] || !in->wires[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null sigma/wire %d", j);
-    if (!in->perm || !in->pub_input) return plonk_fail(PLONK_ERR_ARG, "plonk_quotient_evals_dev: null perm/pub_input");
+    if (!in || !alpha || !beta || !gamma || !k || !d_out) return plonk_fail(PLONK_ERR_ARG, "%s: null", who);
+    for (int j = 0; j < 13; j++) if (!in->selectors[j]) return plonk_fail(PLONK_ERR_ARG, "%s: null selector %d", who, j);
+    for (int j = 0; j < 5; j++) if (!in->sigmas[j] || !in->wires[j]) return plonk_fail(PLONK_ERR_ARG, "%s: null sigma/wire %d", who, j);
+    if (!in->perm || !in->pub_input) return plonk_fail(PLONK_ERR_ARG, "%s: null perm/pub_input", who);
     if (ctx->domain_size < 2 || ctx->quot_domain_size < ctx->domain_size)
-        return plonk_fail(PLONK_ERR_STATE, "plonk_quotient_evals_dev: domains not initialised (n = %zu, m = %zu)", ctx->domain_size, ctx->quot_domain_size);
+        return plonk_fail(PLONK_ERR_STATE, "%s: domains not initialised (n = %zu, m = %zu)", who, ctx->domain_size, ctx->quot_domain_size);
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc = quotient_evals_run(ctx->tables, in, ctx->domain_size, ctx->quot_domain_size, alpha, beta, gamma, k, d_out, ctx->stream);
+    int rc = quotient_evals_run(ctx->tables, in, ctx->domain_size, ctx->quot_domain_size, alpha, beta, gamma, k, cls_stride, cls_offset, d_out, ctx->stream);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     return rc;
+}
+extern "C" int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
+                                        const uint64_t* gamma, const uint64_t* k, void* d_out) {
+    return quotient_common(ctx, in, alpha, beta, gamma, k, 1, 0, d_out, "plonk_quotient_evals_dev");
+}
+extern "C" int plonk_quotient_evals_class_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
+                                              const uint64_t* gamma, const uint64_t* k, uint32_t class_stride, uint32_t class_offset, void* d_out) {
+    return quotient_common(ctx, in, alpha, beta, gamma, k, class_stride, class_offset, d_out, "plonk_quotient_evals_class_dev");
 }
 
 // ---------------------------------------------------------------------------------------------- permutation product (§8f rank 2)
@@ -691,6 +699,22 @@ extern "C" int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t 
     int rc = ensure_scratch2(ctx, 256);
     if (rc) return rc;
     return poly_degree_run(d_poly, len, degree, ctx->d_scratch2, ctx->stream);
+}
+extern "C" int plonk_coset_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out) {
+    CHECK_CTX(ctx);
+    if ((!d_poly && len) || !shift || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_coset_eval_dev: null");
+    if (d_poly == d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_coset_eval_dev: in-place not supported");
+    int rc = ensure_scratch2(ctx, coset_scratch_bytes(size));
+    if (rc) return rc;
+    return coset_eval_run(ctx->tables, d_poly, len, size, shift, d_out, ctx->d_scratch2, ctx->stream);
+}
+extern "C" int plonk_coset_interp_dev(plonk_ctx* ctx, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count,
+                                      void* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_evals || !shift || !scale || (!d_out && count)) return plonk_fail(PLONK_ERR_ARG, "plonk_coset_interp_dev: null");
+    int rc = ensure_scratch2(ctx, coset_scratch_bytes(size));
+    if (rc) return rc;
+    return coset_interp_run(ctx->tables, d_evals, size, shift, scale, i0, count, d_out, ctx->d_scratch2, ctx->stream);
 }
 extern "C" int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k) {
     CHECK_CTX(ctx);

@@ -69,7 +69,7 @@ struct NttTables {
     size_t plane_budget = (size_t)48 << 30;       // stop creating planes beyond this (fall back to on-the-fly factors)
     // quotient.hip: g * w_Nmax^e (constant form) and 1/(x_i - 1) per quotient-domain size (key = log m)
     F29* quot_x_lo = nullptr;
-    std::unordered_map<int, Fr*> quot_inv_xm1;
+    std::unordered_map<int, Fr*> quot_inv_xm1;     // key: log m | class stride << 8 | class offset << 16
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };
@@ -140,7 +140,7 @@ const FrParams& fr_params(int curve);
 
 // ----------------------------------------------------------------------------------------------- O(n) prover steps (poly_ops.hip, quotient.hip)
 int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
-                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream);
+                       const uint64_t* gamma, const uint64_t* k, uint32_t cls_stride, uint32_t cls_offset, void* d_out, hipStream_t stream);
 size_t perm_product_scratch_bytes(size_t n);
 int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
                      size_t n, void* d_out, void* scratch, hipStream_t stream);
@@ -151,3 +151,7 @@ int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const siz
 int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, void* d_out, void* scratch, hipStream_t stream);
 int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, size_t k, hipStream_t stream);
 int poly_degree_run(const void* d_poly, size_t len, int64_t* degree, void* scratch, hipStream_t stream);
+size_t coset_scratch_bytes(size_t size);
+int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out, void* scratch, hipStream_t stream);
+int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count, void* d_out,
+                     void* scratch, hipStream_t stream);

@@ -234,12 +234,12 @@ __device__ __forceinline__ F29 pow_at(const PowTab& T, uint64_t i, const F29Para
     return r;
 }
 #define POWTAB_BYTES (3 * 1024 * sizeof(F29))
-static int build_pow_tab(const FrParams& P, const Fr& z_mont, uint64_t len, F29* d_tab, PowTab* out, hipStream_t stream) {
+static int build_pow_tab(const FrParams& P, const Fr& z_mont, uint64_t len, F29* d_tab, PowTab* out, hipStream_t stream, const Fr* scale_mont = nullptr) {
     const int levels = len <= 1024 ? 1 : (len <= (1u << 20) ? 2 : 3);
     std::vector<F29> h((size_t)levels * 1024);
     Fr base = z_mont;
     for (int l = 0; l < levels; l++) {
-        Fr acc = fp_one(P);
+        Fr acc = (l == 0 && scale_mont) ? *scale_mont : fp_one(P);      // level 0 carries an optional constant factor
         for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(acc, P); acc = fp_mul(acc, base, P); }
         base = acc;                       // base^1024
     }
@@ -536,6 +536,114 @@ int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint
         hipLaunchKernelGGL(poly_scale_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, pz, S, c);
     }
     return scan_run<OpAdd>(S, len, true, true, btot, boff, (Fr*)nullptr, c, EpiDivFinal{pzi, (Fr*)d_out}, "poly_div_scan", stream);
+}
+
+// ---------------------------------------------------------------------------------------------- arbitrary cosets
+// Evaluation of a coefficient vector on {shift * w_size^k, k < size} and its inverse, for ANY shift — the building block of
+// coset-class parallelism (rank s of G evaluates every polynomial on the points g*w_m^(s+Gk) = (g*w_m^s) * w_(m/G)^k, which
+// makes the quotient kernel rank-local).  With shift = g, size = m this is Radix2EvaluationDomain::coset_fft / coset_ifft.
+//   eval:    tmp[i] = shift^i * sum_u (shift^size)^u * a[i + u*size]   (coefficients beyond `size` fold back: X^size = shift^size
+//            on the coset), then a plain size-point NTT.
+//   interp:  E = iNTT_size(evals);  out[t] = scale * shift^-(i0+t) * E[(i0+t) mod size]   — the contribution of this coset to
+//            coefficient i0+t when `scale` = 1/G and G cosets tile a domain of G*size points; G = 1: coset_ifft itself.
+struct FoldParams {
+    F29 cpow[4];              // rep((shift^size)^u)
+    int nfold;                // ceil(len / size) <= 4
+};
+__global__ void __launch_bounds__(256) coset_prescale_kernel(const Fr* __restrict__ poly, uint64_t len, uint64_t size, const PowTab pw, const FoldParams fo,
+                                                             Fr* __restrict__ out, const PoCtx c) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size) return;
+    const F29Params& fp = c.f29;
+    F29 acc;
+#pragma unroll
+    for (int l = 0; l < 9; l++) acc.l[l] = 0;
+    bool any = false;
+    if (i < len) { acc = f29_from_sat(load_fr(poly + i)); any = true; }
+    for (int u = 1; u < fo.nfold; u++) {
+        const uint64_t j = i + (uint64_t)u * size;
+        if (j < len) { acc = f29_add(acc, f29_mul(f29_from_sat(load_fr(poly + j)), fo.cpow[u], fp)); any = true; }
+    }
+    if (!any) { store_fr(out + i, fp_zero<8>()); return; }
+    f29_norm(acc);                                              // < 5.1 p
+    store_fr(out + i, f29_to_sat(f29_canon(f29_mul(acc, pow_at(pw, i, fp), fp), fp)));
+}
+__global__ void __launch_bounds__(256) coset_unscale_kernel(const Fr* __restrict__ e, uint64_t size_mask, uint64_t i0, uint64_t count, const PowTab pw,
+                                                            Fr* __restrict__ out, const PoCtx c) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    const uint64_t i = i0 + t;
+    store_fr(out + t, f29_to_sat(f29_canon(f29_mul(f29_from_sat(load_fr(e + (i & size_mask))), pow_at(pw, i, c.f29), c.f29), c.f29)));
+}
+
+size_t coset_scratch_bytes(size_t size) { return align256(size * 32) + align256(POWTAB_BYTES) + 256; }
+
+int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out, void* scratch, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    int log_s = 0;
+    while (((size_t)1 << log_s) < size) log_s++;
+    if (((size_t)1 << log_s) != size || log_s < 1) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: size %zu is not a power of two >= 2", size);
+    if (log_s > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: 2^%d exceeds the two-adicity", log_s);
+    if (len > 4 * size) return plonk_fail(PLONK_ERR_ARG, "coset_eval: %zu coefficients for a %zu-point coset (limit 4x)", len, size);
+    if (!fr_arg_ok(shift, P)) return plonk_fail(PLONK_ERR_ARG, "coset_eval: shift not reduced");
+    char* s = (char*)scratch;
+    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
+    Fr* tmp = (Fr*)s;
+    const Fr h = fr_arg(shift);
+    PowTab pw;
+    int rc = build_pow_tab(P, h, size, tab, &pw, stream);
+    if (rc) return rc;
+    FoldParams fo;
+    memset(&fo, 0, sizeof fo);
+    fo.nfold = (int)((len + size - 1) / size);
+    if (fo.nfold < 1) fo.nfold = 1;
+    Fr cs = fp_pow_u64(h, (uint64_t)size, P), cp = fp_one(P);
+    for (int u = 0; u < 4; u++) { fo.cpow[u] = host_rep(cp, P); cp = fp_mul(cp, cs, P); }
+    const PoCtx c = make_ctx(T);
+    {
+        ProfScope ps("coset_prescale_kernel", stream);
+        hipLaunchKernelGGL(coset_prescale_kernel, dim3((uint32_t)((size + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, (uint64_t)size, pw, fo,
+                           tmp, c);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "coset_prescale launch: %s", hipGetErrorString(e));
+    NttCall call;
+    call.in = tmp; call.out = (Fr*)d_out; call.log_m = log_s; call.batch = 1; call.inverse = false;
+    return ntt_run(T, call, stream);
+}
+
+int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count, void* d_out,
+                     void* scratch, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    int log_s = 0;
+    while (((size_t)1 << log_s) < size) log_s++;
+    if (((size_t)1 << log_s) != size || log_s < 1) return plonk_fail(PLONK_ERR_DOMAIN, "coset_interp: size %zu is not a power of two >= 2", size);
+    if (log_s > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset_interp: 2^%d exceeds the two-adicity", log_s);
+    if (i0 + count >= ((size_t)1 << 30)) return plonk_fail(PLONK_ERR_ARG, "coset_interp: index range beyond 2^30");
+    if (!fr_arg_ok(shift, P) || !fr_arg_ok(scale, P)) return plonk_fail(PLONK_ERR_ARG, "coset_interp: shift/scale not reduced");
+    const Fr h = fr_arg(shift);
+    if (fp_is_zero(h)) return plonk_fail(PLONK_ERR_ARG, "coset_interp: zero shift");
+    if (count == 0) return PLONK_OK;
+    char* s = (char*)scratch;
+    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
+    Fr* tmp = (Fr*)s;
+    const Fr sc = fr_arg(scale);
+    PowTab pw;
+    int rc = build_pow_tab(P, fp_inv(h, P), i0 + count, tab, &pw, stream, &sc);
+    if (rc) return rc;
+    NttCall call;
+    call.in = (const Fr*)d_evals; call.out = tmp; call.log_m = log_s; call.batch = 1; call.inverse = true;     // includes the 1/size factor
+    rc = ntt_run(T, call, stream);
+    if (rc) return rc;
+    const PoCtx c = make_ctx(T);
+    {
+        ProfScope ps("coset_unscale_kernel", stream);
+        hipLaunchKernelGGL(coset_unscale_kernel, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, stream, (const Fr*)tmp, (uint64_t)size - 1, (uint64_t)i0,
+                           (uint64_t)count, pw, (Fr*)d_out, c);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "coset_unscale launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- blinding

@@ -23,11 +23,13 @@ struct QuotParams {
     const Fr* z;
     const Fr* pi;
     Fr* out;
-    uint64_t m;
+    uint64_t m;            // points of the whole quotient domain
+    uint64_t m_local;      // points this launch evaluates: index k <-> global point j = cls_offset + cls_stride * k
+    uint32_t cls_stride, cls_offset;
     uint32_t ratio, lt, x_shift;
     const F29* x_lo;       // g * w_Nmax^e       (constant form = R' form)
     const F29* x_hi;       // w_Nmax^(e << lt)
-    const Fr* inv_xm1;     // 1 / (x_i - 1), R' form, canonical, packed
+    const Fr* inv_xm1;     // 1 / (x_j - 1) for the points of this class, R' form, canonical, packed (index k)
     F29Params fp;
     F29 r2fix;             // 2^266            : R  -> R'
     F29 gamma_rp;          // gamma * 2^261
@@ -52,8 +54,9 @@ struct LazySum {           // sum of normalised values; limbs re-normalised ever
 __device__ __forceinline__ F29 ldq(const Fr* p, uint64_t i) { return f29_from_sat(load_fr(p + i)); }
 
 __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.m) return;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // local index k
+    if (i >= P.m_local) return;
+    const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
     const F29Params& fp = P.fp;
     // wires and z in R' form
     F29 w5[5];
@@ -61,7 +64,7 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
     for (int j = 0; j < 5; j++) w5[j] = f29_mul(ldq(P.wire[j], i), P.r2fix, fp);
     const F29 a = w5[0], b = w5[1], c = w5[2], d = w5[3], e = w5[4];
     const F29 zc = f29_mul(ldq(P.z, i), P.r2fix, fp);
-    const F29 zn = f29_mul(ldq(P.z, (i + P.ratio) & (P.m - 1)), P.r2fix, fp);
+    const F29 zn = f29_mul(ldq(P.z, (i + P.ratio / P.cls_stride) & (P.m_local - 1)), P.r2fix, fp);     // z(w x): point j + ratio, same class
 
     // ---- gate equation (dispatcher2.rs:459-477)
     const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
@@ -85,7 +88,7 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
     f29_norm(gate);
 
     // ---- evaluation point x_i = g * w_m^i and the permutation argument (:479-495)
-    const uint64_t E = i << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
+    const uint64_t E = j << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
     const F29 x = f29_mul(load_f29(P.x_lo + (E & mask)), load_f29(P.x_hi + ((E >> P.lt) & mask)), fp);
     F29 acc1 = zc, acc2 = zn;
 #pragma unroll
@@ -111,7 +114,7 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
     // ---- z_h_inv * (gate + perm) + l1
     F29 s = f29_add(gate, perm);
     f29_norm(s);
-    F29 r = f29_add(f29_mul(s, P.zh_inv_rp[i & (P.ratio - 1)], fp), l1);
+    F29 r = f29_add(f29_mul(s, P.zh_inv_rp[j & (P.ratio - 1)], fp), l1);
     f29_norm(r);                                                                     // < 2.8 p
     r = f29_canon(f29_canon(r, fp), fp);
     store_fr(P.out + i, f29_to_sat(r));
@@ -120,9 +123,9 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
 // 1/(x_i - 1) for all m points: Montgomery batch inversion over 16 consecutive points per lane, one Fermat
 // inversion per lane.  One-time per domain.
 #define QINV_CH 16
-__global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ out, uint64_t m, const F29* __restrict__ x_lo,
-                                                              const F29* __restrict__ x_hi, uint32_t lt, uint32_t x_shift, const F29Params fp,
-                                                              const F29 pm2_bits /* p - 2 as 29-bit limbs */) {
+__global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ out, uint64_t m, uint32_t cls_stride, uint32_t cls_offset,
+                                                              const F29* __restrict__ x_lo, const F29* __restrict__ x_hi, uint32_t lt, uint32_t x_shift,
+                                                              const F29Params fp, const F29 pm2_bits /* p - 2 as 29-bit limbs */) {
     const uint64_t base = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * QINV_CH;
     if (base >= m) return;
     const uint64_t mask = ((uint64_t)1 << lt) - 1;
@@ -132,7 +135,7 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
     F29 d[QINV_CH], pre[QINV_CH];
     F29 run = one_rp;
     for (int k = 0; k < QINV_CH; k++) {
-        const uint64_t E = (base + k) << x_shift;
+        const uint64_t E = ((uint64_t)cls_offset + (uint64_t)cls_stride * (base + k)) << x_shift;
         const F29 x = f29_mul(load_f29(x_lo + (E & mask)), load_f29(x_hi + ((E >> lt) & mask)), fp);
         F29 t = f29_sub2p(x, one_rp, fp);
         f29_norm(t);
@@ -157,7 +160,7 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
 static F29 host_const(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }
 
 int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
-                       const uint64_t* gamma, const uint64_t* k, void* d_out, hipStream_t stream) {
+                       const uint64_t* gamma, const uint64_t* k, uint32_t cls_stride, uint32_t cls_offset, void* d_out, hipStream_t stream) {
     const FrParams& P = T.fp;
     int log_n = 0, log_m = 0;
     while (((size_t)1 << log_n) < n) log_n++;
@@ -165,6 +168,9 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     if (((size_t)1 << log_n) != n || ((size_t)1 << log_m) != m || m < n || m / n > 8 || m / n < 1)
         return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: n = %zu, m = %zu (m/n must be a power of two <= 8)", n, m);
     if (log_m > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "quotient_evals: 2^%d exceeds the two-adicity", log_m);
+    if (cls_stride == 0 || (cls_stride & (cls_stride - 1)) || cls_stride > m / n || cls_offset >= cls_stride)
+        return plonk_fail(PLONK_ERR_ARG, "quotient_evals: class %u of %u (the stride must be a power of two dividing m/n = %zu)", cls_offset, cls_stride, m / n);
+    const uint64_t m_local = m / cls_stride;
     const uint32_t* g_l = T.curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT;
     const Fr g_mont = fp_from_limbs<8>(g_l);
     if (!T.quot_x_lo) {          // g * w_Nmax^e, e < 2^lt, constant form
@@ -180,25 +186,28 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     memset(&q, 0, sizeof q);
     q.fp = T.fp29;
     q.m = m;
+    q.m_local = m_local;
+    q.cls_stride = cls_stride; q.cls_offset = cls_offset;
     q.ratio = (uint32_t)(m / n);
     q.lt = T.lt;
     q.x_shift = T.two_adicity - log_m;
     q.x_lo = T.quot_x_lo;
     q.x_hi = T.tw_hi[0];
     // 1/(x_i - 1) table
-    auto it = T.quot_inv_xm1.find(log_m);
+    const int inv_key = log_m | (int)(cls_stride << 8) | (int)(cls_offset << 16);
+    auto it = T.quot_inv_xm1.find(inv_key);
     if (it == T.quot_inv_xm1.end()) {
         Fr* d = nullptr;
-        HIP_TRY(hipMalloc((void**)&d, m * sizeof(Fr)));
+        HIP_TRY(hipMalloc((void**)&d, m_local * sizeof(Fr)));
         Fr pm2;                                         // p - 2
         uint64_t br = 2;
         for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
-        const uint64_t lanes = (m + QINV_CH - 1) / QINV_CH;
-        hipLaunchKernelGGL(quotient_gen_inv_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, stream, d, (uint64_t)m, q.x_lo, q.x_hi, q.lt,
-                           q.x_shift, q.fp, f29_from_sat(pm2));
+        const uint64_t lanes = (m_local + QINV_CH - 1) / QINV_CH;
+        hipLaunchKernelGGL(quotient_gen_inv_kernel, dim3((uint32_t)((lanes + 63) / 64)), dim3(64), 0, stream, d, (uint64_t)m_local, cls_stride, cls_offset, q.x_lo,
+                           q.x_hi, q.lt, q.x_shift, q.fp, f29_from_sat(pm2));
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { (void)hipFree(d); return plonk_fail(PLONK_ERR_HIP, "quotient_gen_inv launch: %s", hipGetErrorString(e)); }
-        T.quot_inv_xm1[log_m] = d;
+        T.quot_inv_xm1[inv_key] = d;
         q.inv_xm1 = d;
     } else {
         q.inv_xm1 = it->second;
@@ -234,7 +243,7 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        hipLaunchKernelGGL(quotient_evals_kernel, dim3((uint32_t)((m + 255) / 256)), dim3(256), 0, stream, q);
+        hipLaunchKernelGGL(quotient_evals_kernel, dim3((uint32_t)((m_local + 255) / 256)), dim3(256), 0, stream, q);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "quotient_evals launch: %s", hipGetErrorString(e));

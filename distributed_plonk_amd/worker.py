@@ -204,9 +204,11 @@ class PlonkWorker:
         return out, bool(inf.value)
 
     # ------------------------------------------------------------------ next row: quotient evaluations (dispatcher2.rs:362-504)
-    def quotient_evals_dev(self, selectors, sigmas, wires, perm, pub_input, alpha, beta, gamma, k, d_out: int):
+    def quotient_evals_dev(self, selectors, sigmas, wires, perm, pub_input, alpha, beta, gamma, k, d_out: int, class_stride: int = 1,
+                           class_offset: int = 0):
         """selectors (13), sigmas (5), wires (5): device pointers to m coset evaluations each; perm / pub_input: device
-        pointers; alpha, beta, gamma (4,) and k (5,4): Montgomery limbs on the host."""
+        pointers; alpha, beta, gamma (4,) and k (5,4): Montgomery limbs on the host.  class_stride G > 1: every vector holds the
+        m/G evaluations of coset class `class_offset` (points class_offset + G*k)."""
         q = _ffi.QuotientInputs()
         for j in range(13):
             q.selectors[j] = selectors[j]
@@ -215,7 +217,10 @@ class PlonkWorker:
             q.wires[j] = wires[j]
         q.perm, q.pub_input = perm, pub_input
         al, be, ga, kk = _u64(alpha), _u64(beta), _u64(gamma), _u64(k)
-        check(self.lib.plonk_quotient_evals_dev(self.ctx, C.byref(q), _ptr(al), _ptr(be), _ptr(ga), _ptr(kk), d_out))
+        if class_stride == 1:
+            check(self.lib.plonk_quotient_evals_dev(self.ctx, C.byref(q), _ptr(al), _ptr(be), _ptr(ga), _ptr(kk), d_out))
+        else:
+            check(self.lib.plonk_quotient_evals_class_dev(self.ctx, C.byref(q), _ptr(al), _ptr(be), _ptr(ga), _ptr(kk), class_stride, class_offset, d_out))
 
     # ------------------------------------------------------------------ next rows: permutation product, round 4/5 polynomial ops
     def perm_product_dev(self, wires, d_id_perm: int, d_perm_idx: int, beta, gamma, n: int, d_out: int):
@@ -244,6 +249,16 @@ class PlonkWorker:
         """quotient of poly / (X - point), remainder dropped (dispatcher2.rs:651-666): length-1 coefficients."""
         z = _u64(point)
         check(self.lib.plonk_poly_div_linear_dev(self.ctx, d_poly, length, _ptr(z), d_out))
+
+    def coset_eval_dev(self, d_poly: int, length: int, size: int, shift, d_out: int):
+        """d_out[k] = poly(shift * w_size^k), k < size (any shift; length <= 4*size folds back)."""
+        h = _u64(shift)
+        check(self.lib.plonk_coset_eval_dev(self.ctx, d_poly, length, size, _ptr(h), d_out))
+
+    def coset_interp_dev(self, d_evals: int, size: int, shift, scale, i0: int, count: int, d_out: int):
+        """d_out[t] = scale * shift^-(i0+t) * iNTT_size(evals)[(i0+t) mod size]; d_evals is destroyed."""
+        h, sc = _u64(shift), _u64(scale)
+        check(self.lib.plonk_coset_interp_dev(self.ctx, d_evals, size, _ptr(h), _ptr(sc), i0, count, d_out))
 
     def poly_degree_dev(self, d_poly: int, length: int) -> int:
         """DensePolynomial::degree() after trimming (-1 = zero polynomial), dispatcher2.rs:511-518."""

@@ -144,6 +144,12 @@ typedef struct {
 int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
                              const uint64_t* gamma, const uint64_t* k, void* d_out);
 
+/* The same on ONE coset class: all inputs hold the m/G evaluations at the points x_j, j = class_offset + class_stride * k
+ * (plonk_coset_eval_dev with shift g * w_m^class_offset), d_out[k] is the quotient evaluation at that point.  G = class_stride
+ * must be a power of two dividing m/n, so z(w x) — point j + m/n — stays inside the class: rank-local with no halo. */
+int plonk_quotient_evals_class_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
+                                   const uint64_t* gamma, const uint64_t* k, uint32_t class_stride, uint32_t class_offset, void* d_out);
+
 /* ---- next row: permutation grand product — dispatcher2.rs:329-344 ---------------------------
  * d_out[0] = 1, d_out[j+1] = d_out[j] * prod_i (w_i[j] + gamma + beta*id[i*n+j]) / prod_i (w_i[j] + gamma + beta*id[perm[i*n+j]]),
  * j < n-1: the `product_vec` the reference builds gate by gate on the host.  d_wires[i]: n wire values
@@ -169,6 +175,18 @@ int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t len, int64_
 /* d_poly (n + k coefficients, the top k already valid, normally zero) += (sum_{i<k} blinders[i] X^i) * (X^n - 1):
  * DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly (:311-312 k = 2, :347-348 k = 3).  k <= 4. */
 int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k);
+
+/* ---- evaluation on / interpolation from an ARBITRARY coset (building block of coset-class parallelism) ------
+ * d_out[k] = poly(shift * w_size^k), k < size; size a power of two, len <= 4*size (coefficients beyond `size` fold back, since
+ * X^size = shift^size on the coset).  shift = Fr::multiplicative_generator(), size = m: quot_domain.coset_fft (dispatcher2.rs:387-424)
+ * of the zero-padded vector.  shift = g * w_m^s, size = m/G: the evaluations at the points of index s, s+G, s+2G, ... of that
+ * same coset FFT — rank s's share of every round-3 vector with no communication. */
+int plonk_coset_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out);
+/* E = iNTT_size(d_evals) (d_evals is destroyed), d_out[t] = scale * shift^-(i0+t) * E[(i0+t) mod size], t < count.
+ * shift = g, scale = 1, i0 = 0, count = size: quot_domain.coset_ifft (dispatcher2.rs:507).  With scale = 1/G and shift = g * w_m^s,
+ * the sum over s < G of these vectors is coefficient i0+t of the polynomial interpolating all G cosets. */
+int plonk_coset_interp_dev(plonk_ctx* ctx, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count,
+                           void* d_out);
 
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
