@@ -75,6 +75,7 @@ SIGNATURES = {
     "plonk_ntt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "plonk_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "plonk_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "plonk_commit_range_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
     "plonk_fft1_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "plonk_fft2_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "plonk_transpose_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),

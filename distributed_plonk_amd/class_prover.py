@@ -1,0 +1,220 @@
+"""Multi-rank prover by COSET CLASSES: the five rounds of `Prover::prove` (/root/reference/src/dispatcher2.rs:296-712) on G ranks
+(one per GPU) with two data-path collectives per proof instead of one all-to-all per NTT.
+
+The reference distributes every one of its 33 NTTs over the workers (row pass, all-to-all, column pass — `Prover::fft`,
+dispatcher2.rs:732-787) and reassembles each result on the dispatcher.  On MI355X the per-proof vectors fit every GPU, so the
+parallelism is moved to where the work is: the 8n-point quotient domain  {x_j = g * w_m^j}  splits into G classes
+j = s (mod G), and class s is itself a coset  {(g * w_m^s) * w_(m/G)^k}.  Rank s
+
+  * evaluates all 25 round-3 polynomials on ITS class with a local (m/G)-point NTT (`plonk_coset_eval_dev`) — no exchange;
+  * runs the quotient kernel on its class (`plonk_quotient_evals_class_dev`) — z(w x) is point j + m/n, same class for G | 8;
+  * inverts locally (`plonk_coset_interp_dev`): its additive contribution to every quotient coefficient;
+  * ONE all-to-all sums the contributions (rank r ends up owning coefficients [r*m/G, (r+1)*m/G)), ONE all-gather replicates
+    the quotient polynomial;
+  * every commitment is an index-sharded MSM (dispatcher2.rs:870-890): rank s covers coefficients [s*L/G, (s+1)*L/G), the G
+    partial points (96/144 bytes) are all-gathered and added on the host.
+
+The O(n) rounds (wire / permutation iNTTs, grand product, evaluations at zeta, linearisation, openings) are computed redundantly
+on every rank: ~45 ms at n = 2^24 against ~100 ms of class work per rank at G = 8; sharding them is the next step.
+Results are bit-identical to the single-GPU `Prover` (and the oracle): tests/test_gpu_class_prover.py runs G = 2, 4, 8 ranks as
+threads sharing one GPU; tests/test_gloo_multirank.py covers the torch.distributed transport on CPU tensors.
+"""
+from __future__ import annotations
+
+import threading
+import time
+from typing import List, Optional
+
+import numpy as np
+
+from .prover import NUM_WIRE_TYPES, Prover
+from .worker import PlonkWorker
+
+
+# --------------------------------------------------------------------------------------------- transports
+class LocalComm:
+    """G ranks as threads of one process (tests): device buffers are exchanged with plonk_memcpy_d2d, host objects through a
+    shared board.  Every rank owns its PlonkWorker (context + stream) — possibly on the same GPU."""
+
+    class Board:
+        def __init__(self, size: int):
+            self.size = size
+            self.barrier = threading.Barrier(size)
+            self.slots: List[object] = [None] * size
+
+    def __init__(self, board: "LocalComm.Board", rank: int, worker: PlonkWorker):
+        self.board, self.rank, self.size, self.w = board, rank, board.size, worker
+
+    def all_gather_host(self, obj):
+        b = self.board
+        b.slots[self.rank] = obj
+        b.barrier.wait()
+        out = list(b.slots)
+        b.barrier.wait()
+        return out
+
+    def all_to_all_dev(self, d_send: int, d_recv: int, nbytes: int):
+        """block p of d_send (nbytes each) -> block `rank` of rank p's d_recv."""
+        self.w.sync()
+        peers = self.all_gather_host((d_recv, None))
+        for p in range(self.size):
+            self.w.memcpy_d2d(peers[p][0] + self.rank * nbytes, d_send + p * nbytes, nbytes)
+        self.w.sync()
+        self.board.barrier.wait()
+
+    def all_gather_dev(self, d_send: int, d_recv: int, nbytes: int):
+        """d_send (nbytes) -> block `rank` of every rank's d_recv."""
+        self.w.sync()
+        peers = self.all_gather_host(d_recv)
+        for p in range(self.size):
+            self.w.memcpy_d2d(peers[p] + self.rank * nbytes, d_send, nbytes)
+        self.w.sync()
+        self.board.barrier.wait()
+
+
+class TorchComm:
+    """One process per GPU under torchrun: torch.distributed (backend nccl = RCCL over xGMI) on the library's stream.
+    `device` = None uses CPU tensors through host staging (gloo; tests)."""
+
+    def __init__(self, worker: PlonkWorker, device=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.w, self.device = torch, dist, worker, device
+        self.rank, self.size = dist.get_rank(), dist.get_world_size()
+
+    def all_gather_host(self, obj):
+        out = [None] * self.size
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def _tensor(self, ptr: int, nbytes: int):
+        class _Buf:
+            __cuda_array_interface__ = {"shape": (nbytes // 8,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+        return self.torch.as_tensor(_Buf(), device=self.device)
+
+    def _staged(self, ptr: int, nbytes: int):
+        import ctypes as C
+        from ._ffi import check
+        t = self.torch.empty(nbytes // 8, dtype=self.torch.int64)
+        check(self.w.lib.plonk_memcpy_d2h(self.w.ctx, C.c_void_p(t.data_ptr()), ptr, nbytes))
+        return t
+
+    def _unstage(self, t, ptr: int):
+        import ctypes as C
+        from ._ffi import check
+        check(self.w.lib.plonk_memcpy_h2d(self.w.ctx, ptr, C.c_void_p(t.data_ptr()), t.numel() * 8))
+
+    def all_to_all_dev(self, d_send: int, d_recv: int, nbytes: int):
+        total = nbytes * self.size
+        if self.device is None:
+            src, dst = self._staged(d_send, total), self.torch.empty(total // 8, dtype=self.torch.int64)
+            self.dist.all_to_all_single(dst, src)
+            self._unstage(dst, d_recv)
+            return
+        stream = self.torch.cuda.ExternalStream(self.w.stream_ptr(), device=self.device)
+        with self.torch.cuda.stream(stream):
+            self.dist.all_to_all_single(self._tensor(d_recv, total), self._tensor(d_send, total))
+
+    def all_gather_dev(self, d_send: int, d_recv: int, nbytes: int):
+        total = nbytes * self.size
+        if self.device is None:
+            src, dst = self._staged(d_send, nbytes), self.torch.empty(total // 8, dtype=self.torch.int64)
+            self.dist.all_gather_into_tensor(dst, src)
+            self._unstage(dst, d_recv)
+            return
+        stream = self.torch.cuda.ExternalStream(self.w.stream_ptr(), device=self.device)
+        with self.torch.cuda.stream(stream):
+            self.dist.all_gather_into_tensor(self._tensor(d_recv, total), self._tensor(d_send, nbytes))
+
+
+# --------------------------------------------------------------------------------------------- the SPMD prover
+def shard_range(length: int, rank: int, size: int):
+    """coefficients [i*L/S, (i+1)*L/S) — the MSM sharding of dispatcher2.rs:875-878."""
+    return rank * length // size, (rank + 1) * length // size
+
+
+class ClassProver(Prover):
+    """Rank `comm.rank` of `comm.size` (a power of two <= 8).  Same calls, same results as `Prover`; every rank must make them.
+    `worker.init(ck, n, 8n)` with the WHOLE commit key on every rank (72 B per point resident: replicated, not sharded, because
+    a coefficient shard of the split quotient polynomials needs bases from anywhere in the key)."""
+
+    def __init__(self, worker: PlonkWorker, log_n: int, comm):
+        super().__init__(worker, log_n, cache_key_cosets=False)
+        G = comm.size
+        if G & (G - 1) or G > self.m // self.n:
+            raise ValueError(f"{G} ranks: coset classes need a power of two <= m/n = {self.m // self.n}")
+        self.comm = comm
+        self.G, self.s = G, comm.rank
+        f = self.f
+        w_m = f.root_of_unity(self.m)
+        self.shift = f.to_limbs(f.generator * pow(w_m, self.s, f.p))     # g * w_m^s : this rank's class is shift * <w_(m/G)>
+        self.inv_G = f.to_limbs(f.inv(G))
+
+    # ---- commitments: index-sharded MSM + 96/144-byte all-gather (dispatcher2.rs:870-892)
+    def _commit(self, d_poly: int, length: int):
+        lo, hi = shard_range(length, self.s, self.G)
+        part = self.w.commit_range_dev(d_poly + lo * 32, lo, hi - lo)
+        acc = None
+        for p in self.comm.all_gather_host(part):
+            acc = p if acc is None else self.w.g1_add(acc, p)
+        return self.w.g1_to_affine(acc)
+
+    # ---- the quotient's degree: every rank holds the whole polynomial after the all-gather
+    def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
+        w, n, m, key, G, s = self.w, self.n, self.m, self._key, self.G, self.s
+        mL = m // G
+        t0 = time.perf_counter()
+        d_cls = alloc(25 * mL)
+        cls = [d_cls.ptr + j * mL * 32 for j in range(25)]
+        srcs = [(p, n) for p in key["sel"] + key["sig"]] + list(wire_polys) + [perm_poly, pi_poly]
+        for j, (ptr, ln) in enumerate(srcs):
+            w.coset_eval_dev(ptr, ln, mL, self.shift, cls[j])             # this class's slice of the coset FFT of :387-429
+        tick("round3_coset_ffts", t0)
+        t0 = time.perf_counter()
+        d_qev = alloc(mL)
+        w.quotient_evals_dev(cls[0:13], cls[13:18], cls[18:23], cls[23], cls[24], alpha, beta, gamma, key["k"], d_qev.ptr,
+                             class_stride=G, class_offset=s)
+        d_contrib = alloc(m)                                              # this class's share of every coefficient
+        w.coset_interp_dev(d_qev.ptr, mL, self.shift, self.inv_G, 0, m, d_contrib.ptr)
+        tick("round3_quotient", t0)
+        t0 = time.perf_counter()
+        d_recv = alloc(m)
+        self.comm.all_to_all_dev(d_contrib.ptr, d_recv.ptr, mL * 32)     # block r: coefficients [r*mL, (r+1)*mL)
+        d_mine = alloc(mL)
+        ones = np.tile(self.f.to_limbs(1), (G, 1))
+        w.poly_lincomb_dev([(d_recv.ptr + p * mL * 32, mL) for p in range(G)], ones, d_mine.ptr, mL)
+        d_quot = alloc(m)
+        self.comm.all_gather_dev(d_mine.ptr, d_quot.ptr, mL * 32)
+        tick("round3_exchange", t0)
+        return d_quot.ptr
+
+
+def run_local_ranks(G: int, fn, device: int = 0, curve: str = "bn254"):
+    """Run fn(comm, worker) on G threads sharing one GPU (tests / single-GPU dry runs of the multi-rank path).
+    Returns the list of results; re-raises the first exception."""
+    board = LocalComm.Board(G)
+    results: List[object] = [None] * G
+    errors: List[Optional[BaseException]] = [None] * G
+
+    def body(r):
+        w = PlonkWorker(me=r, device=device, curve=curve)
+        try:
+            results[r] = fn(LocalComm(board, r, w), w)
+        except BaseException as e:          # noqa: BLE001 - reported to the caller below
+            errors[r] = e
+            board.barrier.abort()
+        finally:
+            w.close()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(G)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for e in errors:
+        if e is not None and not isinstance(e, threading.BrokenBarrierError):
+            raise e
+    for e in errors:
+        if e is not None:
+            raise e
+    return results

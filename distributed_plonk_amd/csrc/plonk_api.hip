@@ -335,6 +335,17 @@ extern "C" int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_
     return msm_device(ctx, 0, n, (const uint32_t*)ctx->d_scratch2, out_jacobian);
 }
 
+extern "C" int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t start, size_t count, uint64_t* out_jacobian) {
+    CHECK_CTX(ctx);
+    if (!out_jacobian || (count && !d_coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_range_dev: null argument");
+    if (start > ctx->n_bases) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_range_dev: start %zu beyond the %zu resident bases", start, ctx->n_bases);
+    const size_t n = std::min(count, ctx->n_bases - start);
+    int rc = ensure_scratch2(ctx, std::max<size_t>(n, 1) * 32);
+    if (rc) return rc;
+    if ((rc = fr_from_mont_dev(ctx->curve, (const Fr*)d_coeffs_mont, (Fr*)ctx->d_scratch2, n, ctx->stream))) return rc;
+    return msm_device(ctx, start, n, (const uint32_t*)ctx->d_scratch2, out_jacobian);
+}
+
 extern "C" int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian) {
     CHECK_CTX(ctx);
     if (!out_jacobian || (n_coeffs && !coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit: null argument");

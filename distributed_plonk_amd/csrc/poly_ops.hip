@@ -239,8 +239,9 @@ static int build_pow_tab(const FrParams& P, const Fr& z_mont, uint64_t len, F29*
     std::vector<F29> h((size_t)levels * 1024);
     Fr base = z_mont;
     for (int l = 0; l < levels; l++) {
-        Fr acc = (l == 0 && scale_mont) ? *scale_mont : fp_one(P);      // level 0 carries an optional constant factor
-        for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(acc, P); acc = fp_mul(acc, base, P); }
+        const Fr mult = (l == 0 && scale_mont) ? *scale_mont : fp_one(P);      // level 0 carries an optional constant factor
+        Fr acc = fp_one(P);
+        for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(fp_mul(acc, mult, P), P); acc = fp_mul(acc, base, P); }
         base = acc;                       // base^1024
     }
     HIP_TRY(hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(F29), hipMemcpyHostToDevice, stream));

@@ -144,6 +144,42 @@ class Prover:
         """commit_polynomial (dispatcher2.rs:835-893) -> affine (xy limbs, is_infinity)."""
         return self.w.g1_to_affine(self.w.commit_dev(d_poly, length))
 
+    def _degree(self, d_poly: int, length: int) -> int:
+        return self.w.poly_degree_dev(d_poly, length)
+
+    def _download(self, d_ptr: int, n_fr: int) -> np.ndarray:
+        out = np.empty((n_fr, 4), dtype=np.uint64)
+        import ctypes as C
+        from ._ffi import check
+        check(self.w.lib.plonk_memcpy_d2h(self.w.ctx, out.ctypes.data_as(C.c_void_p), d_ptr, out.nbytes))
+        return out
+
+    def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
+        """Round 3 between the challenges and the split commitments (dispatcher2.rs:362-509): 25 coset FFTs over the 8n domain,
+        the pointwise quotient evaluation, one coset iFFT.  Returns a device pointer to the m quotient coefficients."""
+        w, n, m, key = self.w, self.n, self.m, self._key
+        t0 = time.perf_counter()
+        d_tmp = alloc(m)
+        if key["cos"] is None:
+            d_kc = alloc(18 * m)
+            kc = [d_kc.ptr + j * m * 32 for j in range(18)]
+            for j, src in enumerate(key["sel"] + key["sig"]):
+                self._coset_fft(src, n, d_tmp.ptr, kc[j])
+        else:
+            kc = key["cos"]
+        d_c = alloc(7 * m)
+        cw = [d_c.ptr + j * m * 32 for j in range(7)]
+        for j, (ptr, ln) in enumerate(list(wire_polys) + [perm_poly, pi_poly]):
+            self._coset_fft(ptr, ln, d_tmp.ptr, cw[j])                    # :406-429
+        tick("round3_coset_ffts", t0)
+        t0 = time.perf_counter()
+        d_qev = alloc(m)
+        w.quotient_evals_dev(kc[0:13], kc[13:18], cw[0:5], cw[5], cw[6], alpha, beta, gamma, key["k"], d_qev.ptr)
+        d_quot = alloc(m)
+        w.ntt_dev(d_qev.ptr, d_quot.ptr, m, True, True)                   # :507
+        tick("round3_quotient", t0)
+        return d_quot.ptr
+
     # ------------------------------------------------------------------ the five rounds
     def prove(self, wires: np.ndarray, id_perm: np.ndarray, perm_idx: np.ndarray, pub_input: np.ndarray, blinders: dict,
               challenge: Callable[[str, dict], np.ndarray], check_degree: bool = True, keep: bool = False) -> dict:
@@ -212,39 +248,19 @@ class Prover:
         # ---- Round 3 (:360-533): quotient polynomial
         t0 = time.perf_counter()
         alpha = challenge("alpha", proof)
-        d_tmp = alloc(m)
-        if key["cos"] is None:
-            d_kc = alloc(18 * m)
-            kc = [d_kc.ptr + j * m * 32 for j in range(18)]
-            for j, src in enumerate(key["sel"] + key["sig"]):
-                self._coset_fft(src, n, d_tmp.ptr, kc[j])
-        else:
-            kc = key["cos"]
-        d_c = alloc(7 * m)
-        cw = [d_c.ptr + j * m * 32 for j in range(7)]
-        for i in range(5):
-            self._coset_fft(wp[i], WP, d_tmp.ptr, cw[i])
-        self._coset_fft(d_pp.ptr, PP, d_tmp.ptr, cw[5])
         d_pi_poly = alloc(n)
         w.memcpy_d2d(d_tmp_n.ptr, d_pi, n * 32)
         w.ntt_dev(d_tmp_n.ptr, d_pi_poly.ptr, n, True, False)             # :426
-        self._coset_fft(d_pi_poly.ptr, n, d_tmp.ptr, cw[6])               # :428
-        tick("round3_coset_ffts", t0)
-        t0 = time.perf_counter()
-        d_qev = alloc(m)
-        w.quotient_evals_dev(kc[0:13], kc[13:18], cw[0:5], cw[5], cw[6], alpha, beta, gamma, key["k"], d_qev.ptr)
-        d_quot = alloc(m)
-        w.ntt_dev(d_qev.ptr, d_quot.ptr, m, True, True)                 # :507
-        tick("round3_quotient", t0)
+        d_quot_ptr = self._quotient_poly(alloc, tick, [(wp[i], WP) for i in range(5)], (d_pp.ptr, PP), (d_pi_poly.ptr, n), alpha, beta, gamma)
         t0 = time.perf_counter()
         expected = NUM_WIRE_TYPES * (n + 1) + 2
         if check_degree:
-            deg = w.poly_degree_dev(d_quot.ptr, m)
+            deg = self._degree(d_quot_ptr, m)
             if deg != expected:
                 raise WrongQuotientPolyDegree(deg, expected)
         split = []
         for off in range(0, expected + 1, n + 2):                       # coeffs.chunks(n + 2)  (:519-523)
-            split.append((d_quot.ptr + off * 32, min(n + 2, expected + 1 - off)))
+            split.append((d_quot_ptr + off * 32, min(n + 2, expected + 1 - off)))
         proof["split_quot_poly_comms"] = [self._commit(ptr, ln) for ptr, ln in split]
         tick("round3_commit", t0)
         # ---- Round 4 (:536-555): evaluations at zeta
@@ -297,6 +313,6 @@ class Prover:
         tick("round5", t0)
         if keep:
             proof["_debug"] = dict(perm_product=dbg_prod, perm_poly=d_pp.download((PP, 4)),
-                                   quot_poly=d_quot.download((expected + 1, 4)), lin_poly=d_lin.download((PP, 4)),
+                                   quot_poly=self._download(d_quot_ptr, expected + 1), lin_poly=d_lin.download((PP, 4)),
                                    batch_poly=d_batch.download((PP, 4)))
         return proof

@@ -123,6 +123,12 @@ class PlonkWorker:
         check(self.lib.plonk_commit_dev(self.ctx, d_coeffs_ptr, n_coeffs, _ptr(out)))
         return out
 
+    def commit_range_dev(self, d_coeffs_ptr: int, start: int, count: int) -> np.ndarray:
+        """One shard of commit_polynomial: coefficients [start, start+count) against bases [start, start+count)."""
+        out = np.empty(3 * self.q64, dtype=np.uint64)
+        check(self.lib.plonk_commit_range_dev(self.ctx, d_coeffs_ptr, start, count, _ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ PlonkSlave @2..@5
     def fft_init(self, id: int, workloads: Sequence[FftWorkload], is_quot: bool, is_inv: bool, is_coset: bool):
         arr = (FftWorkload * len(workloads))(*workloads)

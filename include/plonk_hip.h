@@ -120,6 +120,10 @@ int plonk_transpose(plonk_ctx* ctx, uint64_t* v, size_t rows, size_t cols);
 int plonk_ntt_dev(plonk_ctx* ctx, void* d_in, void* d_out, size_t n, int is_inv, int is_coset);
 int plonk_msm_dev(plonk_ctx* ctx, size_t start, size_t end, const void* d_scalars, uint64_t* out_jacobian);
 int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian);
+/* The shard [start, start + count) of commit_polynomial (dispatcher2.rs:870-890 hands each worker such a range): d_coeffs_mont points
+ * at coefficient `start`; out = sum_{i < count} into_repr(coeff[start + i]) * bases[start + i].  The shards' points add up to the
+ * commitment. */
+int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t start, size_t count, uint64_t* out_jacobian);
 /* All local rows at once, row-major [num_rows][c] in HBM (replaces num_rows fft1 calls). */
 int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows);
 /* Result of fft2 left in HBM.  layout 0: [num_cols][r] (the reference's reply); layout 1:

@@ -1,0 +1,135 @@
+"""The multi-rank prover by coset classes (distributed_plonk_amd/class_prover.py): G ranks run as threads sharing the one
+GPU of the test box, exchanging device buffers through the same all-to-all / all-gather calls the torch.distributed
+transport makes.  Every rank must end up with the proof the oracle's restatement of dispatcher2.rs:296-712 produces."""
+import numpy as np
+import pytest
+
+from distributed_plonk_amd.class_prover import ClassProver, TorchComm, run_local_ranks, shard_range
+
+pytestmark = pytest.mark.gpu
+
+
+def _instance(oracle, cid, log_n, seed):
+    from oracle import prover_ref as P
+    n = 1 << log_n
+    circ = P.make_circuit(cid, log_n, seed=seed)
+    ck, inf = P.make_ck(cid, n, seed=seed + 1, unique=min(64, n))
+    bl = dict(wires=oracle.rand_fr(cid, seed + 2, 10).reshape(5, 2, 4), perm=oracle.rand_fr(cid, seed + 3, 3))
+    ch = {k: oracle.rand_fr(cid, seed + 10 + i, 1)[0] for i, k in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
+    return P, circ, ck, inf, bl, ch
+
+
+def _same_point(got, want):
+    return got[1] == want[1] and np.array_equal(got[0], want[0])
+
+
+def _check(got, want):
+    for key in ("wires_poly_comms", "split_quot_poly_comms"):
+        assert len(got[key]) == 5
+        for g, x in zip(got[key], want[key]):
+            assert _same_point(g, x), key
+    for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+        assert _same_point(got[key], want[key]), key
+    for key in ("wires_evals", "wire_sigma_evals"):
+        assert np.array_equal(np.stack(got[key]), np.stack(want[key])), key
+    assert np.array_equal(got["perm_next_eval"], want["perm_next_eval"])
+    for key in ("quot_poly", "lin_poly", "batch_poly"):
+        assert np.array_equal(got["_debug"][key], want[key]), key
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,G", [(4, 2), (7, 4), (10, 8)])
+def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
+    P, circ, ck, inf, bl, ch = _instance(oracle, cid, log_n, 600 + log_n)
+    n = 1 << log_n
+
+    def rank_main(comm, w):
+        w.init(ck, n, 8 * n)                               # whole commit key on every rank
+        pv = ClassProver(w, log_n, comm)
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            out = None
+            for _ in range(2):                             # second proof reuses the work buffers
+                out = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+            return out, dict(pv.timings)
+        finally:
+            pv.close()
+
+    results = run_local_ranks(G, rank_main, curve=curve)
+    want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=8)
+    for got, timings in results:
+        _check(got, want)
+        assert "round3_exchange" in timings
+
+
+def test_class_prover_with_transcript_and_bad_witness(oracle):
+    """Fiat-Shamir on every rank (identical transcripts because identical commitments) and the degree check on all ranks."""
+    from distributed_plonk_amd.prover import WrongQuotientPolyDegree
+    log_n, G = 6, 4
+    P, circ, ck, inf, bl, _ = _instance(oracle, 0, log_n, 700)
+    n = 1 << log_n
+    bad = circ["wires"].copy()
+    bad[4, 3] = oracle.rand_fr(0, 5, 1)[0]
+
+    def rank_main(comm, w):
+        w.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, comm)
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            fs = pv.fiat_shamir(circ["pub_input"][:2])
+            proof = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs)
+            raised = False
+            try:
+                pv.prove(bad, circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, pv.fiat_shamir(circ["pub_input"][:2]))
+            except WrongQuotientPolyDegree:
+                raised = True
+            return proof, fs.drawn, raised
+        finally:
+            pv.close()
+
+    results = run_local_ranks(G, rank_main)
+    drawn0 = results[0][1]
+    for proof, drawn, raised in results:
+        assert raised
+        for k in drawn0:
+            assert np.array_equal(drawn[k], drawn0[k])
+    want = P.prove_rounds(0, log_n, ck, inf, circ, bl, drawn0, threads=8)
+    assert _same_point(results[0][0]["opening_proof"], want["opening_proof"])
+    assert _same_point(results[G - 1][0]["shifted_opening_proof"], want["shifted_opening_proof"])
+
+
+def test_class_prover_over_rccl_single_rank(gpu_workers, oracle):
+    """The torch.distributed transport (nccl = RCCL) on the library's stream, world size 1: G = 1 is the degenerate class
+    decomposition (one class = the whole coset), exercising all_to_all_single / all_gather_into_tensor / all_gather_object."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29617")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        log_n = 8
+        P, circ, ck, inf, bl, ch = _instance(oracle, 0, log_n, 800)
+        n = 1 << log_n
+        w = gpu_workers("bn254")
+        w.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, TorchComm(w, torch.device("cuda", 0)))
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+        finally:
+            pv.close()
+        _check(got, P.prove_rounds(0, log_n, ck, inf, circ, bl, ch, threads=8))
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+def test_shard_range_covers_everything():
+    for length in (1, 7, 4099, 1 << 20):
+        for G in (1, 2, 4, 8):
+            edges = [shard_range(length, r, G) for r in range(G)]
+            assert edges[0][0] == 0 and edges[-1][1] == length
+            assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
