@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
+    ap.add_argument("--class-prover", action="store_true",
+                    help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
+                         "opt-in, reported under next_rows, never part of `value`")
     return ap.parse_args()
 
 
@@ -296,6 +299,50 @@ def main():
             next_rows = dict(next_rows or {})
             next_rows["prover_rounds"] = {"error": str(ex)}
 
+    # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
+    class_row = None
+    if args.class_prover:
+        from distributed_plonk_amd.class_prover import ClassProver, TorchComm
+        if world == 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29653")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        n_ck = ((n + 3 + 31) >> 5) << 5
+        ck = w.alloc(n_ck * 16 * q64)
+        w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
+        w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # same key on every rank
+        w.init_dev(ck.ptr, n_ck, n, m)
+        key = w.alloc(18 * n * 32)
+        circ = w.alloc(11 * n * 32)
+        w.synth_fr(0xC1AC, key.ptr, 18 * n)
+        w.synth_fr(0xC1AD, circ.ptr, 10 * n)
+        w.memset_dev(circ.ptr + 10 * n * 32, 0, n * 32)
+        idx = w.alloc(5 * n * 8).upload((np.arange(5 * n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(5 * n))
+        consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
+        ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
+        bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
+        cp = ClassProver(w, args.log_n, TorchComm(w, dev))
+        cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
+        t_cls = None
+        for it in range(2):
+            full_sync()
+            t0 = time.perf_counter()
+            cp.prove_dev([circ.ptr + j * n * 32 for j in range(5)], circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl,
+                         lambda label, _: ch[label], check_degree=False)
+            full_sync()
+            t_cls = (time.perf_counter() - t0) * 1e3
+        if world > 1:
+            tt = torch.tensor([t_cls], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            t_cls = float(tt.item())
+        class_row = {"n": n, "ranks": world, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
+                     "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
+                     "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 13 all-gathers of partial commitments",
+                     "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
+        cp.close()
+        for b in (ck, key, circ, idx):
+            b.free()
+
     # ---- CPU baseline (oracle = C restatement of the reference's arkworks path), bounded sample
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -336,7 +383,7 @@ def main():
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
                         for k, v in sorted(kernels.items())},
             "cpu_baseline": cpu,
-            "next_rows": next_rows,
+            "next_rows": dict(next_rows or {}, class_prover=class_row) if class_row else next_rows,
         }
         print(json.dumps(out))
     for pair in buf_n + buf_m:

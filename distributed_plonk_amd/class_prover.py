@@ -27,7 +27,7 @@ from typing import List, Optional
 
 import numpy as np
 
-from .prover import NUM_WIRE_TYPES, Prover
+from .prover import Prover
 from .worker import PlonkWorker
 
 
@@ -93,16 +93,10 @@ class TorchComm:
         return self.torch.as_tensor(_Buf(), device=self.device)
 
     def _staged(self, ptr: int, nbytes: int):
-        import ctypes as C
-        from ._ffi import check
-        t = self.torch.empty(nbytes // 8, dtype=self.torch.int64)
-        check(self.w.lib.plonk_memcpy_d2h(self.w.ctx, C.c_void_p(t.data_ptr()), ptr, nbytes))
-        return t
+        return self.torch.from_numpy(self.w.read_bytes(ptr, nbytes))
 
     def _unstage(self, t, ptr: int):
-        import ctypes as C
-        from ._ffi import check
-        check(self.w.lib.plonk_memcpy_h2d(self.w.ctx, ptr, C.c_void_p(t.data_ptr()), t.numel() * 8))
+        self.w.write_bytes(ptr, t.numpy())
 
     def all_to_all_dev(self, d_send: int, d_recv: int, nbytes: int):
         total = nbytes * self.size

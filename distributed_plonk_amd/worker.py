@@ -281,6 +281,16 @@ class PlonkWorker:
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 
+    def read_bytes(self, src: int, nbytes: int) -> np.ndarray:
+        """device -> a fresh host array of int64 words (host-staged transports)."""
+        out = np.empty(nbytes // 8, dtype=np.int64)
+        check(self.lib.plonk_memcpy_d2h(self.ctx, _ptr(out), src, nbytes))
+        return out
+
+    def write_bytes(self, dst: int, arr: np.ndarray):
+        a = np.ascontiguousarray(arr)
+        check(self.lib.plonk_memcpy_h2d(self.ctx, dst, _ptr(a), a.nbytes))
+
     def memset_dev(self, dst: int, byte: int, nbytes: int):
         check(self.lib.plonk_memset_dev(self.ctx, dst, byte, nbytes))
 

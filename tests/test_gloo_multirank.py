@@ -87,3 +87,92 @@ def test_two_rank_exchange_and_msm_reduce(log_n, cid):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# --------------------------------------------------------------------------------------------- coset-class decomposition (class_prover.py)
+class _HostMem:
+    """Stands in for PlonkWorker's device memory on a box without a GPU: "pointers" are byte offsets into one numpy arena."""
+
+    def __init__(self, nbytes):
+        self.arena = np.zeros(nbytes // 8, dtype=np.int64)
+
+    def read_bytes(self, src, nbytes):
+        return self.arena[src // 8:(src + nbytes) // 8].copy()
+
+    def write_bytes(self, dst, arr):
+        a = np.ascontiguousarray(arr).view(np.int64).reshape(-1)
+        self.arena[dst // 8:dst // 8 + a.size] = a
+
+
+def _class_rank_main(rank, world, port, log_m, cid, result_q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from distributed_plonk_amd.class_prover import TorchComm, shard_range
+        from oracle import oracle as O
+        from oracle import prover_ref as P
+        f = P.CURVE_OBJ[cid].fr
+        m, G, s = 1 << log_m, world, rank
+        mL = m // G
+        evals = O.rand_fr(cid, 4242, m)                                   # the quotient's coset evaluations (same on every rank)
+        mine = np.ascontiguousarray(evals[s::G])                          # my class
+        # my additive contribution to every coefficient: (1/G) h_s^-i * iNTT_mL(mine)[i mod mL], h_s = g w_m^s
+        E = O.ntt(cid, mine, True, False)
+        w_m = P.fr_from_limbs(f, O.field_const(cid, 0, 4, log_m))
+        h_inv = pow(f.generator * pow(w_m, s, f.p), -1, f.p)
+        pw = np.zeros((m, 4), dtype=np.uint64)
+        pw[0] = P.fr_to_limbs(f, pow(G, -1, f.p))
+        filled = 1
+        while filled < m:
+            step = np.broadcast_to(P.fr_to_limbs(f, pow(h_inv, filled, f.p)), (filled, 4)).copy()
+            pw[filled:2 * filled] = O.field_op(cid, 0, "mul", pw[:filled], step)
+            filled *= 2
+        contrib = O.field_op(cid, 0, "mul", np.tile(E, (G, 1)), pw)
+        # the product's transport: ONE all-to-all (block r -> rank r), local sum, ONE all-gather
+        mem = _HostMem(4 * m * 32)
+        comm = TorchComm(mem, device=None)
+        d_contrib, d_recv, d_mine, d_quot = 0, m * 32, 2 * m * 32, 3 * m * 32
+        mem.write_bytes(d_contrib, contrib)
+        comm.all_to_all_dev(d_contrib, d_recv, mL * 32)
+        recv = mem.read_bytes(d_recv, m * 32).view(np.uint64).reshape(G, mL, 4)
+        acc = recv[0]
+        for p in range(1, G):
+            acc = O.field_op(cid, 0, "add", acc, recv[p])
+        mem.write_bytes(d_mine, acc)
+        comm.all_gather_dev(d_mine, d_quot, mL * 32)
+        quot = mem.read_bytes(d_quot, m * 32).view(np.uint64).reshape(m, 4)
+        ok = bool(np.array_equal(quot, O.ntt(cid, evals, True, True)))    # quot_domain.coset_ifft, dispatcher2.rs:507
+        # partial commitments: my coefficient shard, 96/144-byte all-gather, host add
+        n = 1 << 7
+        bases = O.gen_bases(cid, 11, 32, n)
+        coeffs = O.rand_fr(cid, 13, n - 3)
+        lo, hi = shard_range(coeffs.shape[0], rank, world)
+        part = O.commit_polynomial(cid, bases[lo:hi], coeffs[lo:hi])
+        acc = None
+        for pt in comm.all_gather_host(part):
+            acc = pt if acc is None else O.jac_add(cid, acc, pt)
+        got, gi = O.jac_to_affine(cid, acc)
+        exp, ei = O.jac_to_affine(cid, O.commit_polynomial(cid, bases, coeffs))
+        ok &= bool(gi == ei and np.array_equal(got, exp))
+        result_q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("log_m,cid", [(8, 0), (9, 1)])
+def test_two_rank_coset_class_exchange(log_m, cid):
+    """class_prover.TorchComm over gloo, world size 2: per-class interpolation contributions -> all-to-all -> sum -> all-gather
+    reproduces the whole-domain coset iFFT; sharded commitments add up."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_class_rank_main, args=(rk, 2, port, log_m, cid, q)) for rk in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
