@@ -54,6 +54,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries exactly ONE JSON line: libraries that print there (RCCL's version banner at the first collective) are
+    # sent to stderr by pointing fd 1 at fd 2 for the duration of the run; the result goes out through the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -385,14 +390,14 @@ def main():
             "cpu_baseline": cpu,
             "next_rows": dict(next_rows or {}, class_prover=class_row) if class_row else next_rows,
         }
-        print(json.dumps(out))
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     for pair in buf_n + buf_m:
         for b in pair:
             b.free()
     bases.free()
     for x in workers:
         x.close()
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 
