@@ -588,9 +588,9 @@ struct SumJobs {
     const void* src[16];
     uint64_t count[16];
 };
-#define SUM_SPLIT 16      // workgroups per (level, window) sum: a merged bucket set has 2^17 level-0 values and only one window
+#define SUM_SPLIT_MAX 16  // workgroups per (level, window) sum in merged (table) mode: 2^17 level-0 values and only one window; 1 otherwise
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels,
+__global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels, uint32_t nsplit,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -599,7 +599,7 @@ __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzP
     const uint64_t cnt = jobs.count[l];
     const XyzzL<NL, B>* src = reinterpret_cast<const XyzzL<NL, B>*>(jobs.src[l]) + (uint64_t)w * cnt;
     XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-    for (uint64_t i = (uint64_t)z * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)SUM_SPLIT * blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
+    for (uint64_t i = (uint64_t)z * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)nsplit * blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int d = blockDim.x / 2; d > 0; d >>= 1) {
@@ -609,7 +609,7 @@ __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzP
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_std<NQ>(out + ((uint64_t)w * nlevels + l) * SUM_SPLIT + z, sh[0], P);
+    if (threadIdx.x == 0) store_std<NQ>(out + ((uint64_t)w * nlevels + l) * nsplit + z, sh[0], P);
 }
 
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
@@ -845,7 +845,8 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(BucketL), 256);
     const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
-    const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * SUM_SPLIT * sizeof(XyzzPt<NQ>), 256);
+    const uint32_t nsplit = merged ? SUM_SPLIT_MAX : 1;
+    const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * nsplit * sizeof(XyzzPt<NQ>), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
@@ -924,22 +925,22 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         }
         jobs.src[nlev] = in;            // the single entry left per window: Sigma (nb == 1: the bucket itself)
         jobs.count[nlev] = 1;
-        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr, SUM_SPLIT), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1),
+        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr, nsplit), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1), nsplit,
                            fl_params<NQ>(curve));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
 
-    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * SUM_SPLIT);
+    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * nsplit);
     HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     for (int w = Wr - 1; w >= 0; w--) {
         // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
-        const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1) * SUM_SPLIT;
-        auto part = [&](int l) {                     // the SUM_SPLIT partial sums of (level l, window w)
-            XyzzPt<NQ> t = xyzz_inf<NQ>();
-            for (int z = 0; z < SUM_SPLIT; z++) t = xyzz_add(t, hw[(size_t)l * SUM_SPLIT + z], P);
+        const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1) * nsplit;
+        auto part = [&](int l) {                     // the partial sums of (level l, window w)
+            XyzzPt<NQ> t = hw[(size_t)l * nsplit];
+            for (uint32_t z = 1; z < nsplit; z++) t = xyzz_add(t, hw[(size_t)l * nsplit + z], P);
             return t;
         };
         XyzzPt<NQ> v = xyzz_inf<NQ>();
