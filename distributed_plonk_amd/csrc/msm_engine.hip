@@ -15,15 +15,16 @@
 //   4. accumulate  one lane per bucket walks its segment and adds the resident limb-form bases (negated for
 //                  negative digits) into an XYZZ accumulator held in VGPRs   (msm_accumulate_kernel;
 //                  same-x exceptional additions are redone by msm_accumulate_redo_kernel)
-//   5. reduce      sum_d d*B_d per window: every lane does the running-sum trick on a chunk of K
-//                  buckets and fixes its offset with a small double-and-add   (msm_reduce_chunks_kernel)
-//                  followed by an LDS tree over the chunk sums                (msm_window_sum_kernel)
-//   6. fold        W window sums -> one point (W*c doublings), on the host; the result is returned as
-//                  a normalised Jacobian triple (x, y, 1) / (1, 1, 0).
+//   5. reduce      sum_d d*B_d per window as a pyramid of running-sum passes over chunks of K = 4 entries
+//                  (msm_reduce_level_kernel, fast path + redo), then per-level sums (msm_points_sum_kernel)
+//   6. fold        V_w = Sigma + sum_l 4^l A_l per window and the W window sums -> one point (W*c doublings), on the
+//                  host; the result is returned as a normalised Jacobian triple (x, y, 1) / (1, 1, 0).
+//   (opt.)         a fixed-base window table built at `init` merges all windows into one bucket set (msm_table_kernel);
+//                  measured slower on MI355X and off by default — see the comment there.
 //
 // Zero scalars and digit 0 never touch a bucket (the reference filters zeros too); scalar 1 needs no
 // special case (digit 1 in window 0).  Infinity bases are skipped, P+P and P+(-P) are handled in
-// ec.cuh.  No MFMA: ~10 Fq Montgomery products per (point, window) dominate everything — the
+// ec_lazy.cuh (device) / ec.cuh (host fold).  No MFMA: ~10 Fq Montgomery products per (point, window) dominate everything — the
 // kernel is v_mad_u64_u32 bound; algorithmic HBM bytes are n*(sizeof(affine)+32).
 #include <algorithm>
 #include <cstring>
