@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
+    ap.add_argument("--simulate-ranks", type=int, default=0,
+                    help="diagnostic: run rank 0's share of an S-rank job on ONE GPU with a no-op exchange (results are garbage, "
+                         "timings are one rank's compute without communication)")
     ap.add_argument("--class-prover", action="store_true",
                     help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
                          "opt-in, reported under next_rows, never part of `value`")
@@ -82,6 +85,9 @@ def main():
     n = 1 << args.log_n
     m = 8 * n
     S = world
+    sim = args.simulate_ranks if (world == 1 and args.simulate_ranks > 1) else 0
+    if sim:
+        S = sim
     if (split_rc(n)[0] % S) or (n % S):
         raise SystemExit(f"{S} ranks do not divide r = {split_rc(n)[0]}")
     dev = torch.device("cuda", local_rank)
@@ -91,7 +97,8 @@ def main():
     workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_lanes)]
     w = workers[0]
     q64 = w.q64
-    provers = [RankProver(x, rank, world) for x in workers]
+    noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
+    provers = [RankProver(x, rank, S, exchange=noop_exchange) for x in workers]
 
     # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
     n_loc, m_loc = n // S, m // S
@@ -115,9 +122,14 @@ def main():
             provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
 
+    sim_scalars = None
+    if sim:                                   # the no-op exchange leaves garbage in the NTT outputs: commit to fresh uniform scalars
+        sim_scalars = w.alloc(n_loc * 32)
+        w.synth_fr(0x51A1, sim_scalars.ptr, n_loc)
+
     def commit():
-        part = w.commit_dev(buf_n[0][0].ptr, n_loc)
-        if S == 1:
+        part = w.commit_dev(sim_scalars.ptr if sim else buf_n[0][0].ptr, n_loc)
+        if S == 1 or sim:
             return part
         acc = None
         for p in gather_points(part, None, dev):
@@ -201,7 +213,7 @@ def main():
 
     # ---- next row, measured on its own, NOT part of `value`: quotient coset evaluations over 8n points
     next_rows = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not sim:
         try:
             vecs = [w.alloc(m * 32) for _ in range(25)]
             for j, b in enumerate(vecs):
@@ -350,7 +362,7 @@ def main():
 
     # ---- CPU baseline (oracle = C restatement of the reference's arkworks path), bounded sample
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not sim and not args.no_cpu_baseline:
         from oracle import oracle as O
         cid = O.CURVE_IDS[args.curve]
         ls = min(args.cpu_sample_log_n, args.log_n)
@@ -382,7 +394,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof",
                        "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
-                       "parallelism": "single GPU" if world == 1 else f"{world} ranks: 2-D NTT with RCCL all-to-all, index-sharded MSM"},
+                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic)" if sim else "single GPU") if world == 1
+                                      else f"{world} ranks: 2-D NTT with RCCL all-to-all, index-sharded MSM"},
             "roofline": roofline_entry(dominant) if dominant else None,
             "roofline_other": [roofline_entry(k) for k in roof if k != dominant],
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}

@@ -198,11 +198,13 @@ def gather_points(point: np.ndarray, group=None, device=None) -> List[np.ndarray
 class RankProver:
     """One rank of the multi-GPU path: this process owns one GPU, `rank` of `world` workers."""
 
-    def __init__(self, worker: PlonkWorker, rank: int, world: int, group=None, seed: int = 0xD15EA5E, force_exchange: bool = False):
+    def __init__(self, worker: PlonkWorker, rank: int, world: int, group=None, seed: int = 0xD15EA5E, force_exchange: bool = False,
+                 exchange=None):
         self.w, self.rank, self.world, self.group = worker, rank, world, group
         worker.me = rank
         self._rng = random.Random(seed)          # same seed on every rank -> same task ids
-        self._exchange = make_torch_exchange(group) if (world > 1 or force_exchange) else None
+        # `exchange` overrides the transport (bench.py --simulate-ranks times one rank's compute with a no-op exchange)
+        self._exchange = exchange if exchange is not None else (make_torch_exchange(group) if (world > 1 or force_exchange) else None)
 
     def fft_dev(self, d_rows_ptr: int, d_out_ptr: int, domain_size: int, is_quot: bool, is_inv: bool, is_coset: bool,
                 out_layout: int = 1):
