@@ -200,6 +200,27 @@ def main():
     except Exception:
         pass
 
+    sq_db = {}
+    try:      # VALU instruction counts of the committed PMC pass (same workload: BN254 2^24, one GPU); informational
+        if args.log_n == 24 and args.curve == "bn254" and world == 1:
+            with open(os.path.join(ROOT, "profiles", "r01_pmc_sq_2p24.json")) as f:
+                sq_db = json.load(f)
+    except Exception:
+        pass
+
+    def valu_entry(name, avg_ms):
+        """The roofline that actually binds these kernels: VALU issue.  insts = SQ_INSTS_VALU per launch (launch-weighted
+        over the template instances of `name`); issue_ms = insts * 4.5 clk / (1024 SIMDs * 2.4 GHz), 4.5 clk being the measured
+        issue interval of v_mad_u64_u32 and the carry ops (profiles/r01_valu_microbench.txt) and 2.4 GHz the peak clock (a
+        lower sustained clock raises the fraction; plain VOP2 issues faster, which lowers it)."""
+        rows = [(v["SQ_INSTS_VALU"], v["launches"]) for k, v in sq_db.items() if k.startswith(name) and "redo" not in k and "SQ_INSTS_VALU" in v]
+        if not rows:
+            return None
+        insts = sum(i * l for i, l in rows) / sum(l for _, l in rows)
+        issue_ms = insts * 4.5 / (1024 * 2.4e9) * 1e3
+        return {"insts_per_launch": round(insts), "issue_ms_at_4.5clk": round(issue_ms, 3), "frac_of_launch": round(issue_ms / avg_ms, 3),
+                "source": "profiles/r01_pmc_sq_2p24.json, profiles/r01_valu_microbench.txt"}
+
     def roofline_entry(name):
         r = roof[name]
         achieved = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
@@ -207,7 +228,8 @@ def main():
         return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": round(r["avg_ms"], 4),
-                "share_of_step": round(r["total_ms"] / (ms_per_step * args.steps), 3)}
+                "share_of_step": round(r["total_ms"] / (ms_per_step * args.steps), 3),
+                "valu_issue": valu_entry(name, r["avg_ms"])}
 
     dominant = max(roof, key=lambda k: roof[k]["total_ms"]) if roof else None
 
