@@ -92,6 +92,9 @@ void ntt_tables_destroy(NttTables& T) {
     if (T.quot_x_lo) { (void)hipFree(T.quot_x_lo); T.quot_x_lo = nullptr; }
     for (auto& kv : T.quot_inv_xm1) (void)hipFree(kv.second);
     T.quot_inv_xm1.clear();
+    for (auto& kv : T.pow_tabs) (void)hipFree(kv.second);
+    T.pow_tabs.clear();
+    T.pow_order.clear();
 }
 
 // w^-e * 2^-log_m for e < 2^lt (inverse transforms of size 2^log_m fold their 1/M here)

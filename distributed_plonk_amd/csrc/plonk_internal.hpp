@@ -70,6 +70,9 @@ struct NttTables {
     // quotient.hip: g * w_Nmax^e (constant form) and 1/(x_i - 1) per quotient-domain size (key = log m)
     F29* quot_x_lo = nullptr;
     std::unordered_map<int, Fr*> quot_inv_xm1;     // key: log m | class stride << 8 | class offset << 16
+    // poly_ops.hip: three-level power tables z^i keyed by (z, levels, scale) — FIFO cache
+    std::unordered_map<std::string, F29*> pow_tabs;
+    std::vector<std::string> pow_order;
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };

@@ -19,6 +19,7 @@
 // the totals, phase 3 re-reads the tile, scans it through LDS and applies an epilogue.  All streaming; none of this
 // is on the critical path of the proof-equivalent mix (a few ms at n = 2^24 against ~1 s of NTT + MSM).
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include "constants.h"
@@ -234,18 +235,40 @@ __device__ __forceinline__ F29 pow_at(const PowTab& T, uint64_t i, const F29Para
     return r;
 }
 #define POWTAB_BYTES (3 * 1024 * sizeof(F29))
-static int build_pow_tab(const FrParams& P, const Fr& z_mont, uint64_t len, F29* d_tab, PowTab* out, hipStream_t stream, const Fr* scale_mont = nullptr) {
+// Power tables are cached per context, keyed by (point, levels, scale): the prover evaluates 25 polynomials on the same
+// coset shift and divides by the same (X - zeta) repeatedly; building a table costs ~3000 host products + an upload + a sync.
+#define POWTAB_CACHE_MAX 64
+static int build_pow_tab(NttTables& T, const Fr& z_mont, uint64_t len, PowTab* out, hipStream_t stream, const Fr* scale_mont = nullptr) {
+    const FrParams& P = T.fp;
     const int levels = len <= 1024 ? 1 : (len <= (1u << 20) ? 2 : 3);
-    std::vector<F29> h((size_t)levels * 1024);
-    Fr base = z_mont;
-    for (int l = 0; l < levels; l++) {
-        const Fr mult = (l == 0 && scale_mont) ? *scale_mont : fp_one(P);      // level 0 carries an optional constant factor
-        Fr acc = fp_one(P);
-        for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(fp_mul(acc, mult, P), P); acc = fp_mul(acc, base, P); }
-        base = acc;                       // base^1024
+    std::string key((const char*)z_mont.l, 32);
+    key.push_back((char)levels);
+    if (scale_mont) key.append((const char*)scale_mont->l, 32);
+    F29* d_tab = nullptr;
+    auto it = T.pow_tabs.find(key);
+    if (it != T.pow_tabs.end()) {
+        d_tab = it->second;
+    } else {
+        std::vector<F29> h((size_t)levels * 1024);
+        Fr base = z_mont;
+        for (int l = 0; l < levels; l++) {
+            const Fr mult = (l == 0 && scale_mont) ? *scale_mont : fp_one(P);      // level 0 carries an optional constant factor
+            Fr acc = fp_one(P);
+            for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(fp_mul(acc, mult, P), P); acc = fp_mul(acc, base, P); }
+            base = acc;                       // base^1024
+        }
+        if (T.pow_order.size() >= POWTAB_CACHE_MAX) {          // FIFO eviction; a table may still be in flight on the stream
+            HIP_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(T.pow_tabs[T.pow_order.front()]);
+            T.pow_tabs.erase(T.pow_order.front());
+            T.pow_order.erase(T.pow_order.begin());
+        }
+        HIP_TRY(hipMalloc((void**)&d_tab, POWTAB_BYTES));
+        HIP_TRY(hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        T.pow_tabs[key] = d_tab;
+        T.pow_order.push_back(key);
     }
-    HIP_TRY(hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
     out->t0 = d_tab; out->t1 = d_tab + 1024; out->t2 = d_tab + 2048; out->levels = levels;
     return PLONK_OK;
 }
@@ -417,11 +440,10 @@ int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* 
     if (!fr_arg_ok(point, P)) return plonk_fail(PLONK_ERR_ARG, "poly_eval: point not reduced");
     if (len == 0) { memset(out_host, 0, 32); return PLONK_OK; }
     char* s = (char*)scratch;
-    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
     Fr* partial = (Fr*)s; s += align256(tiles_of(len) * 32);
     Fr* res = (Fr*)s;
     PowTab pw;
-    int rc = build_pow_tab(P, fr_arg(point), len, tab, &pw, stream);
+    int rc = build_pow_tab(T, fr_arg(point), len, &pw, stream);
     if (rc) return rc;
     const PoCtx c = make_ctx(T);
     const uint64_t nb = tiles_of(len);
@@ -522,14 +544,12 @@ int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint
         return PLONK_OK;
     }
     char* s = (char*)scratch;
-    F29* tab_z = (F29*)s; s += align256(POWTAB_BYTES);
-    F29* tab_zi = (F29*)s; s += align256(POWTAB_BYTES);
     Fr* S = (Fr*)s; s += align256(len * 32);
     Fr* btot = (Fr*)s; s += align256(tiles_of(len) * 32);
     Fr* boff = (Fr*)s;
     PowTab pz, pzi;
-    int rc = build_pow_tab(P, z, len, tab_z, &pz, stream);
-    if (!rc) rc = build_pow_tab(P, fp_inv(z, P), len, tab_zi, &pzi, stream);
+    int rc = build_pow_tab(T, z, len, &pz, stream);
+    if (!rc) rc = build_pow_tab(T, fp_inv(z, P), len, &pzi, stream);
     if (rc) return rc;
     const PoCtx c = make_ctx(T);
     {
@@ -587,12 +607,10 @@ int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, co
     if (log_s > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: 2^%d exceeds the two-adicity", log_s);
     if (len > 4 * size) return plonk_fail(PLONK_ERR_ARG, "coset_eval: %zu coefficients for a %zu-point coset (limit 4x)", len, size);
     if (!fr_arg_ok(shift, P)) return plonk_fail(PLONK_ERR_ARG, "coset_eval: shift not reduced");
-    char* s = (char*)scratch;
-    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
-    Fr* tmp = (Fr*)s;
+    Fr* tmp = (Fr*)scratch;
     const Fr h = fr_arg(shift);
     PowTab pw;
-    int rc = build_pow_tab(P, h, size, tab, &pw, stream);
+    int rc = build_pow_tab(T, h, size, &pw, stream);
     if (rc) return rc;
     FoldParams fo;
     memset(&fo, 0, sizeof fo);
@@ -625,12 +643,10 @@ int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* s
     const Fr h = fr_arg(shift);
     if (fp_is_zero(h)) return plonk_fail(PLONK_ERR_ARG, "coset_interp: zero shift");
     if (count == 0) return PLONK_OK;
-    char* s = (char*)scratch;
-    F29* tab = (F29*)s; s += align256(POWTAB_BYTES);
-    Fr* tmp = (Fr*)s;
+    Fr* tmp = (Fr*)scratch;
     const Fr sc = fr_arg(scale);
     PowTab pw;
-    int rc = build_pow_tab(P, fp_inv(h, P), i0 + count, tab, &pw, stream, &sc);
+    int rc = build_pow_tab(T, fp_inv(h, P), i0 + count, &pw, stream, &sc);
     if (rc) return rc;
     NttCall call;
     call.in = (const Fr*)d_evals; call.out = tmp; call.log_m = log_s; call.batch = 1; call.inverse = true;     // includes the 1/size factor

@@ -56,11 +56,19 @@ class FiatShamir:
 class Prover:
     """One GPU.  `worker.init(ck, n, 8n)` must have been called with the commit key padded as dispatcher2.rs:207-208."""
 
-    def __init__(self, worker: PlonkWorker, log_n: int, cache_key_cosets: bool = False):
+    def __init__(self, worker: PlonkWorker, log_n: int, cache_key_cosets: bool = False, quotient_mode: str = "coset8n"):
+        """quotient_mode "coset8n": round 3 exactly as the reference does it (25 coset FFTs over the 8n-point domain, one coset
+        iFFT).  "classes6": the same quotient polynomial from 6n evaluations — see _quotient_poly_classes."""
         self.w = worker
         self.f = _fr.FIELDS[worker.curve_name]
         self.log_n, self.n, self.m = log_n, 1 << log_n, 8 << log_n
         self.cache_key_cosets = cache_key_cosets
+        if quotient_mode not in ("coset8n", "classes6"):
+            raise ValueError(quotient_mode)
+        if quotient_mode == "classes6" and self.n < 16:
+            raise ValueError("classes6 needs n >= 16: below that 5n+7 >= 6n-1 and the degree check of dispatcher2.rs:511-518 is vacuous")
+        self.quotient_mode = quotient_mode
+        self._cls = None
         self._key = None
         self._bufs = []
         self._ws: Dict[str, object] = {}      # named work buffers, allocated by the first proof and reused (hipMalloc of ~100 GiB takes seconds)
@@ -105,7 +113,15 @@ class Prover:
         k = np.ascontiguousarray(k, dtype=np.uint64)
         assert len(sel_ptrs) == NUM_SELECTORS and len(sig_ptrs) == NUM_WIRE_TYPES and k.shape == (NUM_WIRE_TYPES, 4)
         self._key = dict(sel=[int(x) for x in sel_ptrs], sig=[int(x) for x in sig_ptrs], k=k, cos=None, vk=None)
-        if self.cache_key_cosets:
+        if self.cache_key_cosets and self.quotient_mode == "classes6":
+            cls = self._class_setup()
+            cos = self._alloc(18 * cls["ncls"] * n)
+            ptrs = [[cos.ptr + (j * cls["ncls"] + c) * n * 32 for c in range(cls["ncls"])] for j in range(18)]
+            for j, src in enumerate(self._key["sel"] + self._key["sig"]):
+                for c in range(cls["ncls"]):
+                    self.w.coset_eval_dev(src, n, n, cls["shift"][c], ptrs[j][c])
+            self._key["cos"] = ptrs
+        elif self.cache_key_cosets:
             cos = self._alloc(18 * m)
             tmp = self._alloc(m)
             ptrs = [cos.ptr + j * m * 32 for j in range(18)]
@@ -154,9 +170,74 @@ class Prover:
         check(self.w.lib.plonk_memcpy_d2h(self.w.ctx, out.ctypes.data_as(C.c_void_p), d_ptr, out.nbytes))
         return out
 
+    # ---- the quotient from 6n evaluations instead of 8n
+    def _class_setup(self):
+        """The quotient has degree 5n+7 < 6n, so its values on SIX of the eight cosets  h_s * H_n  (h_s = g * w_m^s) of the
+        reference's 8n-point domain determine it.  Writing t(X) = sum_{u<6} X^{un} t_u(X), deg t_u < n: on coset s, X^n is the
+        constant c_s = h_s^n, so the size-n interpolant on that coset is P_s = sum_u c_s^u t_u — a 6x6 Vandermonde system per
+        coefficient index, inverted once on the host."""
+        if self._cls is None:
+            f, n, m = self.f, self.n, self.m
+            p = f.p
+            ncls = 6
+            w_m = f.root_of_unity(m)
+            h = [f.generator * pow(w_m, s, p) % p for s in range(ncls)]
+            c = [pow(x, n, p) for x in h]
+            # inverse of V[s][u] = c_s^u by Gauss-Jordan mod p
+            V = [[pow(c[s], u, p) for u in range(ncls)] + [1 if s == t else 0 for t in range(ncls)] for s in range(ncls)]
+            for col in range(ncls):
+                piv = next(r for r in range(col, ncls) if V[r][col])
+                V[col], V[piv] = V[piv], V[col]
+                inv = pow(V[col][col], -1, p)
+                V[col] = [x * inv % p for x in V[col]]
+                for r in range(ncls):
+                    if r != col and V[r][col]:
+                        fac = V[r][col]
+                        V[r] = [(x - fac * y) % p for x, y in zip(V[r], V[col])]
+            vinv = [row[ncls:] for row in V]                                   # vinv[u][s]
+            self._cls = dict(ncls=ncls, shift=[f.to_limbs(x) for x in h], one=f.to_limbs(1),
+                             vinv=[f.vec_to_limbs(row) for row in vinv])
+        return self._cls
+
+    def _quotient_poly_classes(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
+        w, n, m, key = self.w, self.n, self.m, self._key
+        cls = self._class_setup()
+        C = cls["ncls"]
+        t0 = time.perf_counter()
+        if key["cos"] is None:
+            d_kc = alloc(18 * C * n)
+            kc = [[d_kc.ptr + (j * C + c) * n * 32 for c in range(C)] for j in range(18)]
+            for j, src in enumerate(key["sel"] + key["sig"]):
+                for c in range(C):
+                    w.coset_eval_dev(src, n, n, cls["shift"][c], kc[j][c])
+        else:
+            kc = key["cos"]
+        d_c = alloc(7 * C * n)
+        cw = [[d_c.ptr + (j * C + c) * n * 32 for c in range(C)] for j in range(7)]
+        for j, (ptr, ln) in enumerate(list(wire_polys) + [perm_poly, pi_poly]):
+            for c in range(C):
+                w.coset_eval_dev(ptr, ln, n, cls["shift"][c], cw[j][c])         # n+2 / n+3 coefficients fold onto n
+        tick("round3_coset_ffts", t0)
+        t0 = time.perf_counter()
+        d_qev = alloc(n)
+        d_P = alloc(C * n)
+        for c in range(C):
+            w.quotient_evals_dev([kc[j][c] for j in range(13)], [kc[13 + j][c] for j in range(5)], [cw[j][c] for j in range(5)], cw[5][c], cw[6][c],
+                                 alpha, beta, gamma, key["k"], d_qev.ptr, class_stride=m // n, class_offset=c)
+            w.coset_interp_dev(d_qev.ptr, n, cls["shift"][c], cls["one"], 0, n, d_P.ptr + c * n * 32)      # P_c = t mod (X^n - c_c)
+        d_quot = alloc(m)
+        w.memset_dev(d_quot.ptr + C * n * 32, 0, (m - C * n) * 32)
+        terms = [(d_P.ptr + c * n * 32, n) for c in range(C)]
+        for u in range(C):
+            w.poly_lincomb_dev(terms, cls["vinv"][u], d_quot.ptr + u * n * 32, n)     # t_u = sum_s Vinv[u][s] P_s
+        tick("round3_quotient", t0)
+        return d_quot.ptr
+
     def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
         """Round 3 between the challenges and the split commitments (dispatcher2.rs:362-509): 25 coset FFTs over the 8n domain,
         the pointwise quotient evaluation, one coset iFFT.  Returns a device pointer to the m quotient coefficients."""
+        if self.quotient_mode == "classes6":
+            return self._quotient_poly_classes(alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma)
         w, n, m, key = self.w, self.n, self.m, self._key
         t0 = time.perf_counter()
         d_tmp = alloc(m)

@@ -113,3 +113,37 @@ def test_prover_with_real_transcript(gpu_workers, oracle, curve, cid):
         assert not np.array_equal(fs3("beta", got), ch["beta"])
     finally:
         pv.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,cache", [(4, False), (8, True), (11, False)])
+def test_prover_six_coset_quotient_matches_oracle(gpu_workers, oracle, curve, cid, log_n, cache):
+    """quotient_mode="classes6": the quotient polynomial interpolated from 6 of the 8 cosets of H_n in the 8n-point domain
+    (6n evaluations instead of 8n).  It is the same polynomial, so every output must still equal the reference's."""
+    P, circ, ck, inf, bl, ch = _instance(oracle, cid, log_n, 900 + log_n)
+    n = 1 << log_n
+    w = gpu_workers(curve)
+    w.init(ck, n, 8 * n)
+    pv = Prover(w, log_n, cache_key_cosets=cache, quotient_mode="classes6")
+    try:
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        for _ in range(2):
+            got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+        want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=16)
+        for key in ("wires_poly_comms", "split_quot_poly_comms"):
+            for g, x in zip(got[key], want[key]):
+                assert _same_point(g, x), key
+        for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+            assert _same_point(got[key], want[key]), key
+        assert np.array_equal(np.stack(got["wires_evals"]), np.stack(want["wires_evals"]))
+        for key in ("quot_poly", "lin_poly", "batch_poly"):
+            assert np.array_equal(got["_debug"][key], want[key]), key
+        # an unsatisfied witness still fails the degree check
+        bad = circ["wires"].copy()
+        bad[4, 1] = oracle.rand_fr(cid, 4321, 1)[0]
+        with pytest.raises(WrongQuotientPolyDegree):
+            pv.prove(bad, circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
+        with pytest.raises(ValueError):
+            Prover(w, 3, quotient_mode="classes6")             # n = 8: 5n+7 = 6n-1, the degree check would be vacuous
+    finally:
+        pv.close()
