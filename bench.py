@@ -308,30 +308,37 @@ def main():
             w.profile_enable(False)
             out_n.free()
             pv.close()
-            # the same rounds with the 18 proving-key coset vectors kept resident across proofs (72 GiB at 2^24)
-            t_cached, rounds_cached = None, None
-            try:
-                pvc = Prover(w, args.log_n, cache_key_cosets=True)
-                pvc.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
-                for it in range(2):
-                    t0 = time.perf_counter()
-                    pvc.prove_dev(wev, circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl, lambda label, _: ch[label], check_degree=False)
-                    t_cached = (time.perf_counter() - t0) * 1e3
-                rounds_cached = {k_: round(v_, 2) for k_, v_ in pvc.timings.items()}
-                pvc.close()
-            except Exception as ex:
-                rounds_cached = {"error": str(ex)}
+            # variants of the same rounds (identical proofs): the quotient from 6 cosets of H_n instead of the 8n-point domain,
+            # and/or the 18 proving-key evaluation vectors kept resident across proofs (72 / 54 GiB at 2^24)
+            variants = {}
+            for vname, kw in (("resident_key_cosets", dict(cache_key_cosets=True)),
+                              ("six_cosets", dict(quotient_mode="classes6")),
+                              ("six_cosets_resident_key", dict(quotient_mode="classes6", cache_key_cosets=True))):
+                try:
+                    pvc = Prover(w, args.log_n, **kw)
+                    pvc.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
+                    t_v = None
+                    for it in range(2):
+                        t0 = time.perf_counter()
+                        pvc.prove_dev(wev, circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl, lambda label, _: ch[label], check_degree=False)
+                        t_v = (time.perf_counter() - t0) * 1e3
+                    variants[vname] = {"ms": round(t_v, 2), "constraints_per_s": round(n / t_v * 1e3, 1),
+                                       "rounds_ms": {k_: round(v_, 2) for k_, v_ in pvc.timings.items()}}
+                    pvc.close()
+                except Exception as ex:
+                    variants[vname] = {"error": str(ex)}
             next_rows = dict(next_rows or {})
             next_rows.update(small)
             next_rows["prover_rounds"] = {
                 "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
                 "rounds_ms": rounds,
-                "ms_with_resident_key_cosets": round(t_cached, 2) if t_cached else None, "rounds_ms_with_resident_key_cosets": rounds_cached,
+                "variants": variants,
                 "reference": "dispatcher2.rs:296-712 (rounds 1-5: 13 commitments, 7 NTT(n), 26 NTT(8n), permutation product, quotient, "
                              "10 evaluations, linearisation, 2 openings)",
                 "note": "synthetic circuit-shaped inputs (random wires/selectors, fixed challenges): identical work to a real proof; "
-                        "the quotient-degree check is skipped because random wires do not satisfy the gates.  The resident-key "
-                        "variant skips the 18 selector/sigma coset NTTs per proof (proving-key data, 72 GiB at 2^24)"}
+                        "the quotient-degree check is skipped because random wires do not satisfy the gates.  Variants produce the "
+                        "same proof: resident_key_cosets skips the 18 selector/sigma coset NTTs per proof (proving-key data); six_cosets "
+                        "interpolates the degree-(5n+7) quotient from 6n evaluations (6 cosets of H_n) instead of the 8n-point domain"}
             for b in (ck, key, circ, idx):
                 b.free()
         except Exception as ex:
