@@ -1,7 +1,7 @@
 """Fiat-Shamir transcript and canonical serialization of the reference prover, host side.
 
 What it mirrors: `FakeStandardTranscript` (/root/reference/src/dispatcher2.rs:44-154), a wrapper of `merlin::Transcript`
-(merlin 2.x: STROBE-128 over Keccak-f[1600], Cargo.lock pins merlin; both are un-vendored third-party crates), and
+(merlin 3.0.0, Cargo.toml:40: STROBE-128 over Keccak-f[1600]; an un-vendored third-party crate), and
 `jf_utils::to_bytes!` = ark-serialize 0.3 `CanonicalSerialize::serialize` (compressed):
   * Fr            32 bytes little-endian of the canonical (non-Montgomery) integer
   * G1Affine      the x coordinate little-endian (32 B BN254 / 48 B BLS12-381) with SWFlags in the two top bits of the
@@ -167,6 +167,22 @@ def serialize_g1(curve: str, xy, is_inf: bool) -> bytes:
     if y > (q - y) % q:                      # SWFlags::from_y_sign(self.y > -self.y)
         out[-1] |= 1 << 7
     return bytes(out)
+
+
+def serialize_proof(curve: str, proof: dict) -> bytes:
+    """`CanonicalSerialize::serialize` of jf-plonk 0.1.1's `Proof<E>` as built at dispatcher2.rs:699-710 — derive order of the
+    struct fields [upstream: jellyfish turbo-plonk branch, Cargo.lock:801-803, not vendored]: wires_poly_comms: Vec<Commitment>,
+    prod_perm_poly_comm, split_quot_poly_comms: Vec<Commitment>, opening_proof, shifted_opening_proof, poly_evals
+    { wires_evals: Vec<Fr>, wire_sigma_evals: Vec<Fr>, perm_next_eval }.  A Vec is its length as u64 little-endian followed
+    by the elements (ark-serialize 0.3)."""
+    def vec(items, enc):
+        return len(items).to_bytes(8, "little") + b"".join(enc(x) for x in items)
+
+    pt = lambda c: serialize_g1(curve, *c)
+    fe = lambda x: serialize_fr(curve, x)
+    return (vec(proof["wires_poly_comms"], pt) + pt(proof["prod_perm_poly_comm"]) + vec(proof["split_quot_poly_comms"], pt)
+            + pt(proof["opening_proof"]) + pt(proof["shifted_opening_proof"])
+            + vec(proof["wires_evals"], fe) + vec(proof["wire_sigma_evals"], fe) + fe(proof["perm_next_eval"]))
 
 
 # --------------------------------------------------------------------------------------------- the PLONK transcript

@@ -91,3 +91,18 @@ def test_plonk_transcript_challenges_are_reduced_and_chained():
     t2.append_vk_and_pub_input(8, 2, [one] * 5, [pt] * 13, [pt] * 5, [one, one])
     t2.append_commitments(b"witness_poly_comms", [pt] * 5)
     assert np.array_equal(t2.get_and_append_challenge(b"beta"), beta)
+
+
+def test_serialize_proof_layout():
+    """13 compressed points + 10 field elements + four u64 length prefixes (BN254: 416 + 320 + 32 bytes)."""
+    f = FR.FIELDS["bn254"]
+    q = T.FQ_MODULI["bn254"]
+    pt = (np.array(_mont(4, 1, q) + _mont(4, 2, q), dtype=np.uint64), False)
+    inf = (np.zeros(8, dtype=np.uint64), True)
+    proof = dict(wires_poly_comms=[pt] * 5, prod_perm_poly_comm=inf, split_quot_poly_comms=[pt] * 5, opening_proof=pt, shifted_opening_proof=pt,
+                 wires_evals=[f.to_limbs(i + 1) for i in range(5)], wire_sigma_evals=[f.to_limbs(9)] * 4, perm_next_eval=f.to_limbs(7))
+    b = T.serialize_proof("bn254", proof)
+    assert len(b) == 13 * 32 + 10 * 32 + 4 * 8
+    assert b[:8] == (5).to_bytes(8, "little") and b[8:40] == (1).to_bytes(32, "little")
+    assert b[8 + 5 * 32:8 + 6 * 32] == bytes(31) + b"\x40"                   # the infinity commitment
+    assert b[-32:] == (7).to_bytes(32, "little")
