@@ -94,11 +94,14 @@ def main():
     # N > 1: two contexts (two HIP streams) per rank, so that the all-to-all of one transform overlaps the
     # row / column passes of the next (the 26 size-8n transforms of a proof are independent polynomials)
     n_lanes = 2 if S > 1 else 1
-    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_lanes)]
+    # always two contexts for the commitments: the 13 MSMs of a proof are independent, and a second stream fills the sort /
+    # reduction phases and the wave tail of one MSM with the bucket accumulation of the next (measured: 29.3 -> 26.8 ms per
+    # 2^24-point commit, 4.9 -> 4.0 ms at the 2^21 points of an 8-rank shard; tools/msm_overlap.py)
+    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(2)]
     w = workers[0]
     q64 = w.q64
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
-    provers = [RankProver(x, rank, S, exchange=noop_exchange) for x in workers]
+    provers = [RankProver(x, rank, S, exchange=noop_exchange) for x in workers[:n_lanes]]
 
     # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
     n_loc, m_loc = n // S, m // S
@@ -110,10 +113,9 @@ def main():
     bases = w.alloc(n_loc * 16 * q64)
     # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
     w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
-    w.init_dev(bases.ptr, n_loc, n, m)
-    for x in workers[1:]:
-        x.init_dev(bases.ptr, 0, n, m)          # domains only: the MSMs run on lane 0
-    w.sync()
+    for x in workers:
+        x.init_dev(bases.ptr, n_loc, n, m)      # both contexts hold the SRS shard in the resident limb form
+        x.sync()
 
     def ntt(lane, bufs, size, inv, coset, is_quot):
         if S == 1:
@@ -127,14 +129,38 @@ def main():
         sim_scalars = w.alloc(n_loc * 32)
         w.synth_fr(0x51A1, sim_scalars.ptr, n_loc)
 
-    def commit():
-        part = w.commit_dev(sim_scalars.ptr if sim else buf_n[0][0].ptr, n_loc)
+    import threading
+
+    def commits(count):
+        """`count` commitments to this rank's scalar shard, alternating between the two contexts from two host threads; for
+        S > 1 the partial points are reduced across ranks with ONE all-gather of count * 96/144 bytes (dispatcher.rs:236-238)."""
+        src = sim_scalars.ptr if sim else buf_n[0][0].ptr
+        parts = [None] * count
+        errs = []
+
+        def run(lane):
+            try:
+                for i in range(lane, count, 2):
+                    parts[i] = workers[lane].commit_dev(src, n_loc)
+            except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
+                errs.append(ex)
+
+        th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        if errs:
+            raise errs[0]
         if S == 1 or sim:
-            return part
-        acc = None
-        for p in gather_points(part, None, dev):
-            acc = p if acc is None else w.g1_add(acc, p)
-        return acc
+            return parts[-1]
+        gathered = gather_points(np.concatenate(parts), None, dev)          # one collective for all partial points
+        acc = [None] * count
+        for p in gathered:                                                   # reduce(a + b) per commitment, on the host
+            for i in range(count):
+                pt = p[i * 3 * q64:(i + 1) * 3 * q64]
+                acc[i] = pt if acc[i] is None else w.g1_add(acc[i], pt)
+        return acc[-1]
 
     def step():
         for i in range(N_NTT_SMALL):
@@ -142,12 +168,9 @@ def main():
         for i in range(N_NTT_BIG - 1):
             ntt(i % n_lanes, buf_m[i % n_lanes], m, False, True, True)
         ntt(0, buf_m[0], m, True, True, True)
-        for x in workers[1:]:
-            x.sync()                              # the commitments read lane-0 buffers only; keep lanes in step
-        last = None
-        for _ in range(N_MSM):
-            last = commit()
-        return last
+        for x in workers:
+            x.sync()                              # the commitments read lane-0 buffers from both contexts
+        return commits(N_MSM)
 
     def full_sync():
         for x in workers:
@@ -265,7 +288,8 @@ def main():
             ck = w.alloc(n_ck * 16 * q64)
             w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
             w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)
-            w.init_dev(ck.ptr, n_ck, n, m)
+            for x in workers:
+                x.init_dev(ck.ptr, n_ck, n, m)
             key = w.alloc(18 * n * 32)
             circ = w.alloc(11 * n * 32)                                       # wires[5], id_perm[5], pub_input
             w.synth_fr(0xC1AC, key.ptr, 18 * n)
@@ -275,7 +299,7 @@ def main():
             consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
             ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
             bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-            pv = Prover(w, args.log_n)
+            pv = Prover(w, args.log_n, commit_helper=workers[1])
             pv.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
             wev = [circ.ptr + j * n * 32 for j in range(5)]
             for it in range(2):
@@ -315,7 +339,7 @@ def main():
                               ("six_cosets", dict(quotient_mode="classes6")),
                               ("six_cosets_resident_key", dict(quotient_mode="classes6", cache_key_cosets=True))):
                 try:
-                    pvc = Prover(w, args.log_n, **kw)
+                    pvc = Prover(w, args.log_n, commit_helper=workers[1], **kw)
                     pvc.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
                     t_v = None
                     for it in range(2):

@@ -153,6 +153,9 @@ class ClassProver(Prover):
             acc = p if acc is None else self.w.g1_add(acc, p)
         return self.w.g1_to_affine(acc)
 
+    def _commit_many(self, items):
+        return [self._commit(ptr, ln) for ptr, ln in items]      # collectives inside: strictly in program order
+
     # ---- the quotient's degree: every rank holds the whole polynomial after the all-gather
     def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
         w, n, m, key, G, s = self.w, self.n, self.m, self._key, self.G, self.s

@@ -25,6 +25,7 @@ extern "C" const char* plonk_last_error(void) { return g_err; }
 // ---------------------------------------------------------------------------------------------- per-kernel timing
 KernelProfiler& kernel_profiler() { static KernelProfiler p; return p; }
 void KernelProfiler::resolve() {
+    std::lock_guard<std::mutex> g(mu);
     for (auto& r : pending) {
         float ms = 0;
         if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
@@ -35,7 +36,7 @@ void KernelProfiler::resolve() {
     }
     pending.clear();
 }
-void KernelProfiler::reset() { resolve(); totals.clear(); }
+void KernelProfiler::reset() { resolve(); std::lock_guard<std::mutex> g(mu); totals.clear(); }
 
 // ---------------------------------------------------------------------------------------------- context
 struct FftTask {          // reference FftTask, worker.rs:32-40

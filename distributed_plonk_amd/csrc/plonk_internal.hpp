@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -30,7 +31,8 @@ int plonk_fail(int code, const char* fmt, ...);
 // ----------------------------------------------------------------------------------------------- per-kernel timing
 // HIP-event timing of individual kernel launches on the stream they are launched on (bench.py's
 // roofline leg).  Disabled by default (no events are created).
-struct KernelProfiler {
+struct KernelProfiler {       // process-wide; contexts on different host threads record into it concurrently
+    std::mutex mu;
     bool enabled = false;
     struct Rec { const char* name; hipEvent_t a, b; };
     std::vector<Rec> pending;
@@ -45,7 +47,11 @@ struct ProfScope {       // RAII: brackets the launches issued in its lifetime
         if (on) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, stream); }
     }
     ~ProfScope() {
-        if (on) { (void)hipEventRecord(b, stream); kernel_profiler().pending.push_back({name, a, b}); }
+        if (on) {
+            (void)hipEventRecord(b, stream);
+            std::lock_guard<std::mutex> g(kernel_profiler().mu);
+            kernel_profiler().pending.push_back({name, a, b});
+        }
     }
 };
 

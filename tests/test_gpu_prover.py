@@ -124,7 +124,11 @@ def test_prover_six_coset_quotient_matches_oracle(gpu_workers, oracle, curve, ci
     n = 1 << log_n
     w = gpu_workers(curve)
     w.init(ck, n, 8 * n)
-    pv = Prover(w, log_n, cache_key_cosets=cache, quotient_mode="classes6")
+    from distributed_plonk_amd.worker import PlonkWorker
+    helper = PlonkWorker(curve=curve) if cache else None   # exercise the two-stream commitments in half of the cases
+    if helper is not None:
+        helper.init(ck, n, 8 * n)
+    pv = Prover(w, log_n, cache_key_cosets=cache, quotient_mode="classes6", commit_helper=helper)
     try:
         pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
         for _ in range(2):
@@ -147,3 +151,5 @@ def test_prover_six_coset_quotient_matches_oracle(gpu_workers, oracle, curve, ci
             Prover(w, 3, quotient_mode="classes6")             # n = 8: 5n+7 = 6n-1, the degree check would be vacuous
     finally:
         pv.close()
+        if helper is not None:
+            helper.close()
