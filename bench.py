@@ -131,9 +131,9 @@ def main():
 
     import threading
 
-    def commits(count):
-        """`count` commitments to this rank's scalar shard, alternating between the two contexts from two host threads; for
-        S > 1 the partial points are reduced across ranks with ONE all-gather of count * 96/144 bytes (dispatcher.rs:236-238)."""
+    cworkers = workers
+
+    def commits_start(count):
         src = sim_scalars.ptr if sim else buf_n[0][0].ptr
         parts = [None] * count
         errs = []
@@ -141,13 +141,18 @@ def main():
         def run(lane):
             try:
                 for i in range(lane, count, 2):
-                    parts[i] = workers[lane].commit_dev(src, n_loc)
+                    parts[i] = cworkers[lane].commit_dev(src, n_loc)
             except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
                 errs.append(ex)
 
         th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
         for t_ in th:
             t_.start()
+        return th, parts, errs
+
+    def commits_finish(handle):
+        th, parts, errs = handle
+        count = len(parts)
         for t_ in th:
             t_.join()
         if errs:
@@ -170,10 +175,12 @@ def main():
         ntt(0, buf_m[0], m, True, True, True)
         for x in workers:
             x.sync()                              # the commitments read lane-0 buffers from both contexts
-        return commits(N_MSM)
+        # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
+        #  distorting the per-launch NTT timings the roofline is computed from)
+        return commits_finish(commits_start(N_MSM))
 
     def full_sync():
-        for x in workers:
+        for x in set(workers) | set(cworkers):
             x.sync()
         torch.cuda.synchronize()
         if world > 1:
