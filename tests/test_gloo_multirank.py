@@ -176,3 +176,59 @@ def test_two_rank_coset_class_exchange(log_m, cid):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(results) == [(0, True), (1, True)]
+
+
+# --------------------------------------------------------------------------------------------- the whole class prover, SPMD over gloo
+def _prover_rank_main(rank, world, port, log_n, cid, result_q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_worker import CpuWorker
+        from distributed_plonk_amd.class_prover import ClassProver, TorchComm
+        from oracle import oracle as O
+        from oracle import prover_ref as P
+        curve = {0: "bn254", 1: "bls12_381"}[cid]
+        n = 1 << log_n
+        circ = P.make_circuit(cid, log_n, seed=77)                      # identical on every rank
+        ck, inf = P.make_ck(cid, n, seed=78, unique=8)
+        bl = dict(wires=O.rand_fr(cid, 1, 10).reshape(5, 2, 4), perm=O.rand_fr(cid, 2, 3))
+        w = CpuWorker(curve, me=rank)
+        w.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, TorchComm(w, device=None))
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        fs = pv.fiat_shamir(circ["pub_input"][:2])                      # every rank runs its own transcript
+        got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs, keep=True)
+        want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, fs.drawn)
+        same = lambda a, b: a[1] == b[1] and np.array_equal(a[0], b[0])
+        ok = all(same(g, x) for g, x in zip(got["wires_poly_comms"], want["wires_poly_comms"]))
+        ok &= all(same(g, x) for g, x in zip(got["split_quot_poly_comms"], want["split_quot_poly_comms"]))
+        ok &= same(got["prod_perm_poly_comm"], want["prod_perm_poly_comm"])
+        ok &= same(got["opening_proof"], want["opening_proof"]) and same(got["shifted_opening_proof"], want["shifted_opening_proof"])
+        ok &= bool(np.array_equal(np.stack(got["wires_evals"]), np.stack(want["wires_evals"])))
+        ok &= bool(np.array_equal(got["_debug"]["quot_poly"], want["quot_poly"]))
+        result_q.put((rank, bool(ok), fs.drawn["v"].tobytes()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,log_n,cid", [(2, 4, 0), (4, 5, 1)])
+def test_class_prover_spmd_over_gloo(world, log_n, cid):
+    """distributed_plonk_amd.class_prover.ClassProver end to end as `world` processes over gloo: the product's SPMD orchestration
+    and torch.distributed calls run for real (host-staged tensors); each rank's device work is done by the oracle through the
+    test-only stand-in tests/cpu_worker.py.  Every rank must produce the oracle prover's proof and draw the same challenges."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_prover_rank_main, args=(rk, world, port, log_n, cid, q)) for rk in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world))
+    assert all(r[1] for r in results)
+    assert len({r[2] for r in results}) == 1            # identical transcripts on all ranks
