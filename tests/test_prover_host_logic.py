@@ -1,0 +1,83 @@
+"""The host side of distributed_plonk_amd.prover (round sequencing, challenge points, linearisation coefficients, the 6-coset
+Vandermonde reconstruction, two-lane commitments, Fiat-Shamir) on CPU: the device calls are served by the oracle through the
+test-only stand-in tests/cpu_worker.py, so a mistake in the orchestration shows up without a GPU.  The same flows run on the
+real library in tests/test_gpu_prover.py."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from cpu_worker import CpuWorker  # noqa: E402
+
+from distributed_plonk_amd.prover import Prover, WrongQuotientPolyDegree  # noqa: E402
+from distributed_plonk_amd.transcript import serialize_proof  # noqa: E402
+
+
+def _instance(oracle, cid, log_n, seed):
+    from oracle import prover_ref as P
+    n = 1 << log_n
+    circ = P.make_circuit(cid, log_n, seed=seed)
+    ck, inf = P.make_ck(cid, n, seed=seed + 1, unique=8)
+    bl = dict(wires=oracle.rand_fr(cid, seed + 2, 10).reshape(5, 2, 4), perm=oracle.rand_fr(cid, seed + 3, 3))
+    return P, circ, ck, inf, bl
+
+
+def _same(a, b):
+    return a[1] == b[1] and np.array_equal(a[0], b[0])
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("mode,cache,two_lanes", [("coset8n", False, False), ("coset8n", True, True), ("classes6", False, True), ("classes6", True, False)])
+def test_prover_rounds_on_cpu_stand_in(oracle, curve, cid, mode, cache, two_lanes):
+    log_n = 4
+    n = 1 << log_n
+    P, circ, ck, inf, bl = _instance(oracle, cid, log_n, 1234)
+    w = CpuWorker(curve)
+    w.init(ck, n, 8 * n)
+    helper = None
+    if two_lanes:                       # shares the arena: both "contexts" see the same device memory, as on a GPU
+        helper = CpuWorker(curve)
+        helper.arena, helper.top = w.arena, w.top
+        helper.init(ck, n, 8 * n)
+    pv = Prover(w, log_n, cache_key_cosets=cache, quotient_mode=mode, commit_helper=helper)
+    pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+    fs = pv.fiat_shamir(circ["pub_input"][:2])
+    got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs, keep=True)
+    want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, fs.drawn)
+    for key in ("wires_poly_comms", "split_quot_poly_comms"):
+        assert all(_same(g, x) for g, x in zip(got[key], want[key])), key
+    for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+        assert _same(got[key], want[key]), key
+    for key in ("wires_evals", "wire_sigma_evals"):
+        assert np.array_equal(np.stack(got[key]), np.stack(want[key])), key
+    assert np.array_equal(got["perm_next_eval"], want["perm_next_eval"])
+    for key in ("perm_product", "perm_poly", "quot_poly", "lin_poly", "batch_poly"):
+        assert np.array_equal(got["_debug"][key], want[key]), key
+    # proof bytes: 13 compressed points, 10 field elements, 4 length prefixes
+    q_bytes = 32 if curve == "bn254" else 48
+    assert len(serialize_proof(curve, got)) == 13 * q_bytes + 10 * 32 + 4 * 8
+    # a second proof with a broken witness is rejected by the degree check
+    bad = circ["wires"].copy()
+    bad[4, 2] = oracle.rand_fr(cid, 99, 1)[0]
+    with pytest.raises(WrongQuotientPolyDegree):
+        pv.prove(bad, circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, pv.fiat_shamir(circ["pub_input"][:2]))
+    pv.close()
+
+
+def test_six_coset_vandermonde_is_inverted(oracle):
+    """V[s][u] = c_s^u with c_s = (g w_m^s)^n; the host-side inverse used by quotient_mode="classes6"."""
+    w = CpuWorker("bn254")
+    pv = Prover(w, 6, quotient_mode="classes6")
+    cls = pv._class_setup()
+    f, n, m, p = pv.f, pv.n, pv.m, pv.f.p
+    w_m = f.root_of_unity(m)
+    c = [pow(f.generator * pow(w_m, s, p) % p, n, p) for s in range(6)]
+    vinv = [[f.from_limbs(x) for x in row] for row in cls["vinv"]]
+    for u in range(6):
+        for t in range(6):
+            assert sum(vinv[u][s] * pow(c[s], t, p) for s in range(6)) % p == (1 if u == t else 0)
+    assert len(set(c)) == 6
+    with pytest.raises(ValueError):
+        Prover(w, 3, quotient_mode="classes6")
