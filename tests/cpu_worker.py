@@ -43,24 +43,35 @@ class CpuBuffer:
         self.ptr = None
 
 
+class _Arena:
+    def __init__(self, nbytes):
+        self.mem = np.zeros(nbytes // 8, dtype=np.uint64)
+        self.top = 0
+
+
 class CpuWorker:
-    def __init__(self, curve="bn254", arena_bytes=64 << 20, me=0):
+    def __init__(self, curve="bn254", arena_bytes=64 << 20, me=0, share=None):
+        """share: another CpuWorker whose "device memory" this one addresses too (several contexts on one GPU)."""
         self.curve_name, self.me = curve, me
         self.curve = O.CURVE_IDS[curve]
         self.q64 = O.FQ_LIMBS[self.curve]
         self.f = P.CURVE_OBJ[self.curve].fr
-        self.arena = np.zeros(arena_bytes // 8, dtype=np.uint64)
-        self.top = 0
+        self._a = share._a if share is not None else _Arena(arena_bytes)
         self.lib = _Lib(self)
         self.ctx = None
         self.bases = self.inf = None
+        self._tasks = {}
+
+    @property
+    def arena(self):
+        return self._a.mem
 
     # ---- memory
     def _bump(self, nbytes):
         nbytes = (max(nbytes, 8) + 255) & ~255
-        assert self.top + nbytes <= self.arena.nbytes, "arena exhausted"
-        p = self.top + _BASE
-        self.top += nbytes
+        assert self._a.top + nbytes <= self.arena.nbytes, "arena exhausted"
+        p = self._a.top + _BASE
+        self._a.top += nbytes
         return p
 
     def _addr(self, ptr):
@@ -113,10 +124,57 @@ class CpuWorker:
 
     # ---- PlonkSlave surface used by the provers
     def init(self, bases, domain_size, quot_domain_size, layout=0):
-        b = np.ascontiguousarray(bases, dtype=np.uint64)
-        self.bases = b
-        self.inf = np.array([0 if row.any() else 1 for row in b], dtype=np.uint8)
+        if bases is not None and len(bases):
+            b = np.ascontiguousarray(bases, dtype=np.uint64)
+            self.bases = b
+            self.inf = np.array([0 if row.any() else 1 for row in b], dtype=np.uint8)
         self.n, self.m = domain_size, quot_domain_size
+
+    # ---- PlonkSlave @1..@5 as the reference worker implements them (worker.rs:159-381), on the oracle's helpers
+    def var_msm(self, workload, scalars):
+        lo, hi = workload.start, workload.end
+        sc = np.ascontiguousarray(scalars, dtype=np.uint64)[:hi - lo]
+        if hi == lo:
+            return O.msm(self.curve, self.bases[:1], np.zeros((1, 4), dtype=np.uint64), np.ones(1, dtype=np.uint8))
+        return O.msm(self.curve, self.bases[lo:lo + len(sc)], sc, self.inf[lo:lo + len(sc)])
+
+    def field_op(self, field, op, a, b=None):
+        names = {0: "mul", 1: "add", 2: "sub", 3: "to_mont", 4: "from_mont", 5: "inv", 6: "sqr"}
+        return O.field_op(self.curve, field, names[op], a, b)
+
+    def fft_init(self, id, workloads, is_quot, is_inv, is_coset):
+        N = self.m if is_quot else self.n
+        me = workloads[self.me]
+        self._tasks[id] = dict(wl=list(workloads), log_n=N.bit_length() - 1, inv=is_inv, coset=is_coset, rows={}, N=N,
+                               r=1 << ((N.bit_length() - 1) >> 1), me=me)
+
+    def fft1(self, id, i, v):
+        t = self._tasks[id]
+        t["rows"][i] = O.fft1_helper(self.curve, np.ascontiguousarray(v, dtype=np.uint64), i + t["me"].row_start, t["log_n"], t["inv"], t["coset"])
+
+    def fft2_prepare(self, id, exchange=None):
+        t = self._tasks[id]
+        rows = np.stack([t["rows"][i] for i in range(t["me"].num_rows())])
+        send = np.concatenate([O.exchange_pack(rows, w.col_start, w.col_end) for w in t["wl"]])      # worker.rs:327-330
+        S = len(t["wl"])
+        nbytes = send.nbytes // S
+        d_send, d_recv = self._bump(send.nbytes), self._bump(send.nbytes)
+        self.write_bytes(d_send, send)
+        if exchange is None:
+            assert S == 1
+            self.memcpy_d2d(d_recv, d_send, send.nbytes)
+        else:
+            assert exchange(d_send, d_recv, nbytes, S, 0) in (0, None)
+        t["recv"], t["nbytes"] = d_recv, nbytes
+
+    def fft2(self, id, r):
+        t = self._tasks.pop(id)
+        S, me = len(t["wl"]), t["me"]
+        cols = np.zeros((me.num_cols(), r, 4), dtype=np.uint64)
+        for src in range(S):                                                                          # worker.rs:432-435
+            blk = self.read_bytes(t["recv"] + src * t["nbytes"], t["nbytes"]).view(np.uint64).reshape(-1, 4)
+            O.exchange_scatter(cols, t["wl"][src].row_start, blk)
+        return np.stack([O.fft2_helper(self.curve, cols[i], i + me.col_start, t["log_n"], t["inv"], t["coset"]) for i in range(me.num_cols())])
 
     def ntt_dev(self, d_in, d_out, n, is_inv=False, is_coset=False):
         self._fr(d_out, n)[:] = O.ntt(self.curve, self._fr(d_in, n).copy(), is_inv, is_coset)

@@ -38,8 +38,7 @@ def test_prover_rounds_on_cpu_stand_in(oracle, curve, cid, mode, cache, two_lane
     w.init(ck, n, 8 * n)
     helper = None
     if two_lanes:                       # shares the arena: both "contexts" see the same device memory, as on a GPU
-        helper = CpuWorker(curve)
-        helper.arena, helper.top = w.arena, w.top
+        helper = CpuWorker(curve, share=w)
         helper.init(ck, n, 8 * n)
     pv = Prover(w, log_n, cache_key_cosets=cache, quotient_mode=mode, commit_helper=helper)
     pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
@@ -81,3 +80,31 @@ def test_six_coset_vandermonde_is_inverted(oracle):
     assert len(set(c)) == 6
     with pytest.raises(ValueError):
         Prover(w, 3, quotient_mode="classes6")
+
+
+@pytest.mark.parametrize("S", [1, 2, 4])
+def test_dispatcher_call_sequence_on_cpu_stand_in(oracle, S):
+    """distributed_plonk_amd.dispatcher.Dispatcher — the reference's `Prover::fft` sequence (dispatcher2.rs:732-787: fft_init on
+    every worker, one fft1 per decimated row, fft2_prepare with the block exchange, fft2, host undecimate), its sharded MSM
+    (dispatcher.rs:218-238) and commit_polynomial (dispatcher2.rs:835-893) — with S in-process stand-in workers."""
+    from distributed_plonk_amd.dispatcher import Dispatcher
+    cid, n = 0, 1 << 6
+    first = CpuWorker("bn254")
+    workers = [first] + [CpuWorker("bn254", share=first) for _ in range(S - 1)]
+    d = Dispatcher(workers)
+    bases = oracle.gen_bases(cid, 3, 16, n)
+    d.init(bases, n, 8 * n)
+    v = oracle.rand_fr(cid, 5, n)
+    for is_quot, is_inv, is_coset in [(False, True, False), (True, False, True), (True, True, True), (False, False, False)]:
+        N = 8 * n if is_quot else n
+        x = np.zeros((N, 4), dtype=np.uint64)
+        x[:n] = v
+        assert np.array_equal(d.fft(v, is_quot, is_inv, is_coset), oracle.ntt(cid, x, is_inv, is_coset)), (is_quot, is_inv, is_coset)
+    sc = oracle.from_mont(cid, oracle.rand_fr(cid, 6, n))
+    got = oracle.jac_to_affine(cid, d.msm(sc))
+    want = oracle.jac_to_affine(cid, oracle.msm(cid, bases, sc))
+    assert got[1] == want[1] and np.array_equal(got[0], want[0])
+    poly = oracle.rand_fr(cid, 7, n - 5)
+    xy, isinf = d.commit_polynomial(poly)
+    want = oracle.jac_to_affine(cid, oracle.commit_polynomial(cid, bases, poly))
+    assert isinf == bool(want[1]) and np.array_equal(xy, want[0])
