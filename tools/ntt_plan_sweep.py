@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from distributed_plonk_amd.worker import PlonkWorker
 w = PlonkWorker(0, 0, "bn254")
 for log_n in (20, 24, 27):
