@@ -388,7 +388,8 @@ def main():
         ck = w.alloc(n_ck * 16 * q64)
         w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
         w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # same key on every rank
-        w.init_dev(ck.ptr, n_ck, n, m)
+        for x in workers:
+            x.init_dev(ck.ptr, n_ck, n, m)
         key = w.alloc(18 * n * 32)
         circ = w.alloc(11 * n * 32)
         w.synth_fr(0xC1AC, key.ptr, 18 * n)
@@ -398,7 +399,7 @@ def main():
         consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
         ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
         bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-        cp = ClassProver(w, args.log_n, TorchComm(w, dev))
+        cp = ClassProver(w, args.log_n, TorchComm(w, dev), commit_helper=workers[1])
         cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
         t_cls = None
         for it in range(2):
@@ -414,7 +415,7 @@ def main():
             t_cls = float(tt.item())
         class_row = {"n": n, "ranks": world, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
                      "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
-                     "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 13 all-gathers of partial commitments",
+                     "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round)",
                      "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
         cp.close()
         for b in (ck, key, circ, idx):

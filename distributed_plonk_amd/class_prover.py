@@ -11,8 +11,8 @@ j = s (mod G), and class s is itself a coset  {(g * w_m^s) * w_(m/G)^k}.  Rank s
   * inverts locally (`plonk_coset_interp_dev`): its additive contribution to every quotient coefficient;
   * ONE all-to-all sums the contributions (rank r ends up owning coefficients [r*m/G, (r+1)*m/G)), ONE all-gather replicates
     the quotient polynomial;
-  * every commitment is an index-sharded MSM (dispatcher2.rs:870-890): rank s covers coefficients [s*L/G, (s+1)*L/G), the G
-    partial points (96/144 bytes) are all-gathered and added on the host.
+  * every commitment is an index-sharded MSM (dispatcher2.rs:870-890): rank s covers coefficients [s*L/G, (s+1)*L/G); the
+    partial points of a round (96/144 bytes each) travel in ONE all-gather and are added on the host.
 
 The O(n) rounds (wire / permutation iNTTs, grand product, evaluations at zeta, linearisation, openings) are computed redundantly
 on every rank: ~45 ms at n = 2^24 against ~100 ms of class work per rank at G = 8; sharding them is the next step.
@@ -132,8 +132,8 @@ class ClassProver(Prover):
     `worker.init(ck, n, 8n)` with the WHOLE commit key on every rank (72 B per point resident: replicated, not sharded, because
     a coefficient shard of the split quotient polynomials needs bases from anywhere in the key)."""
 
-    def __init__(self, worker: PlonkWorker, log_n: int, comm):
-        super().__init__(worker, log_n, cache_key_cosets=False)
+    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None):
+        super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper)
         G = comm.size
         if G & (G - 1) or G > self.m // self.n:
             raise ValueError(f"{G} ranks: coset classes need a power of two <= m/n = {self.m // self.n}")
@@ -144,17 +144,45 @@ class ClassProver(Prover):
         self.shift = f.to_limbs(f.generator * pow(w_m, self.s, f.p))     # g * w_m^s : this rank's class is shift * <w_(m/G)>
         self.inv_G = f.to_limbs(f.inv(G))
 
-    # ---- commitments: index-sharded MSM + 96/144-byte all-gather (dispatcher2.rs:870-892)
+    # ---- commitments: index-sharded MSMs, ONE all-gather of the round's partial points (dispatcher2.rs:870-892)
     def _commit(self, d_poly: int, length: int):
-        lo, hi = shard_range(length, self.s, self.G)
-        part = self.w.commit_range_dev(d_poly + lo * 32, lo, hi - lo)
-        acc = None
-        for p in self.comm.all_gather_host(part):
-            acc = p if acc is None else self.w.g1_add(acc, p)
-        return self.w.g1_to_affine(acc)
+        return self._commit_many([(d_poly, length)])[0]
 
     def _commit_many(self, items):
-        return [self._commit(ptr, ln) for ptr, ln in items]      # collectives inside: strictly in program order
+        """The shard [s*L/G, (s+1)*L/G) of every polynomial of the round (two contexts / host threads when a commit_helper
+        is set), then one collective for all partial points and the host reduce(a + b) per commitment."""
+        shards = []
+        for ptr, ln in items:
+            lo, hi = shard_range(ln, self.s, self.G)
+            shards.append((ptr + lo * 32, lo, hi - lo))
+        parts = [None] * len(shards)
+        lanes = [self.w] + ([self.commit_helper] if self.commit_helper is not None and len(shards) > 1 else [])
+        if len(lanes) == 1:
+            for i, sh in enumerate(shards):
+                parts[i] = self.w.commit_range_dev(*sh)
+        else:
+            self.w.sync()
+            errs = []
+
+            def run(lane):
+                try:
+                    for i in range(lane, len(shards), 2):
+                        parts[i] = lanes[lane].commit_range_dev(*shards[i])
+                except BaseException as ex:     # noqa: BLE001 - re-raised below
+                    errs.append(ex)
+
+            th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+        acc = [None] * len(shards)
+        for rank_parts in self.comm.all_gather_host(parts):               # collectives only on this thread, in program order
+            for i, p in enumerate(rank_parts):
+                acc[i] = p if acc[i] is None else self.w.g1_add(acc[i], p)
+        return [self.w.g1_to_affine(a) for a in acc]
 
     # ---- the quotient's degree: every rank holds the whole polynomial after the all-gather
     def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:

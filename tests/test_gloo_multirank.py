@@ -197,7 +197,11 @@ def _prover_rank_main(rank, world, port, log_n, cid, result_q):
         bl = dict(wires=O.rand_fr(cid, 1, 10).reshape(5, 2, 4), perm=O.rand_fr(cid, 2, 3))
         w = CpuWorker(curve, me=rank)
         w.init(ck, n, 8 * n)
-        pv = ClassProver(w, log_n, TorchComm(w, device=None))
+        helper = None
+        if rank % 2 == 0:                                               # half of the ranks use two commitment lanes
+            helper = CpuWorker(curve, me=rank, share=w)
+            helper.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, TorchComm(w, device=None), commit_helper=helper)
         pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
         fs = pv.fiat_shamir(circ["pub_input"][:2])                      # every rank runs its own transcript
         got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs, keep=True)
