@@ -34,3 +34,13 @@ def gpu_workers():
     yield get
     for w in ws.values():
         w.close()
+
+
+def free_port() -> int:
+    """A free TCP port on 127.0.0.1 for a torch.distributed rendezvous."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p

@@ -105,7 +105,8 @@ def test_class_prover_over_rccl_single_rank(gpu_workers, oracle):
     import torch
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29617")
+    from conftest import free_port
+    os.environ["MASTER_PORT"] = str(free_port())
     created = not dist.is_initialized()
     if created:
         dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))

@@ -128,7 +128,8 @@ def test_rank_prover_rccl_single_rank(oracle):
     from distributed_plonk_amd.dispatcher import RankProver, gather_points
     from distributed_plonk_amd.worker import PlonkWorker
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    os.environ.setdefault("MASTER_PORT", "29533")
+    from conftest import free_port
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     w = PlonkWorker(me=0, device=0, curve="bn254")
@@ -163,7 +164,8 @@ def test_two_contexts_pipelined_transforms(oracle):
     from distributed_plonk_amd.dispatcher import RankProver
     from distributed_plonk_amd.worker import PlonkWorker
     os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = "29541"
+    from conftest import free_port
+    os.environ["MASTER_PORT"] = str(free_port())
     torch.cuda.set_device(0)
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     lanes = [PlonkWorker(me=0, device=0, curve="bn254") for _ in range(2)]
