@@ -185,3 +185,29 @@ def test_quotient_evals_vs_bigint(name, cid, cv):
         got = O.quotient_evals(cid, log_n, np.stack([M(v) for v in sel]), np.stack([M(v) for v in sig]), np.stack([M(v) for v in wire]),
                                M(z), M(pi), M([al])[0], M([be])[0], M([ga])[0], M(k), threads=2)
         assert ints(got) == [f.to_mont(x) for x in ref]
+
+
+def test_bn254_group_law_published_points():
+    """Published known answers for the BN254 (alt_bn128) group law — 2G and 3G for G = (1, 2), the values the EIP-196 precompile
+    tests use — for both oracle layers.  (The reference itself holds no vectors; these pin affine doubling / addition and the
+    Jacobian scalar multiplication to something outside this repository.)"""
+    cv = B.BN254
+    g2 = (1368015179489954701390400359078579693043519447331113978918064868415326638035,
+          9918110051302171585080402603319702774565515993150576347155970296011118125764)
+    g3 = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+          19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    G = (cv.gx, cv.gy)
+    assert B.affine_add(cv, G, G) == g2
+    assert B.affine_add(cv, g2, G) == g3
+    assert B.scalar_mul(cv, 3, G) == g3
+    fq = cv.fq
+    for k, want in ((2, g2), (3, g3)):
+        jac = O.scalar_mul(0, O.generator(0), np.array([k, 0, 0, 0], dtype=np.uint64))
+        xy, inf = O.jac_to_affine(0, jac)
+        assert not inf
+        assert (fq.from_mont(B.from_limbs(xy[:4])), fq.from_mont(B.from_limbs(xy[4:]))) == want
+    # the MSM agrees: 1*G + 2*G = 3G
+    bases = np.stack([O.generator(0), O.generator(0)])
+    sc = np.array([[1, 0, 0, 0], [2, 0, 0, 0]], dtype=np.uint64)
+    xy, inf = O.jac_to_affine(0, O.msm(0, bases, sc))
+    assert (fq.from_mont(B.from_limbs(xy[:4])), fq.from_mont(B.from_limbs(xy[4:]))) == g3
