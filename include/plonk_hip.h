@@ -4,7 +4,9 @@
  * of `interface PlonkSlave` @0..@6 and `interface PlonkPeer` @0 (reference
  * src/hello_world.capnp:16-24,49-50; server src/worker.rs:125-439; clients src/dispatcher.rs:50-175,
  * src/dispatcher2.rs:961-1086), plus the three third-party operator calls the worker makes
- * (VariableBaseMSM::multi_scalar_mul, Radix2EvaluationDomain::{fft,ifft}_in_place, Fr::pow loops).
+ * (VariableBaseMSM::multi_scalar_mul, Radix2EvaluationDomain::{fft,ifft}_in_place, Fr::pow loops), and — further down — the
+ * O(n) loops the dispatcher runs itself in `Prover::prove` (src/dispatcher2.rs:329-344, 435-504, 545-688: SURVEY.md §8f) as
+ * device-resident calls, with the coset-class primitives a multi-rank prover is built from.
  * Plain pointers and sizes only; the caller owns every host buffer; the library owns device memory
  * inside the context.  INTEGRATION.md shows the Rust `extern "C"` block a maintainer would add.
  *
@@ -20,7 +22,8 @@
  * Every function returns 0 (PLONK_OK) or a negative error code; nothing throws across the boundary.
  * The reference panics (`.unwrap()`) on malformed input (worker.rs:131,253,303); here ranges, sizes
  * and domain two-adicity are validated and reported.  A context is bound to one GPU and is not
- * thread-safe (the reference worker is a single-threaded tokio LocalSet, worker.rs:441-448).
+ * thread-safe (the reference worker is a single-threaded tokio LocalSet, worker.rs:441-448); DIFFERENT contexts may be
+ * driven from different host threads concurrently (two contexts on one GPU overlap independent commitments).
  */
 #ifndef PLONK_HIP_H
 #define PLONK_HIP_H
