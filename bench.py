@@ -44,6 +44,10 @@ def parse():
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("PLONK_BENCH_LOG_N", "24")))
     ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
     ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
+    ap.add_argument("--dense-coset", action="store_true",
+                    help="feed the 25 forward coset transforms dense random 8n-point inputs through plonk_ntt_dev (the round-1 bench line) "
+                         "instead of the n+3 coefficients the prover actually has (zero-padded to 8n by the reference, dispatcher2.rs:746)")
+    ap.add_argument("--no-verify", action="store_true", help="skip the post-run result checks (`verified` becomes null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-n", type=int, default=19)
     ap.add_argument("--simulate-ranks", type=int, default=0,
@@ -110,6 +114,17 @@ def main():
     for lane in range(n_lanes):
         w.synth_fr(0xD15EA5E + 16 * rank + lane, buf_n[lane][0].ptr, n_loc)
         w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
+    # the coefficient vectors the 25 forward coset transforms start from: n + 3 coefficients (the blinded permutation polynomial's
+    # length; wires have n + 2, selectors n), which the reference zero-pads to 8n (dispatcher2.rs:746)
+    padded = (S == 1) and not args.dense_coset
+    poly_len = n + 3
+    gen_limbs = None
+    buf_p = None
+    if padded:
+        from distributed_plonk_amd import fr as _fr
+        gen_limbs = _fr.FIELDS[args.curve].to_limbs(_fr.FIELDS[args.curve].generator)
+        buf_p = w.alloc(poly_len * 32)
+        w.synth_fr(0xC0EFF, buf_p.ptr, poly_len)
     bases = w.alloc(n_loc * 16 * q64)
     # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
     w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
@@ -123,6 +138,13 @@ def main():
         else:
             provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
+
+    def coset_fft_8n(lane):
+        """quot_domain.coset_fft of one polynomial (dispatcher2.rs:387-424)."""
+        if padded:
+            w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[lane][0].ptr)
+        else:
+            ntt(lane, buf_m[lane], m, False, True, True)
 
     sim_scalars = None
     if sim:                                   # the no-op exchange leaves garbage in the NTT outputs: commit to fresh uniform scalars
@@ -171,7 +193,7 @@ def main():
         for i in range(N_NTT_SMALL):
             ntt(i % n_lanes, buf_n[i % n_lanes], n, True, False, False)
         for i in range(N_NTT_BIG - 1):
-            ntt(i % n_lanes, buf_m[i % n_lanes], m, False, True, True)
+            coset_fft_8n(i % n_lanes)
         ntt(0, buf_m[0], m, True, True, True)
         for x in workers:
             x.sync()                              # the commitments read lane-0 buffers from both contexts

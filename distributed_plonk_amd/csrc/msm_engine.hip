@@ -964,12 +964,15 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     return PLONK_OK;
 }
 
+static int g_msm_slice_log = 26;
+void msm_set_slice_log(int v) { g_msm_slice_log = v < 8 ? 8 : (v > 26 ? 26 : v); }
+
 template <int NQ>
 static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
                      const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     XyzzPt<NQ> total = xyzz_inf<NQ>();
-    const size_t SLICE = (size_t)1 << 26;
+    const size_t SLICE = (size_t)1 << g_msm_slice_log;      // default 2^26 points per slice (workspace sizing); "msm_slice_log" option for tests
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
         XyzzPt<NQ> part;

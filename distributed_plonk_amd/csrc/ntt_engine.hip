@@ -88,6 +88,8 @@ void ntt_tables_destroy(NttTables& T) {
     T.planes.clear();
     for (auto& kv : T.rowtabs) (void)hipFree(kv.second);
     T.rowtabs.clear();
+    for (auto& kv : T.shift_sets) { (void)hipFree(kv.second.planes); (void)hipFree(kv.second.rowtabs); (void)hipFree(kv.second.foldc); }
+    T.shift_sets.clear();
     T.plane_bytes = 0;
     if (T.quot_x_lo) { (void)hipFree(T.quot_x_lo); T.quot_x_lo = nullptr; }
     for (auto& kv : T.quot_inv_xm1) (void)hipFree(kv.second);
@@ -176,6 +178,95 @@ static int get_rowtab(NttTables& T, int log_r1, int log_w, F29** out, hipStream_
     if (rc) return rc;
     T.rowtabs[key] = d;
     *out = d;
+    return PLONK_OK;
+}
+
+// c * base^i, i < count, appended to `h` in constant form
+static void host_powers_const(std::vector<F29>& h, const Fr& base, size_t count, const FrParams& P) {
+    Fr r261;
+    for (int i = 0; i < 8; i++) r261.l[i] = P.one[i];
+    for (int i = 0; i < 5; i++) r261 = fp_add(r261, r261, P);
+    const Fr k_mont = fp_to_mont(r261, P);
+    Fr acc = fp_one(P);
+    for (size_t i = 0; i < count; i++) {
+        h.push_back(f29_from_sat(fp_from_mont(fp_mul(acc, k_mont, P), P)));
+        acc = fp_mul(acc, base, P);
+    }
+}
+
+// First-pass tables for the evaluation of one coefficient vector on the B cosets h_q * <w_M>, h_q = h * w_(M*B)^q:
+// row tables h_q^(a*r_1), fold constants (h_q^M)^u and — for transforms of more than one pass — the planes w_M^(b*i) * h_q^b.
+// Cached per (h, log M, log B, first pass width); planes count against the plane budget (older sets are dropped to make room;
+// running out of memory is an ERROR here, not a silent slow path: there is no plane-less variant of this transform).
+static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, int NP, const NttTables::ShiftSet** out, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    const int logB = ilog2(B);
+    std::string key((const char*)h.l, 32);
+    key.push_back((char)L); key.push_back((char)logB); key.push_back((char)w0);
+    auto it = T.shift_sets.find(key);
+    if (it != T.shift_sets.end()) { *out = &it->second; return PLONK_OK; }
+    if (L + logB > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset classes: 2^%d points exceed the two-adicity", L + logB);
+    const uint64_t M = (uint64_t)1 << L, R1 = (uint64_t)1 << w0, r1 = M >> w0;
+    NttTables::ShiftSet set;
+    set.bytes = NP > 1 ? (size_t)(B * M) * sizeof(Fr) : 0;
+    if (T.plane_bytes + set.bytes > T.plane_budget && !T.shift_sets.empty()) {        // make room: drop the other shift sets
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (auto& kv : T.shift_sets) {
+            (void)hipFree(kv.second.planes); (void)hipFree(kv.second.rowtabs); (void)hipFree(kv.second.foldc);
+            T.plane_bytes -= kv.second.bytes;
+        }
+        T.shift_sets.clear();
+    }
+    if (T.plane_bytes + set.bytes > T.plane_budget)
+        return plonk_fail(PLONK_ERR_HIP, "coset classes: %zu bytes of first-pass planes exceed the plane budget (%zu of %zu in use)", set.bytes,
+                          T.plane_bytes, T.plane_budget);
+    const Fr wB = host_pow2k(T.h_root[0], T.two_adicity - (L + logB), P);          // primitive (M*B)-th root of unity
+    std::vector<F29> h_row, h_fold;
+    h_row.reserve(B * R1); h_fold.reserve(B * 4);
+    std::vector<Fr> hq(B);
+    Fr acc = h;
+    for (uint64_t q = 0; q < B; q++) { hq[q] = acc; acc = fp_mul(acc, wB, P); }
+    for (uint64_t q = 0; q < B; q++) {
+        host_powers_const(h_row, host_pow2k(hq[q], L - w0, P), R1, P);             // (h_q^r_1)^a
+        host_powers_const(h_fold, host_pow2k(hq[q], L, P), 4, P);                  // (h_q^M)^u
+    }
+    HIP_TRY(hipMalloc((void**)&set.rowtabs, h_row.size() * sizeof(F29)));
+    HIP_TRY(hipMalloc((void**)&set.foldc, h_fold.size() * sizeof(F29)));
+    HIP_TRY(hipMemcpyAsync(set.rowtabs, h_row.data(), h_row.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipMemcpyAsync(set.foldc, h_fold.data(), h_fold.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (NP > 1) {
+        if (hipMalloc((void**)&set.planes, set.bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipFree(set.rowtabs); (void)hipFree(set.foldc);
+            return plonk_fail(PLONK_ERR_HIP, "coset classes: out of memory for %zu bytes of first-pass planes", set.bytes);
+        }
+        const size_t n_hi = (size_t)std::max<uint64_t>(1, r1 >> 10);
+        std::vector<F29> h_pw;
+        h_pw.reserve(B * (1024 + n_hi));
+        for (uint64_t q = 0; q < B; q++) {
+            host_powers_const(h_pw, hq[q], 1024, P);
+            host_powers_const(h_pw, host_pow2k(hq[q], 10, P), n_hi, P);
+        }
+        F29* d_pw = nullptr;
+        HIP_TRY(hipMalloc((void**)&d_pw, h_pw.size() * sizeof(F29)));
+        HIP_TRY(hipMemcpyAsync(d_pw, h_pw.data(), h_pw.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+        for (uint64_t q = 0; q < B; q++) {
+            const F29* lo = d_pw + q * (1024 + n_hi);
+            hipLaunchKernelGGL(ntt_gen_shift_plane_kernel, dim3((uint32_t)((M + 255) / 256)), dim3(256), 0, stream, set.planes + q * M, M, r1, T.tw_lo[0],
+                               T.tw_hi[0], (uint32_t)T.lt, (uint32_t)(T.two_adicity - L), lo, lo + 1024, T.fp29);
+        }
+        hipError_t e = hipGetLastError();
+        hipError_t e2 = hipStreamSynchronize(stream);
+        (void)hipFree(d_pw);
+        if (e != hipSuccess || e2 != hipSuccess) {
+            (void)hipFree(set.planes); (void)hipFree(set.rowtabs); (void)hipFree(set.foldc);
+            return plonk_fail(PLONK_ERR_HIP, "ntt_gen_shift_plane: %s", hipGetErrorString(e != hipSuccess ? e : e2));
+        }
+    }
+    T.plane_bytes += set.bytes;
+    auto ins = T.shift_sets.emplace(key, set);
+    *out = &ins.first->second;
     return PLONK_OK;
 }
 
@@ -281,7 +372,18 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     if (NP > NTT_MAX_PASSES) return plonk_fail(PLONK_ERR_ARG, "ntt_run: too many passes");
     const int dir = c.inverse ? 1 : 0;
     const bool interleaved = c.layout == NTT_INTERLEAVED;
-    if (NP > 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: in == out needs a single pass");
+    if (NP > 1 && !c.shared_in && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: in == out needs a single pass");
+    const NttTables::ShiftSet* sset = nullptr;
+    if (c.shared_in) {
+        if (interleaved || c.inverse || c.pro.kind || c.epi.kind || c.split_log >= 0 || c.in_len == 0 || c.in_len > 4 * M)
+            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, unscaled, 1 <= len <= 4M");
+        if (NP > 1 && (c.work == nullptr || (const void*)c.work == (const void*)c.out || (const void*)c.work == (const void*)c.in))
+            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation needs a separate work buffer");
+        if (NP == 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation cannot run in place");
+        int rc = get_shift_set(T, c.shift, L, Bt, widths[0], NP, &sset, stream);
+        if (rc) return rc;
+    }
+    Fr* const inplace = c.shared_in ? c.work : const_cast<Fr*>(c.in);      // where the non-last passes leave their output
     if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(c))
         return plonk_fail(PLONK_ERR_ARG, "ntt_run: in-place only for contiguous single pass");
 
@@ -319,10 +421,18 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         P.tw_lt = T.lt;
         P.split_log = -1;
         P.is_last = last ? 1 : 0;
-        P.in = c.in;
+        P.in = (p == 0) ? c.in : inplace;
+        if (sset != nullptr && p == 0) {
+            P.in_len = c.in_len;
+            P.fold_m = M;
+            P.nfold = (uint32_t)std::min<uint64_t>(4, (c.in_len + M - 1) / M);
+            P.fold_c = sset->foldc;
+            P.pro_rowtab = sset->rowtabs;
+            P.rowtab_qstride = (uint64_t)1 << widths[0];
+        }
         uint64_t grid = 0, avail = 1;
         if (!last) {
-            P.out = const_cast<Fr*>(c.in);
+            P.out = inplace;
             P.tw_shift = T.two_adicity - ilog2(r_prev);
             if (p == 0 && c.inverse) {
                 F29* scaled = nullptr;
@@ -330,7 +440,11 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
                 if (rc) return rc;
                 P.tw_lo = scaled;
             }
-            if (planes_on) {
+            if (sset != nullptr && p == 0) {
+                P.tw_plane = sset->planes;
+                P.plane_qstride = M;
+                P.plane_rp = r_p;
+            } else if (planes_on) {
                 const bool want_coset = (p == 0 && coset_foldable && !interleaved);
                 Fr* plane = nullptr;
                 int rc = get_plane(T, L, ilog2(r_prev), ilog2(r_p), dir, p == 0 && c.inverse, want_coset, want_coset ? log_b0 : 0, &plane, stream);
@@ -370,7 +484,22 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         } else {
             P.out = c.out;
             P.kstride = M >> w;
-            if (!interleaved && NP >= 2) {
+            if (sset != nullptr && NP >= 2 && c.out_layout == NTT_INTERLEAVED && Bt >= 2) {
+                // the tile's columns are the ARRAYS (cosets): contiguous runs in, and for every output index k the T arrays' values
+                // leave as one T*32-byte piece of the interleaved (natural-order) result
+                avail = Bt;
+                int lt = std::min(pref_log_t(w), ilog2(avail));
+                const uint64_t Tt = (uint64_t)1 << lt;
+                P.log_t = lt;
+                P.n0 = Bt / Tt; P.n1 = M >> w;
+                P.ls0 = Tt * M; P.ls1 = R; P.ls2 = 0; P.l_astride = 1; P.l_tstride = M; P.load_a_fast = 1;
+                P.qs0 = Tt; P.tq = 1;
+                P.ms0 = 0; P.tk = 0;
+                P.rev_ndig = NP - 1;
+                for (int d = 0; d < NP - 1; d++) P.rev_w[d] = widths[d];
+                P.rev_shift0 = 0;
+                grid = P.n0 * P.n1;
+            } else if (!interleaved && NP >= 2) {
                 const uint64_t R1 = (uint64_t)1 << widths[0], r1 = M >> widths[0];
                 avail = R1;
                 int lt = std::min(pref_log_t(w), ilog2(avail));

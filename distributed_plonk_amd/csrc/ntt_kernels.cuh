@@ -77,6 +77,15 @@ struct NttPassParams {
     const Fr* tw_plane;                   // non-last pass: precomputed inter-pass factors, index i*r_p + b (nullable)
     uint64_t plane_rp;                    // r_p (row pitch of the plane)
     const F29* pro_rowtab;                // first pass: per-row input scale G[a] (coset shift g^(a*r_1)), nullable
+    uint64_t rowtab_qstride;              // entries between the row tables of consecutive arrays (0: one table for all)
+    uint64_t plane_qstride;               // elements between the planes of consecutive arrays (0: one plane for all)
+    // Shared zero-padded input (class-decomposed coset evaluation, ntt_engine.hip: NttCall::shared_in): every array q reads the SAME
+    // coefficient vector — element `pos` is in[pos] for pos < in_len, else 0 — and coefficients beyond the array size M fold back
+    // with the constants of the array's own coset:  + sum_{u=1}^{nfold-1} fold_c[q][u] * in[pos + u*M]   (X^M = h_q^M on coset q).
+    uint64_t in_len;                      // 0: dense per-array input
+    uint64_t fold_m;
+    uint32_t nfold;
+    const F29* fold_c;                    // [array][4], constant form
     const Fr* epi_plane;                  // last pass: precomputed output factors, index q*epi_qstride + k (nullable)
     uint64_t epi_qstride;
     uint32_t scale_const_enabled;         // multiply outputs by `scale_const` (1/N when P==1)
@@ -231,9 +240,28 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         uint32_t a, t;
         if (P.load_a_fast) { a = e & (R - 1); t = e >> LOG_R; }
         else               { t = e & (T - 1); a = e >> P.log_t; }
-        F29 v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));
+        F29 v;
+        if (P.in_len != 0) {
+            const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
+            if (pos < P.in_len) {
+                v = f29_from_sat(load_fr(P.in + pos));
+            } else {
+#pragma unroll
+                for (int l = 0; l < 9; l++) v.l[l] = 0;
+            }
+            if (P.nfold > 1 && pos + P.fold_m < P.in_len) {       // a handful of elements per transform (n + 3 coefficients on n points)
+                const F29* fc = P.fold_c + 4 * (q0 + (uint64_t)t * P.tq);
+                for (uint32_t uu = 1; uu < P.nfold; uu++) {
+                    const uint64_t j = pos + (uint64_t)uu * P.fold_m;
+                    if (j < P.in_len) v = f29_add(v, f29_mul(f29_from_sat(load_fr(P.in + j)), load_f29(fc + uu), P.fp));
+                }
+                f29_norm(v);                                      // < p + 3 * 1.36 p
+            }
+        } else {
+            v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));
+        }
         if (P.pro_rowtab != nullptr) {
-            v = f29_mul(v, load_f29(P.pro_rowtab + a), P.fp);
+            v = f29_mul(v, load_f29(P.pro_rowtab + (q0 + (uint64_t)t * P.tq) * P.rowtab_qstride + a), P.fp);
         } else if (P.pro.enabled) {
             const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
             const F29 s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
@@ -293,7 +321,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             const uint64_t b = b0 + (uint64_t)t * P.tb;
             if (P.tw_plane != nullptr) {
                 // streamed factor plane: one 256-bit-limb load replaces two table gathers and a product
-                v = f29_mul(v, f29_from_sat(load_fr(P.tw_plane + (uint64_t)idx * P.plane_rp + b)), P.fp);
+                v = f29_mul(v, f29_from_sat(load_fr(P.tw_plane + (q0 + (uint64_t)t * P.tq) * P.plane_qstride + (uint64_t)idx * P.plane_rp + b)), P.fp);
             } else {
                 const uint64_t ex = (b * idx) << P.tw_shift;
                 const uint64_t mask = ((uint64_t)1 << P.tw_lt) - 1;
@@ -346,6 +374,22 @@ static __global__ void __launch_bounds__(256) ntt_gen_plane_kernel(Fr* __restric
         const F29 g = f29_mul(load_f29(g_lo + (eg & mask)), load_f29(g_hi + ((eg >> lt) & mask)), fp);
         v = f29_mul(v, g, fp);
     }
+    store_fr(out + pos, f29_to_sat(f29_canon(v, fp)));
+}
+
+
+// First-pass plane of a transform on the coset h * <w_M>:  plane[i*r_p + b] = w_M^(b*i) * h^b, with h^b = h_lo[b & 1023] * h_hi[b >> 10]
+// (host-built power tables of the arbitrary shift h).  Same storage form as ntt_gen_plane_kernel.
+static __global__ void __launch_bounds__(256) ntt_gen_shift_plane_kernel(Fr* __restrict__ out, uint64_t r_prev, uint64_t r_p, const F29* __restrict__ tw_lo,
+                                                                  const F29* __restrict__ tw_hi, uint32_t lt, uint32_t shift,
+                                                                  const F29* __restrict__ h_lo, const F29* __restrict__ h_hi, const F29Params fp) {
+    const uint64_t pos = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= r_prev) return;
+    const uint64_t i = pos / r_p, b = pos % r_p;
+    const uint64_t ex = (b * i) << shift, mask = ((uint64_t)1 << lt) - 1;
+    F29 v = f29_mul(load_f29(tw_lo + (ex & mask)), load_f29(tw_hi + ((ex >> lt) & mask)), fp);
+    v = f29_mul(v, load_f29(h_lo + (b & 1023)), fp);
+    if (r_p > 1024) v = f29_mul(v, load_f29(h_hi + (b >> 10)), fp);
     store_fr(out + pos, f29_to_sat(f29_canon(v, fp)));
 }
 

@@ -9,6 +9,7 @@
 #include "plonk_internal.hpp"
 
 void ntt_set_max_log_r(int v);
+void msm_set_slice_log(int v);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -193,6 +194,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
+    if (!strcmp(key, "msm_slice_log")) { msm_set_slice_log((int)value); return PLONK_OK; }          // process-wide; MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);
 }
 
@@ -494,7 +496,7 @@ extern "C" int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_
     return PLONK_OK;
 }
 
-extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows) {
+extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows) {
     CHECK_CTX(ctx);
     FftTask* t;
     int rc = get_task(ctx, id, &t);
@@ -502,7 +504,7 @@ extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows) {
     if (!d_rows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev: null");
     if (t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1_dev: already prepared");
     if (t->d_rows && !t->rows_external) pool_put(ctx, t->nrows * t->c * 32, t->d_rows);
-    t->d_rows = (Fr*)const_cast<void*>(d_rows);
+    t->d_rows = (Fr*)d_rows;     // consumed: the row pass uses it as workspace
     t->rows_external = true;
     t->rows_filled = t->nrows;
     return PLONK_OK;

@@ -71,12 +71,20 @@ struct NttTables {
     std::unordered_map<int, F29*> tw_lo_scaled;   // key = log_m (inverse only): w^-e * 2^-log_m
     std::unordered_map<uint64_t, Fr*> planes;     // inter-pass factor planes (see ntt_engine.hip: plane_key)
     std::unordered_map<uint64_t, F29*> rowtabs;   // coset row tables g^(a*r_1)
+    // first-pass tables of class-decomposed coset evaluations (ntt_engine.hip: get_shift_set), keyed by (shift, log M, log B, first width)
+    struct ShiftSet {
+        Fr* planes = nullptr;       // [B][M]: w_M^(b*i) * h_q^b            (transforms of two or more passes)
+        F29* rowtabs = nullptr;     // [B][R_1]: h_q^(a * r_1)
+        F29* foldc = nullptr;       // [B][4]: (h_q^M)^u
+        size_t bytes = 0;
+    };
+    std::unordered_map<std::string, ShiftSet> shift_sets;
     size_t plane_bytes = 0;                       // HBM currently held by planes
     size_t plane_budget = (size_t)48 << 30;       // stop creating planes beyond this (fall back to on-the-fly factors)
     // quotient.hip: g * w_Nmax^e (constant form) and 1/(x_i - 1) per quotient-domain size (key = log m)
     F29* quot_x_lo = nullptr;
     std::unordered_map<int, Fr*> quot_inv_xm1;     // key: log m | class stride << 8 | class offset << 16
-    // poly_ops.hip: three-level power tables z^i keyed by (z, levels, scale) — FIFO cache
+    // poly_ops.hip: three-level power tables z^i keyed by (z, levels, scale) — LRU cache (pow_order: least recent first)
     std::unordered_map<std::string, F29*> pow_tabs;
     std::vector<std::string> pow_order;
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
@@ -104,6 +112,15 @@ struct NttCall {
     int split_log = -1;       // output re-blocking for the all-to-all send buffer (see ntt_kernels.cuh)
     uint64_t split_blk = 0;
     NttLayout out_layout = NTT_CONTIGUOUS;
+    // Class-decomposed evaluation of ONE coefficient vector on the cosets h_q * <w_M>, h_q = shift * w_(M*batch)^q, q < batch
+    // (coset_eval_run): every array reads the same `in` (in_len coefficients, NOT modified; zero beyond in_len; coefficients beyond M
+    // fold back), layout contiguous, forward only, no other scale.  With out_layout = NTT_INTERLEAVED the result is the natural-order
+    // evaluation vector on the coset shift * <w_(M*batch)> — the zero-padding-aware coset FFT of dispatcher2.rs:387-424.
+    // `work` (M*batch elements) receives the intermediate passes.
+    bool shared_in = false;
+    uint64_t in_len = 0;
+    Fr shift;
+    Fr* work = nullptr;
 };
 
 int ntt_tables_create(NttTables& T, int curve, hipStream_t stream);

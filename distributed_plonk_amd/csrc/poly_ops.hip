@@ -18,6 +18,7 @@
 // Scans: block tile = 256 lanes x 8 consecutive elements per lane; phase 1 tile totals, phase 2 one workgroup scans
 // the totals, phase 3 re-reads the tile, scans it through LDS and applies an epilogue.  All streaming; none of this
 // is on the critical path of the proof-equivalent mix (a few ms at n = 2^24 against ~1 s of NTT + MSM).
+#include <algorithm>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -248,6 +249,10 @@ static int build_pow_tab(NttTables& T, const Fr& z_mont, uint64_t len, PowTab* o
     auto it = T.pow_tabs.find(key);
     if (it != T.pow_tabs.end()) {
         d_tab = it->second;
+        // LRU: a hit moves the entry to the back, so the tables a call has already been handed (poly_div_linear fetches z, then
+        // 1/z) are the LAST to be evicted — with FIFO order, a miss on the second could free the first while it is still in use
+        auto pos = std::find(T.pow_order.begin(), T.pow_order.end(), key);
+        if (pos != T.pow_order.end()) { T.pow_order.erase(pos); T.pow_order.push_back(key); }
     } else {
         std::vector<F29> h((size_t)levels * 1024);
         Fr base = z_mont;
@@ -257,7 +262,7 @@ static int build_pow_tab(NttTables& T, const Fr& z_mont, uint64_t len, PowTab* o
             for (int i = 0; i < 1024; i++) { h[(size_t)l * 1024 + i] = host_rep(fp_mul(acc, mult, P), P); acc = fp_mul(acc, base, P); }
             base = acc;                       // base^1024
         }
-        if (T.pow_order.size() >= POWTAB_CACHE_MAX) {          // FIFO eviction; a table may still be in flight on the stream
+        if (T.pow_order.size() >= POWTAB_CACHE_MAX) {          // evict the least recently used; it may still be in flight on the stream
             HIP_TRY(hipStreamSynchronize(stream));
             (void)hipFree(T.pow_tabs[T.pow_order.front()]);
             T.pow_tabs.erase(T.pow_order.front());
@@ -563,32 +568,12 @@ int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint
 // Evaluation of a coefficient vector on {shift * w_size^k, k < size} and its inverse, for ANY shift — the building block of
 // coset-class parallelism (rank s of G evaluates every polynomial on the points g*w_m^(s+Gk) = (g*w_m^s) * w_(m/G)^k, which
 // makes the quotient kernel rank-local).  With shift = g, size = m this is Radix2EvaluationDomain::coset_fft / coset_ifft.
-//   eval:    tmp[i] = shift^i * sum_u (shift^size)^u * a[i + u*size]   (coefficients beyond `size` fold back: X^size = shift^size
-//            on the coset), then a plain size-point NTT.
+//   eval:    NTT_size of  shift^i * sum_u (shift^size)^u * a[i + u*size]   (coefficients beyond `size` fold back: X^size = shift^size
+//            on the coset) — fused into the first pass of the transform (shared-input mode of ntt_run: the shift enters as a row
+//            table and the first inter-pass plane), and decomposed into 2^k sub-cosets when fewer than size/2 coefficients are
+//            non-zero (see coset_eval_run).
 //   interp:  E = iNTT_size(evals);  out[t] = scale * shift^-(i0+t) * E[(i0+t) mod size]   — the contribution of this coset to
 //            coefficient i0+t when `scale` = 1/G and G cosets tile a domain of G*size points; G = 1: coset_ifft itself.
-struct FoldParams {
-    F29 cpow[4];              // rep((shift^size)^u)
-    int nfold;                // ceil(len / size) <= 4
-};
-__global__ void __launch_bounds__(256) coset_prescale_kernel(const Fr* __restrict__ poly, uint64_t len, uint64_t size, const PowTab pw, const FoldParams fo,
-                                                             Fr* __restrict__ out, const PoCtx c) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= size) return;
-    const F29Params& fp = c.f29;
-    F29 acc;
-#pragma unroll
-    for (int l = 0; l < 9; l++) acc.l[l] = 0;
-    bool any = false;
-    if (i < len) { acc = f29_from_sat(load_fr(poly + i)); any = true; }
-    for (int u = 1; u < fo.nfold; u++) {
-        const uint64_t j = i + (uint64_t)u * size;
-        if (j < len) { acc = f29_add(acc, f29_mul(f29_from_sat(load_fr(poly + j)), fo.cpow[u], fp)); any = true; }
-    }
-    if (!any) { store_fr(out + i, fp_zero<8>()); return; }
-    f29_norm(acc);                                              // < 5.1 p
-    store_fr(out + i, f29_to_sat(f29_canon(f29_mul(acc, pow_at(pw, i, fp), fp), fp)));
-}
 __global__ void __launch_bounds__(256) coset_unscale_kernel(const Fr* __restrict__ e, uint64_t size_mask, uint64_t i0, uint64_t count, const PowTab pw,
                                                             Fr* __restrict__ out, const PoCtx c) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -607,27 +592,21 @@ int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, co
     if (log_s > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: 2^%d exceeds the two-adicity", log_s);
     if (len > 4 * size) return plonk_fail(PLONK_ERR_ARG, "coset_eval: %zu coefficients for a %zu-point coset (limit 4x)", len, size);
     if (!fr_arg_ok(shift, P)) return plonk_fail(PLONK_ERR_ARG, "coset_eval: shift not reduced");
-    Fr* tmp = (Fr*)scratch;
-    const Fr h = fr_arg(shift);
-    PowTab pw;
-    int rc = build_pow_tab(T, h, size, &pw, stream);
-    if (rc) return rc;
-    FoldParams fo;
-    memset(&fo, 0, sizeof fo);
-    fo.nfold = (int)((len + size - 1) / size);
-    if (fo.nfold < 1) fo.nfold = 1;
-    Fr cs = fp_pow_u64(h, (uint64_t)size, P), cp = fp_one(P);
-    for (int u = 0; u < 4; u++) { fo.cpow[u] = host_rep(cp, P); cp = fp_mul(cp, cs, P); }
-    const PoCtx c = make_ctx(T);
-    {
-        ProfScope ps("coset_prescale_kernel", stream);
-        hipLaunchKernelGGL(coset_prescale_kernel, dim3((uint32_t)((size + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, (uint64_t)size, pw, fo,
-                           tmp, c);
-    }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "coset_prescale launch: %s", hipGetErrorString(e));
+    if (d_poly == d_out) return plonk_fail(PLONK_ERR_ARG, "coset_eval: d_out must not alias d_poly");
+    if (len == 0) { HIP_TRY(hipMemsetAsync(d_out, 0, size * 32, stream)); return PLONK_OK; }      // the zero polynomial
+    // Zero-padding awareness (the reference zero-pads n+2 / n+3 coefficients to the 8n-point domain, dispatcher2.rs:746): with
+    // B = 2^k classes, the evaluations at the
+    // points of index q, q+B, q+2B, ... are a size/B-point transform on the coset (shift * w_size^q) * <w_(size/B)> of the SAME
+    // coefficients (folded modulo size/B).  B independent transforms of log(size/B) stages each, no zero is ever loaded, multiplied
+    // or stored, and the last pass interleaves the B results into natural order.
+    int k = 0;
+    // one more halving removes a stage (0.5 products per point) and folds len - size/2B coefficients into each of 2B classes (one
+    // product each): worth it while len < 1.5 * size/2B.  n + 3 coefficients on 8n points: B = 8 classes of n points.
+    while (k < 4 && log_s - k > 1 && 2 * len < 3 * (size >> (k + 1))) k++;
     NttCall call;
-    call.in = tmp; call.out = (Fr*)d_out; call.log_m = log_s; call.batch = 1; call.inverse = false;
+    call.in = (const Fr*)d_poly; call.out = (Fr*)d_out; call.log_m = log_s - k; call.batch = (uint64_t)1 << k; call.inverse = false;
+    call.shared_in = true; call.in_len = len; call.shift = fr_arg(shift); call.work = (Fr*)scratch;
+    call.out_layout = k ? NTT_INTERLEAVED : NTT_CONTIGUOUS;
     return ntt_run(T, call, stream);
 }
 

@@ -209,7 +209,8 @@ class RankProver:
     def fft_dev(self, d_rows_ptr: int, d_out_ptr: int, domain_size: int, is_quot: bool, is_inv: bool, is_coset: bool,
                 out_layout: int = 1):
         """HBM-resident distributed NTT.  In: this rank's decimated rows [r/S][c] (row b = elements with
-        index mod r == b).  Out (layout 1): [r][c/S], element (j, i) = X[(i + col_start) + j*c]."""
+        index mod r == b) — CONSUMED (the row pass uses the buffer as its workspace, like plonk_ntt_dev's d_in).
+        Out (layout 1): [r][c/S], element (j, i) = X[(i + col_start) + j*c]."""
         id = self._rng.getrandbits(64)
         wl = make_fft_workloads(domain_size, self.world)
         self.w.fft_init(id, wl, is_quot, is_inv, is_coset)

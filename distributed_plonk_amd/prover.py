@@ -54,7 +54,10 @@ class FiatShamir:
 
 
 class Prover:
-    """One GPU.  `worker.init(ck, n, 8n)` must have been called with the commit key padded as dispatcher2.rs:207-208."""
+    """One GPU.  `worker.init(ck, n, 8n)` must have been called with the commit key padded to a multiple of 32 points as
+    dispatcher2.rs:207-208 does.  The reference pads with `G1Affine::zero()` = (0, 1, infinity = true): pass such a key in the
+    PLONK_BASES_ARK layout (the infinity flag travels), or, in the PLONK_BASES_XY layout, encode the padding points as x = y = 0 —
+    XY has no flag byte, and (0, 1) there would be read as a finite (off-curve) point."""
 
     def __init__(self, worker: PlonkWorker, log_n: int, cache_key_cosets: bool = False, quotient_mode: str = "coset8n",
                  commit_helper: Optional[PlonkWorker] = None):
@@ -65,6 +68,7 @@ class Prover:
         iFFT).  "classes6": the same quotient polynomial from 6n evaluations — see _quotient_poly_classes."""
         self.w = worker
         self.f = _fr.FIELDS[worker.curve_name]
+        self._gen_limbs = self.f.to_limbs(self.f.generator)          # Fr::multiplicative_generator(), the coset shift of the quotient domain
         self.log_n, self.n, self.m = log_n, 1 << log_n, 8 << log_n
         self.cache_key_cosets = cache_key_cosets
         if quotient_mode not in ("coset8n", "classes6"):
@@ -128,11 +132,9 @@ class Prover:
             self._key["cos"] = ptrs
         elif self.cache_key_cosets:
             cos = self._alloc(18 * m)
-            tmp = self._alloc(m)
             ptrs = [cos.ptr + j * m * 32 for j in range(18)]
             for j, src in enumerate(self._key["sel"] + self._key["sig"]):
-                self._coset_fft(src, n, tmp.ptr, ptrs[j])
-            self._free([tmp])
+                self._coset_fft(src, n, ptrs[j])
             self._key["cos"] = ptrs
 
     def verifying_key(self) -> dict:
@@ -154,12 +156,11 @@ class Prover:
         return FiatShamir(t)
 
     # ------------------------------------------------------------------ building blocks
-    def _coset_fft(self, d_src: int, length: int, d_tmp: int, d_dst: int):
-        """Self::fft(.., quot_domain, coeffs, true, false, true): zero-pad to m, coset FFT (dispatcher2.rs:387-424)."""
-        w, m = self.w, self.m
-        w.memcpy_d2d(d_tmp, d_src, length * 32)
-        w.memset_dev(d_tmp + length * 32, 0, (m - length) * 32)
-        w.ntt_dev(d_tmp, d_dst, m, False, True)
+    def _coset_fft(self, d_src: int, length: int, d_dst: int):
+        """Self::fft(.., quot_domain, coeffs, true, false, true): the coset FFT of the coefficients zero-padded to m
+        (dispatcher2.rs:387-424, 746).  plonk_coset_eval_dev with shift = g is that transform without ever materialising the
+        zeros: 8 interleaved n-point transforms of the n+2 / n+3 coefficients."""
+        self.w.coset_eval_dev(d_src, length, self.m, self._gen_limbs, d_dst)
 
     def _commit(self, d_poly: int, length: int):
         """commit_polynomial (dispatcher2.rs:835-893) -> affine (xy limbs, is_infinity)."""
@@ -271,18 +272,17 @@ class Prover:
             return self._quotient_poly_classes(alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma)
         w, n, m, key = self.w, self.n, self.m, self._key
         t0 = time.perf_counter()
-        d_tmp = alloc(m)
         if key["cos"] is None:
             d_kc = alloc(18 * m)
             kc = [d_kc.ptr + j * m * 32 for j in range(18)]
             for j, src in enumerate(key["sel"] + key["sig"]):
-                self._coset_fft(src, n, d_tmp.ptr, kc[j])
+                self._coset_fft(src, n, kc[j])
         else:
             kc = key["cos"]
         d_c = alloc(7 * m)
         cw = [d_c.ptr + j * m * 32 for j in range(7)]
         for j, (ptr, ln) in enumerate(list(wire_polys) + [perm_poly, pi_poly]):
-            self._coset_fft(ptr, ln, d_tmp.ptr, cw[j])                    # :406-429
+            self._coset_fft(ptr, ln, cw[j])                               # :406-429
         tick("round3_coset_ffts", t0)
         t0 = time.perf_counter()
         d_qev = alloc(m)

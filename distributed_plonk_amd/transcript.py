@@ -174,7 +174,12 @@ def serialize_proof(curve: str, proof: dict) -> bytes:
     struct fields [upstream: jellyfish turbo-plonk branch, Cargo.lock:801-803, not vendored]: wires_poly_comms: Vec<Commitment>,
     prod_perm_poly_comm, split_quot_poly_comms: Vec<Commitment>, opening_proof, shifted_opening_proof, poly_evals
     { wires_evals: Vec<Fr>, wire_sigma_evals: Vec<Fr>, perm_next_eval }.  A Vec is its length as u64 little-endian followed
-    by the elements (ark-serialize 0.3)."""
+    by the elements (ark-serialize 0.3).
+
+    UNVERIFIED LAYOUT: the struct's definition lives in an un-vendored git dependency; the reference only shows the field names in
+    construction order (dispatcher2.rs:699-710) and holds no serialized proof.  The byte layout of this function is therefore
+    outside every parity claim of this repository until one reference-generated `Proof` pins it; what IS pinned is
+    each element's encoding (serialize_fr / serialize_g1, against the curve generators) and everything the transcript absorbs."""
     def vec(items, enc):
         return len(items).to_bytes(8, "little") + b"".join(enc(x) for x in items)
 

@@ -140,6 +140,7 @@ class PlonkWorker:
         check(self.lib.plonk_fft1(self.ctx, id, i, _ptr(v), v.shape[0]))
 
     def fft1_dev(self, id: int, d_rows_ptr: int):
+        """All local rows at once; the buffer is consumed (must stay alive until fft2_prepare returns, contents destroyed)."""
         check(self.lib.plonk_fft1_dev(self.ctx, id, d_rows_ptr))
 
     def fft2_prepare(self, id: int, exchange: Optional[Callable] = None):

@@ -127,8 +127,10 @@ int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t n_coeffs,
  * at coefficient `start`; out = sum_{i < count} into_repr(coeff[start + i]) * bases[start + i].  The shards' points add up to the
  * commitment. */
 int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t start, size_t count, uint64_t* out_jacobian);
-/* All local rows at once, row-major [num_rows][c] in HBM (replaces num_rows fft1 calls). */
-int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, const void* d_rows);
+/* All local rows at once, row-major [num_rows][c] in HBM (replaces num_rows fft1 calls).  d_rows is CONSUMED: the buffer must stay
+ * alive until plonk_fft2_prepare returns, which runs the row pass with d_rows as its inter-pass workspace (c > 2^9) and leaves
+ * garbage in it — like plonk_ntt_dev's d_in. */
+int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows);
 /* Result of fft2 left in HBM.  layout 0: [num_cols][r] (the reference's reply); layout 1:
  * [r][num_cols] (natural order restricted to this rank's columns: element (j, i) = X[(i + col_start) + j*c]). */
 int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layout);
@@ -187,7 +189,11 @@ int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blin
  * d_out[k] = poly(shift * w_size^k), k < size; size a power of two, len <= 4*size (coefficients beyond `size` fold back, since
  * X^size = shift^size on the coset).  shift = Fr::multiplicative_generator(), size = m: quot_domain.coset_fft (dispatcher2.rs:387-424)
  * of the zero-padded vector.  shift = g * w_m^s, size = m/G: the evaluations at the points of index s, s+G, s+2G, ... of that
- * same coset FFT — rank s's share of every round-3 vector with no communication. */
+ * same coset FFT — rank s's share of every round-3 vector with no communication.
+ * Zero-padding aware: the `size - len` zero coefficients the reference appends (dispatcher2.rs:746) are never loaded, multiplied or
+ * stored — with len <= size/2 the transform runs as 2^k independent (size/2^k)-point transforms of the same coefficients on the
+ * sub-cosets (shift * w_size^q) * <w_(size/2^k)> whose results are interleaved into natural order by the last pass' stores.
+ * d_poly is not modified; d_out must not alias it. */
 int plonk_coset_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out);
 /* E = iNTT_size(d_evals) (d_evals is destroyed), d_out[t] = scale * shift^-(i0+t) * E[(i0+t) mod size], t < count.
  * shift = g, scale = 1, i0 = 0, count = size: quot_domain.coset_ifft (dispatcher2.rs:507).  With scale = 1/G and shift = g * w_m^s,
@@ -216,7 +222,8 @@ int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_
  * field: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont, 5 inverse, 6 square.  Host buffers. */
 int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                          uint64_t* out, size_t n);
-/* tuning knobs: key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 10). */
+/* tuning knobs: key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 9), "msm_slice_log" (8..26: MSMs above 2^value points are
+ * computed slice by slice and the partial points added; default 26 — process-wide, for tests of the slicing path). */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
 /* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP
  * events on the context's stream (milliseconds). */

@@ -93,3 +93,77 @@ def test_quotient_kernel_on_a_class_equals_the_slice(gpu_workers, oracle, curve,
         w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr, class_stride=G, class_offset=s)
         assert np.array_equal(out.download((mL, 4)), want[s::G]), (s, G)
     buf.free(); out.free()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_size,length", [
+    (3, 1), (4, 3), (6, 64), (6, 65), (6, 100), (6, 256), (6, 0), (9, 70), (10, 1024),
+    (12, (1 << 9) + 3),        # 8 classes of 2^9 points: one pass per class, interleaved stores
+    (13, (1 << 10) + 3),       # 8 classes of 2^10 points: two passes (5, 5)
+    (16, (1 << 12) + 1),       # 16 classes (the cap) of 2^12 points, one folded coefficient
+    (19, (1 << 16) + 3),       # 8 classes of 2^16 points: passes (8, 8) — the shape of n = 2^16 gates
+    (20, 5),                   # almost everything zero: 16 classes, inputs beyond `length` read as zero
+    (20, 1 << 20),             # dense: one class, three passes (7, 7, 6)
+    (20, (1 << 20) + 3),       # dense with fold (the six-coset / class-prover call shape)
+    (21, (1 << 18) + 2),       # 8 classes of 2^18 points: passes (9, 9)
+])
+def test_coset_eval_zero_padding_classes_match_oracle(gpu_workers, oracle, curve, cid, log_size, length):
+    """plonk_coset_eval_dev(shift = g, size) == quot_domain.coset_fft of the zero-padded coefficient vector (dispatcher2.rs:387-424,746)
+    for every class count the planner can choose (1, 2, 4, 8, 16), with and without folding, single- and multi-pass classes."""
+    w = gpu_workers(curve)
+    size = 1 << log_size
+    P, f, g, w_s = _consts(oracle, cid, log_size)
+    poly = oracle.rand_fr(cid, 4000 + log_size, max(length, 1))[:length]
+    folded = np.zeros((size, 4), dtype=np.uint64)
+    if length <= size:
+        folded[:length] = poly
+    else:                                                     # X^size = g^size on the coset: fold on the host with exact integers
+        c = pow(g, size, f.p)
+        acc = [0] * size
+        ints = [P.fr_from_limbs(f, x) for x in poly]
+        for i, v in enumerate(ints):
+            acc[i % size] = (acc[i % size] + v * pow(c, i // size, f.p)) % f.p
+        folded = np.stack([P.fr_to_limbs(f, v) for v in acc])
+    want = oracle.ntt(cid, folded, False, True, threads=32)
+    dp = w.alloc(max(length, 1) * 32)
+    if length:
+        dp.upload(poly)
+    out = w.alloc(size * 32)
+    w.coset_eval_dev(dp.ptr, length, size, P.fr_to_limbs(f, g), out.ptr)
+    got = out.download((size, 4))
+    assert np.array_equal(got, want)
+    if length:
+        assert np.array_equal(dp.download((length, 4)), poly)          # the input is not modified
+    dp.free(); out.free()
+
+
+def test_coset_eval_full_size_8n_against_independent_kernels(gpu_workers, oracle):
+    """BASELINE's size: n + 3 coefficients on the 8n = 2^27-point quotient coset (8 classes of 2^24 points, three passes each).
+    (a) every output equals the dense transform of the explicitly zero-padded vector (plonk_ntt_dev: different planes, different
+    tile mapping, 9-stage passes); (b) sampled outputs equal Horner evaluations by plonk_poly_eval_dev at g * w^k (an unrelated
+    kernel, itself checked against the oracle in test_gpu_polyops); (c) the coset iNTT returns the padded coefficients."""
+    w = gpu_workers("bn254")
+    log_n = 24
+    n, m = 1 << log_n, 8 << log_n
+    P, f, g, w_m = _consts(oracle, 0, log_n + 3)
+    length = n + 3
+    dp = w.alloc(length * 32)
+    w.synth_fr(0xC05E7, dp.ptr, length)
+    a, b, c = w.alloc(m * 32), w.alloc(m * 32), w.alloc(m * 32)
+    w.coset_eval_dev(dp.ptr, length, m, P.fr_to_limbs(f, g), a.ptr)
+    w.memset_dev(b.ptr, 0, m * 32)
+    w.memcpy_d2d(b.ptr, dp.ptr, length * 32)
+    w.ntt_dev(b.ptr, c.ptr, m, False, True)                   # dense route (b destroyed)
+    CH = 1 << 22
+    for off in range(0, m, CH):
+        assert np.array_equal(a.download((CH, 4), byte_offset=off * 32), c.download((CH, 4), byte_offset=off * 32)), off
+    for k in (0, 1, 7, 8, 9, 12345, (5 << 24) + 3, m - 1):
+        x = P.fr_to_limbs(f, g * pow(w_m, k, f.p) % f.p)
+        assert np.array_equal(a.download((1, 4), byte_offset=k * 32)[0], w.poly_eval_dev(dp.ptr, length, x)), k
+    w.ntt_dev(a.ptr, b.ptr, m, True, True)                    # coset iNTT of the class result (a destroyed)
+    assert np.array_equal(b.download((length, 4)), dp.download((length, 4)))
+    for off in range(length * 32, m * 32, CH * 32):
+        nb = min(CH * 32, m * 32 - off)
+        assert not b.download((nb // 8,), byte_offset=off).any(), off
+    for x in (dp, a, b, c):
+        x.free()

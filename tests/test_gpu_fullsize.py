@@ -5,6 +5,8 @@ reference's own 2-D decomposition identity, and an exact MSM check that exploits
 import numpy as np
 import pytest
 
+from distributed_plonk_amd._ffi import MsmWorkload
+
 pytestmark = pytest.mark.gpu
 
 
@@ -45,6 +47,112 @@ def test_msm_full_size_tiled_bases_exact(gpu_workers, oracle, curve, cid, log_n)
     assert gi == ei and np.array_equal(g, e)
     for b in (d_b, d_s, d_c):
         b.free()
+
+
+def _limbs_from_halves(halves, p):
+    out = np.zeros((halves.shape[0], 4), dtype=np.uint64)
+    for j in range(halves.shape[0]):
+        v = sum(int(halves[j, k]) << (32 * k) for k in range(8)) % p
+        out[j] = [(v >> (64 * k)) & (2**64 - 1) for k in range(4)]
+    return out
+
+
+def distinct_bases_expected(oracle, cid, seed, sc, threads=8):
+    """The SRS-like distribution bench.py times by default (`plonk_synth_bases(unique = 0)`): P_i = A[i % 4096] + B[i / 4096] with
+    A = gen_bases(seed), B = gen_bases(seed + 1), pairwise distinct.  Then
+        sum_i s_i P_i = sum_a (sum_{i % 4096 = a} s_i) A_a + sum_b (sum_{i / 4096 = b} s_i) B_b
+    — two small oracle MSMs of aggregated scalars give the EXACT expected point at any n.  sc: canonical scalars (n, 4)."""
+    n, na = sc.shape[0], 4096
+    nbb = (n + na - 1) // na
+    p = int.from_bytes(oracle.field_const(cid, 0, 0).tobytes(), "little")
+    pad = nbb * na - n
+    h = sc.view(np.uint32).reshape(n, 8)
+    if pad:
+        h = np.vstack([h, np.zeros((pad, 8), dtype=np.uint32)])
+    h = h.reshape(nbb, na, 8).astype(np.uint64)
+    agg_a = _limbs_from_halves(h.sum(axis=0), p)                 # (na, 8) sums of 32-bit halves: < 2^32 * nbb, no overflow below 2^32 rows
+    agg_b = _limbs_from_halves(h.sum(axis=1), p)
+    A = oracle.gen_bases(cid, seed, na, na)
+    B = oracle.gen_bases(cid, seed + 1, nbb, nbb)
+    return oracle.jac_add(cid, oracle.msm(cid, A, agg_a, threads=threads), oracle.msm(cid, B, agg_b, threads=threads))
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("n", [300, (1 << 16) + 77])
+def test_msm_distinct_bases_matches_oracle_directly(gpu_workers, oracle, curve, cid, n):
+    """Pairwise-distinct bases (no P+P redo, the pure mixed-addition path) against the oracle's MSM on the SAME downloaded bases,
+    and the A/B decomposition helper against both (pins the helper used at full size)."""
+    w = gpu_workers(curve)
+    q = w.q64
+    d_b, d_s = w.alloc(n * 16 * q), w.alloc(n * 32)
+    w.synth_bases(0x5EED, 0, n, d_b.ptr)
+    w.synth_fr(0x77, d_s.ptr, n)
+    w.init_dev(d_b.ptr, n, 0, 0)
+    bases = d_b.download((n, 2 * q))
+    assert len({bytes(r) for r in bases[: min(n, 5000)]}) == min(n, 5000)          # distinct indeed
+    sc = oracle.from_mont(cid, d_s.download((n, 4)))
+    got = w.commit_dev(d_s.ptr, n)
+    g, gi = w.g1_to_affine(got)
+    e, ei = oracle.jac_to_affine(cid, oracle.msm(cid, bases, sc, threads=8))
+    assert gi == ei and np.array_equal(g, e)
+    e2, ei2 = oracle.jac_to_affine(cid, distinct_bases_expected(oracle, cid, 0x5EED, sc))
+    assert ei2 == ei and np.array_equal(e2, e)
+    d_b.free(); d_s.free()
+
+
+@pytest.mark.parametrize("curve,cid,log_n", [("bn254", 0, 24), ("bls12_381", 1, 22)])
+def test_msm_full_size_distinct_bases_exact(gpu_workers, oracle, curve, cid, log_n):
+    """the configuration bench.py times (`--bases distinct`, full bucket load through the fast mixed-addition
+    kernel) compared with the oracle EXACTLY at BASELINE's sizes."""
+    w = gpu_workers(curve)
+    n, q = 1 << log_n, w.q64
+    d_b, d_s = w.alloc(n * 16 * q), w.alloc(n * 32)
+    w.synth_bases(0x5EED, 0, n, d_b.ptr)
+    w.synth_fr(0xD15EA5E, d_s.ptr, n)
+    w.init_dev(d_b.ptr, n, 0, 0)
+    got = w.commit_dev(d_s.ptr, n)
+    sc = oracle.from_mont(cid, d_s.download((n, 4)))
+    g, gi = w.g1_to_affine(got)
+    e, ei = oracle.jac_to_affine(cid, distinct_bases_expected(oracle, cid, 0x5EED, sc))
+    assert gi == ei and np.array_equal(g, e)
+    d_b.free(); d_s.free()
+
+
+def test_msm_sliced_small_matches_oracle(gpu_workers, oracle):
+    """The slicing path of msm_run (MSMs above 2^26 points are computed slice by slice) forced at 2^10-point slices:
+    17 slices incl. a ragged last one, against the oracle directly."""
+    w = gpu_workers("bn254")
+    n = (1 << 14) + 5
+    bases = oracle.gen_bases(0, 31, 500, n)
+    sc = oracle.from_mont(0, oracle.rand_fr(0, 32, n))
+    w.init(bases, 0, 0)
+    w.set_option("msm_slice_log", 10)
+    try:
+        got = w.var_msm(MsmWorkload(0, n), sc)
+    finally:
+        w.set_option("msm_slice_log", 26)
+    g, gi = w.g1_to_affine(got)
+    e, ei = oracle.jac_to_affine(0, oracle.msm(0, bases, sc, threads=8))
+    assert gi == ei and np.array_equal(g, e)
+
+
+def test_msm_above_2p26_points_sliced_exact(gpu_workers, oracle):
+    """configs[4] territory (2^28 gates over 8 GPUs = 2^25 per GPU; a single GPU can be handed more): n = 2^26 + 2^20 points
+    takes the real two-slice path; exact through tiled bases."""
+    w = gpu_workers("bn254")
+    n, u, q = (1 << 26) + (1 << 20), 1 << 11, w.q64
+    d_b, d_s = w.alloc(n * 16 * q), w.alloc(n * 32)
+    w.synth_bases(0xB1, u, n, d_b.ptr)
+    w.synth_fr(0x5D, d_s.ptr, n)
+    w.init_dev(d_b.ptr, n, 0, 0)
+    got = w.commit_dev(d_s.ptr, n)
+    p = int.from_bytes(oracle.field_const(0, 0, 0).tobytes(), "little")
+    sc = oracle.from_mont(0, d_s.download((n, 4)))
+    want = oracle.msm(0, oracle.gen_bases(0, 0xB1, u, u), _ints_mod_sum(sc, u, p), threads=8)
+    g, gi = w.g1_to_affine(got)
+    e, ei = oracle.jac_to_affine(0, want)
+    assert gi == ei and np.array_equal(g, e)
+    d_b.free(); d_s.free()
 
 
 def test_ntt_2p25_matches_oracle_everywhere(gpu_workers, oracle):

@@ -133,6 +133,31 @@ def test_poly_eval_div_special_points(gpu_workers, oracle):
     dpoly.free(); dq.free()
 
 
+def test_power_table_cache_eviction_keeps_tables_of_the_current_call(gpu_workers, oracle):
+    """the power-table cache holds 64 tables.  poly_div_linear(z) fetches the z table and then the 1/z table; with z
+    the OLDEST cached entry and 1/z a miss on a full cache, a FIFO eviction freed the z table before the kernel read it.
+    Fill the cache exactly, then divide by the oldest point (and keep dividing so freed memory gets reused)."""
+    w = gpu_workers("bn254")
+    length = 3000
+    poly = oracle.rand_fr(0, 4242, length)
+    pts = oracle.rand_fr(0, 4243, 70)
+    dpoly = w.alloc(length * 32).upload(poly)
+    dq = w.alloc(length * 32)
+    # a fresh context would start empty; this one is shared, so first flush whatever is cached with 64 throw-away points
+    for z in oracle.rand_fr(0, 4244, 64):
+        w.poly_eval_dev(dpoly.ptr, length, z)
+    w.poly_eval_dev(dpoly.ptr, length, pts[0])                 # oldest entry from here on
+    for z in pts[1:64]:
+        w.poly_eval_dev(dpoly.ptr, length, z)                  # cache full: pts[0] .. pts[63]
+    for z in (pts[0], pts[1], pts[2]):                         # hit on z (oldest), miss on 1/z -> eviction inside the call
+        w.poly_div_linear_dev(dpoly.ptr, length, z, dq.ptr)
+        for filler in pts[64:]:                                # churn: the freed block is handed out again
+            w.poly_eval_dev(dpoly.ptr, length, filler)
+        w.poly_div_linear_dev(dpoly.ptr, length, z, dq.ptr)
+        assert np.array_equal(dq.download((length - 1, 4)), oracle.poly_div_linear(0, poly, z))
+    dpoly.free(); dq.free()
+
+
 def test_poly_div_identity_full_size(gpu_workers, oracle):
     """Size-independent property at 2^24 + 3 coefficients (the batch polynomial's size at BASELINE's n):
     poly(r) == q(r) * (r - z) + poly(z) at a random r, all evaluated on the device."""

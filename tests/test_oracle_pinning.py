@@ -211,3 +211,38 @@ def test_bn254_group_law_published_points():
     sc = np.array([[1, 0, 0, 0], [2, 0, 0, 0]], dtype=np.uint64)
     xy, inf = O.jac_to_affine(0, O.msm(0, bases, sc))
     assert (fq.from_mont(B.from_limbs(xy[:4])), fq.from_mont(B.from_limbs(xy[4:]))) == g3
+
+
+def test_bls12_381_group_law_published_points():
+    """Published known answers for BLS12-381 G1: the 48-byte compressed encodings (ZCash / IETF BLS-signature format: big-endian x,
+    bit 7 = compressed, bit 5 = y is the larger root) of 1G, 2G and 3G — the public keys of the secret keys 1, 2, 3 that every
+    BLS12-381 signature test suite (eth2, IETF draft) carries.  Pins affine doubling / addition, the Jacobian scalar multiplication and
+    the MSM of both oracle layers for the 381-bit field to values from outside this repository, as EIP-196's 2G / 3G do for BN254."""
+    cv = B.BLS12_381
+    fq = cv.fq
+    published = {
+        1: "97f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb",
+        2: "a572cbea904d67468808c8eb50a9450c9721db309128012543902d0ac358a62ae28f75bb8f1c7c42c39a8c5529bf0f4e",
+        3: "89ece308f9d1f0131765212deca99697b112d61f9be9a5f1f3780a51335b3ff981747a0b2ca2179b96d2c0c9024e5224",
+    }
+
+    def zcash_compressed(pt):
+        x, y = pt
+        b = bytearray(x.to_bytes(48, "big"))
+        b[0] |= 0x80 | (0x20 if y > fq.p - y else 0)
+        return b.hex()
+
+    G = (cv.gx, cv.gy)
+    g2 = B.affine_add(cv, G, G)
+    g3 = B.affine_add(cv, g2, G)
+    assert zcash_compressed(G) == published[1] and zcash_compressed(g2) == published[2] and zcash_compressed(g3) == published[3]
+    assert B.scalar_mul(cv, 3, G) == g3
+    for k in (1, 2, 3):
+        jac = O.scalar_mul(1, O.generator(1), np.array([k, 0, 0, 0], dtype=np.uint64))
+        xy, inf = O.jac_to_affine(1, jac)
+        assert not inf
+        assert zcash_compressed((fq.from_mont(B.from_limbs(xy[:6])), fq.from_mont(B.from_limbs(xy[6:])))) == published[k]
+    bases = np.stack([O.generator(1), O.generator(1)])
+    sc = np.array([[1, 0, 0, 0], [2, 0, 0, 0]], dtype=np.uint64)
+    xy, inf = O.jac_to_affine(1, O.msm(1, bases, sc))
+    assert zcash_compressed((fq.from_mont(B.from_limbs(xy[:6])), fq.from_mont(B.from_limbs(xy[6:])))) == published[3]
