@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         } else {
             const uint64_t q = q0 + (uint64_t)t * P.tq;
             const uint64_t k = m0 + (uint64_t)t * P.tk + (uint64_t)idx * P.kstride;
+            bool lazy = false;
             if (P.epi_plane != nullptr) {
                 v = f29_mul(v, f29_from_sat(load_fr(P.epi_plane + q * P.epi_qstride + k)), P.fp);
                 if (P.scale_const_enabled) v = f29_mul(v, P.scale_const, P.fp);
@@ -343,9 +344,9 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             } else if (P.scale_const_enabled) {
                 v = f29_mul(v, P.scale_const, P.fp);
             } else {
-                v = f29_mul(v, params_one(P.fp), P.fp);          // brings the lazy value below 1.36 p
+                lazy = true;                                     // < 7.4p + 2p per stage beyond the second: < 21.4p after nine
             }
-            v = f29_canon(v, P.fp);
+            v = lazy ? f29_canon_lazy(v, P.fp) : f29_canon(v, P.fp);
             uint64_t addr;
             if (P.split_log >= 0)
                 addr = (k >> P.split_log) * P.split_blk + (q << P.split_log) + (k & (((uint64_t)1 << P.split_log) - 1));
