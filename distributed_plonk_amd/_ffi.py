@@ -53,6 +53,8 @@ class QuotientInputs(C.Structure):   # include/plonk_hip.h plonk_quotient_inputs
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p)
 
 # name -> (restype, argtypes); every symbol include/plonk_hip.h declares
+PLONK_COMM_ID_BYTES = 128
+
 SIGNATURES = {
     "plonk_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int]),
     "plonk_destroy": (None, [C.c_void_p]),
@@ -105,6 +107,14 @@ SIGNATURES = {
     "plonk_profile_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "plonk_profile_get": (C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]),
     "plonk_profile_reset": (C.c_int, [C.c_void_p]),
+    "plonk_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "plonk_comm_init": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    "plonk_comm_destroy": (C.c_int, [C.c_void_p]),
+    "plonk_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "plonk_exchange_rccl": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]),
+    "plonk_comm_alltoall_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "plonk_comm_allgather_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "plonk_comm_allgather_host": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

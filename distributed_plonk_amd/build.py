@@ -15,12 +15,27 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(LIBDIR, "libplonk_hip.so")
-UNITS = ["plonk_api.hip", "ntt_engine.hip", "msm_engine.hip", "synth.hip", "quotient.hip", "poly_ops.hip"]
+UNITS = ["plonk_api.hip", "ntt_engine.hip", "msm_engine.hip", "synth.hip", "quotient.hip", "poly_ops.hip", "comm_rccl.hip"]
 HEADERS = ["fp.cuh", "fp29.cuh", "flimb.cuh", "ec.cuh", "ec_lazy.cuh", "constants.h", "ntt_kernels.cuh", "plonk_internal.hpp",
            "../../include/plonk_hip.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources (csrc/* and the C header): PMC-derived numbers committed under profiles/ carry it, and
+    bench.py refuses to quote them for a library built from different sources."""
+    import hashlib
+    h = hashlib.sha256()
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".h", ".hpp")))
+    for f in names:
+        h.update(f.encode())
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(fh.read())
+    with open(os.path.join(HERE, "..", "include", "plonk_hip.h"), "rb") as fh:
+        h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def _newest_header():
@@ -42,7 +57,7 @@ def build(force=False, verbose=True):
         res = list(ex.map(lambda u: _compile(u, force), UNITS))
     objs = [r[0] for r in res]
     if force or any(r[1] for r in res) or not os.path.exists(OUT):
-        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", OUT])
+        subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT])      # librccl is dlopen'ed (comm_rccl.hip)
         if verbose:
             print("built", OUT)
     return OUT

@@ -121,6 +121,35 @@ class TorchComm:
             self.dist.all_gather_into_tensor(self._tensor(d_recv, total), self._tensor(d_send, nbytes))
 
 
+class LibComm:
+    """One process per GPU: the library's own RCCL communicator (plonk_comm_init) — grouped ncclSend/ncclRecv and ncclAllGather on
+    the context's stream, no torch and no Python callback in the data path.  `bootstrap(obj) -> [obj of every rank]` is only used
+    for the handful of small host objects the prover exchanges (partial commitment points travel through
+    plonk_comm_allgather_host)."""
+
+    def __init__(self, worker: PlonkWorker, bootstrap=None):
+        self.w = worker
+        self.rank, self.size, self.rccl_version = worker.comm_info()
+        self._bootstrap = bootstrap
+
+    def all_gather_host(self, obj):
+        if isinstance(obj, (list, tuple)) and obj and all(isinstance(x, np.ndarray) for x in obj):
+            obj = np.stack(obj)                   # the partial points of a round: one ncclAllGather
+        if isinstance(obj, np.ndarray):
+            return list(self.w.comm_allgather_host(obj, self.size))
+        if self.size == 1:
+            return [obj]
+        if self._bootstrap is None:
+            raise TypeError("LibComm.all_gather_host: only numpy arrays travel through RCCL; pass `bootstrap` for other objects")
+        return self._bootstrap(obj)
+
+    def all_to_all_dev(self, d_send: int, d_recv: int, nbytes: int):
+        self.w.comm_alltoall_dev(d_send, d_recv, nbytes)
+
+    def all_gather_dev(self, d_send: int, d_recv: int, nbytes: int):
+        self.w.comm_allgather_dev(d_send, d_recv, nbytes)
+
+
 # --------------------------------------------------------------------------------------------- the SPMD prover
 def shard_range(length: int, rank: int, size: int):
     """coefficients [i*L/S, (i+1)*L/S) — the MSM sharding of dispatcher2.rs:875-878."""

@@ -81,6 +81,7 @@ struct plonk_ctx {
     bool ev_valid = false;
     // small free-list of exchange buffers so that back-to-back transforms do not hipMalloc/hipFree
     std::vector<std::pair<size_t, void*>> pool;
+    PlonkComm* comm = nullptr;                  // RCCL communicator (plonk_comm_init), owned
 };
 
 static int pool_get(plonk_ctx* ctx, size_t bytes, void** out) {
@@ -169,6 +170,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
+    comm_destroy(ctx->comm);
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases) (void)hipFree(ctx->d_bases);
     if (ctx->d_wire) (void)hipFree(ctx->d_wire);
@@ -510,6 +512,57 @@ extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows) {
     return PLONK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------- RCCL transport
+extern "C" int plonk_comm_unique_id(void* out_id) {
+    if (!out_id) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_unique_id: null");
+    return comm_unique_id(out_id);
+}
+extern "C" int plonk_comm_init(plonk_ctx* ctx, const void* id, int rank, int world) {
+    CHECK_CTX(ctx);
+    if (!id) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_init: null id");
+    if (ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_init: the context already has a communicator");
+    return comm_create(&ctx->comm, id, rank, world, ctx->device);
+}
+extern "C" int plonk_comm_destroy(plonk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    comm_destroy(ctx->comm);
+    ctx->comm = nullptr;
+    return PLONK_OK;
+}
+extern "C" int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world, int* rccl_version) {
+    CHECK_CTX(ctx);
+    if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_info: no communicator (plonk_comm_init)");
+    if (rank) *rank = comm_rank(ctx->comm);
+    if (world) *world = comm_world(ctx->comm);
+    if (rccl_version) *rccl_version = comm_rccl_version();
+    return PLONK_OK;
+}
+extern "C" int plonk_exchange_rccl(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream) {
+    plonk_ctx* ctx = (plonk_ctx*)user;
+    if (!ctx || !ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_exchange_rccl: no communicator (plonk_comm_init)");
+    if (n_ranks != comm_world(ctx->comm)) return plonk_fail(PLONK_ERR_ARG, "plonk_exchange_rccl: %d blocks for %d ranks", n_ranks, comm_world(ctx->comm));
+    return comm_alltoall(ctx->comm, send, recv, bytes_per_peer, (hipStream_t)stream);
+}
+extern "C" int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer) {
+    CHECK_CTX(ctx);
+    if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_alltoall_dev: no communicator (plonk_comm_init)");
+    if (!d_send || !d_recv) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_alltoall_dev: null");
+    return comm_alltoall(ctx->comm, d_send, d_recv, bytes_per_peer, ctx->stream);
+}
+extern "C" int plonk_comm_allgather_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
+    CHECK_CTX(ctx);
+    if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_allgather_dev: no communicator (plonk_comm_init)");
+    if (!d_send || !d_recv) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_allgather_dev: null");
+    return comm_allgather(ctx->comm, d_send, d_recv, bytes, ctx->stream);
+}
+extern "C" int plonk_comm_allgather_host(plonk_ctx* ctx, const void* in, size_t bytes, void* out) {
+    CHECK_CTX(ctx);
+    if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_allgather_host: no communicator (plonk_comm_init)");
+    if (!in || !out || !bytes) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_allgather_host: null / empty");
+    return comm_allgather_host(ctx->comm, in, bytes, out, ctx->stream);
+}
+
 // ---------------------------------------------------------------------------------------------- fft2Prepare @4 (+ fftExchange)
 extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn exchange, void* user) {
     CHECK_CTX(ctx);
@@ -520,7 +573,13 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     if (t->rows_filled != t->nrows) return plonk_fail(PLONK_ERR_STATE, "plonk_fft2_prepare: %llu of %llu rows received", (unsigned long long)t->rows_filled,
                                                       (unsigned long long)t->nrows);
     const size_t S = t->wl.size();
-    if (S > 1 && !exchange) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu ranks need an exchange callback", S);
+    if (!exchange && ctx->comm) {               // the in-library RCCL transport
+        if ((size_t)comm_world(ctx->comm) != S)
+            return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu workloads but the communicator has %d ranks", S, comm_world(ctx->comm));
+        exchange = plonk_exchange_rccl;
+        user = ctx;
+    }
+    if (S > 1 && !exchange) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu ranks need plonk_comm_init or an exchange callback", S);
     const size_t tile_bytes = t->nrows * t->c * 32;     // == r * ncols * 32
     if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_send))) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));

@@ -181,3 +181,15 @@ size_t coset_scratch_bytes(size_t size);
 int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, const uint64_t* shift, void* d_out, void* scratch, hipStream_t stream);
 int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count, void* d_out,
                      void* scratch, hipStream_t stream);
+
+// ----------------------------------------------------------------------------------------------- RCCL transport (comm_rccl.hip)
+struct PlonkComm;
+int comm_unique_id(void* out128);
+int comm_create(PlonkComm** out, const void* id128, int rank, int world, int device);
+void comm_destroy(PlonkComm* c);
+int comm_rank(const PlonkComm* c);
+int comm_world(const PlonkComm* c);
+int comm_rccl_version();
+int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream);
+int comm_allgather(PlonkComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream);
+int comm_allgather_host(PlonkComm* c, const void* in, size_t bytes, void* out, hipStream_t stream);

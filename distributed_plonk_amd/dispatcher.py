@@ -199,12 +199,20 @@ class RankProver:
     """One rank of the multi-GPU path: this process owns one GPU, `rank` of `world` workers."""
 
     def __init__(self, worker: PlonkWorker, rank: int, world: int, group=None, seed: int = 0xD15EA5E, force_exchange: bool = False,
-                 exchange=None):
+                 exchange=None, transport: str = "torch"):
+        """transport "rccl": the worker carries its own RCCL communicator (PlonkWorker.comm_init) and the library performs the
+        all-to-all and the point gather itself — no Python in the data path; "torch": torch.distributed (nccl = RCCL, or gloo in
+        the CPU tests) through the exchange callback.  `exchange` overrides both (bench.py --simulate-ranks: a no-op)."""
         self.w, self.rank, self.world, self.group = worker, rank, world, group
         worker.me = rank
+        self.transport = transport
         self._rng = random.Random(seed)          # same seed on every rank -> same task ids
-        # `exchange` overrides the transport (bench.py --simulate-ranks times one rank's compute with a no-op exchange)
-        self._exchange = exchange if exchange is not None else (make_torch_exchange(group) if (world > 1 or force_exchange) else None)
+        if exchange is not None:
+            self._exchange = exchange
+        elif transport == "rccl":
+            self._exchange = None                # plonk_fft2_prepare(ctx, id, NULL, NULL): the context's communicator
+        else:
+            self._exchange = make_torch_exchange(group) if (world > 1 or force_exchange) else None
 
     def fft_dev(self, d_rows_ptr: int, d_out_ptr: int, domain_size: int, is_quot: bool, is_inv: bool, is_coset: bool,
                 out_layout: int = 1):
@@ -224,6 +232,7 @@ class RankProver:
         if self.world == 1:
             return part
         acc = None
-        for p in gather_points(part, self.group, device):
+        parts = self.w.comm_allgather_host(part, self.world) if self.transport == "rccl" else gather_points(part, self.group, device)
+        for p in parts:
             acc = p if acc is None else self.w.g1_add(acc, p)
         return acc

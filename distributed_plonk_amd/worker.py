@@ -81,6 +81,43 @@ class PlonkWorker:
         except Exception:
             pass
 
+    # ------------------------------------------------------------------ in-library RCCL transport
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """ncclGetUniqueId (rank 0 calls it and ships the 128 bytes to the other ranks out of band)."""
+        buf = C.create_string_buffer(_ffi.PLONK_COMM_ID_BYTES)
+        check(_ffi.lib().plonk_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int):
+        """ncclCommInitRank on this context's GPU; collective over all `world` ranks.  Afterwards fft2_prepare(id) without a callback
+        runs the all-to-all through RCCL inside the library."""
+        assert len(unique_id) == _ffi.PLONK_COMM_ID_BYTES
+        check(self.lib.plonk_comm_init(self.ctx, unique_id, rank, world))
+        self.me = rank
+
+    def comm_destroy(self):
+        check(self.lib.plonk_comm_destroy(self.ctx))
+
+    def comm_info(self):
+        """-> (rank, world, rccl_version) as RCCL reports them."""
+        r, w, v = C.c_int(), C.c_int(), C.c_int()
+        check(self.lib.plonk_comm_info(self.ctx, C.byref(r), C.byref(w), C.byref(v)))
+        return r.value, w.value, v.value
+
+    def comm_alltoall_dev(self, d_send: int, d_recv: int, bytes_per_peer: int):
+        check(self.lib.plonk_comm_alltoall_dev(self.ctx, d_send, d_recv, bytes_per_peer))
+
+    def comm_allgather_dev(self, d_send: int, d_recv: int, nbytes: int):
+        check(self.lib.plonk_comm_allgather_dev(self.ctx, d_send, d_recv, nbytes))
+
+    def comm_allgather_host(self, arr: np.ndarray, world: int) -> np.ndarray:
+        """Every rank's `arr` (same size everywhere) -> (world, *arr.shape)."""
+        a = np.ascontiguousarray(arr)
+        out = np.empty((world,) + a.shape, dtype=a.dtype)
+        check(self.lib.plonk_comm_allgather_host(self.ctx, _ptr(a), a.nbytes, _ptr(out)))
+        return out
+
     # ------------------------------------------------------------------ PlonkSlave @0
     def init(self, bases: Optional[np.ndarray], domain_size: int, quot_domain_size: int, layout=_ffi.PLONK_BASES_XY):
         """worker.rs:126-157.  bases: (n, 2*Q) x||y Montgomery limbs, or raw ark bytes for PLONK_BASES_ARK."""

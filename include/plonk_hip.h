@@ -62,6 +62,29 @@ typedef struct { uint64_t start, end; } plonk_msm_workload;
 typedef int (*plonk_exchange_fn)(void* user, const void* send, void* recv, size_t bytes_per_peer,
                                  int n_ranks, void* stream);
 
+/* ---- in-library transport: RCCL over xGMI (replaces the worker<->worker TCP + Cap'n Proto links of worker.rs:280-345,412-438
+ * and the `result: Data` replies the dispatcher adds up, dispatcher.rs:236-238).  One process per GPU.  Rank 0 obtains an id with
+ * plonk_comm_unique_id and ships its 128 bytes to the other ranks out of band (the reference's config/network.json + TCP play
+ * that role); every rank then calls plonk_comm_init — a collective: it returns when all `world` ranks have joined.  With a
+ * communicator attached, plonk_fft2_prepare(ctx, id, NULL, NULL) performs the all-to-all itself (grouped ncclSend/ncclRecv on the
+ * context's stream); the callback form stays for tests and for hosts that bring their own transport.  Two contexts of one
+ * process (two streams) need two communicators, created in the same order on every rank, and every rank must issue its
+ * collectives in the same order. */
+#define PLONK_COMM_ID_BYTES 128
+int plonk_comm_unique_id(void* out_id);
+int plonk_comm_init(plonk_ctx* ctx, const void* id, int rank, int world);
+int plonk_comm_destroy(plonk_ctx* ctx);
+/* rank / world as RCCL reports them (ncclCommUserRank / ncclCommCount), and the RCCL version code (ncclGetVersion) */
+int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world, int* rccl_version);
+/* plonk_exchange_fn backed by the context's communicator: pass as `exchange` with user = ctx (what a NULL callback selects) */
+int plonk_exchange_rccl(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream);
+/* device buffers, ordered on the context's stream, not synchronised: block p of d_send -> rank p / every rank's d_send -> block
+ * `rank` of everybody's d_recv.  The two data-path collectives of the coset-class prover. */
+int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer);
+int plonk_comm_allgather_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
+/* host buffers (partial commitment points, 96 / 144 B each): out receives world * bytes.  Synchronises. */
+int plonk_comm_allgather_host(plonk_ctx* ctx, const void* in, size_t bytes, void* out);
+
 /* ---- lifetime ------------------------------------------------------------------------------- */
 /* State::new, worker.rs:455-472. */
 int plonk_create(plonk_ctx** out, int device, int curve);
@@ -90,7 +113,8 @@ int plonk_fft_init(plonk_ctx* ctx, uint64_t id, const plonk_fft_workload* worklo
 int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_t* v, size_t len);
 /* ---- PlonkSlave @4 fft2Prepare + PlonkPeer @0 fftExchange — worker.rs:280-345, 412-438 --------
  * Row pass on every local row, then the all-to-all block transpose.  Collective: every rank calls
- * it for the same id.  exchange may be NULL when n_workloads == 1. */
+ * it for the same id.  exchange == NULL: the context's RCCL communicator (plonk_comm_init) carries the all-to-all; with a
+ * single workload and no communicator there is nothing to exchange. */
 int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn exchange, void* user);
 /* ---- PlonkSlave @5 fft2 — worker.rs:347-381 (helper :96-115).  out_cols receives num_cols
  * columns of r elements each (column-major blobs, as the reply of worker.rs:366-376); the task is

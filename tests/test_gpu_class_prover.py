@@ -134,3 +134,28 @@ def test_shard_range_covers_everything():
             edges = [shard_range(length, r, G) for r in range(G)]
             assert edges[0][0] == 0 and edges[-1][1] == length
             assert all(a[1] == b[0] for a, b in zip(edges, edges[1:]))
+
+
+def test_class_prover_over_in_library_rccl_single_rank(oracle):
+    """The same degenerate G = 1 proof through LibComm: the library's own RCCL communicator carries the all-to-all, the all-gather
+    of quotient coefficients and the all-gather of partial commitment points — no torch.distributed anywhere."""
+    from distributed_plonk_amd.class_prover import LibComm
+    from distributed_plonk_amd.worker import PlonkWorker
+    log_n = 8
+    P, circ, ck, inf, bl, ch = _instance(oracle, 0, log_n, 801)
+    n = 1 << log_n
+    lanes = [PlonkWorker(me=0, device=0, curve="bn254") for _ in range(2)]
+    try:
+        lanes[0].comm_init(PlonkWorker.comm_unique_id(), 0, 1)
+        for wk in lanes:
+            wk.init(ck, n, 8 * n)
+        pv = ClassProver(lanes[0], log_n, LibComm(lanes[0]), commit_helper=lanes[1])
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+        finally:
+            pv.close()
+        _check(got, P.prove_rounds(0, log_n, ck, inf, circ, bl, ch, threads=8))
+    finally:
+        for wk in lanes:
+            wk.close()

@@ -196,3 +196,71 @@ def test_two_contexts_pipelined_transforms(oracle):
         for wk in lanes:
             wk.close()
         dist.destroy_process_group()
+
+
+def test_in_library_rccl_transport_single_rank(oracle):
+    """The transport INSIDE libplonk_hip.so (plonk_comm_init + grouped ncclSend/ncclRecv on the context's stream, comm_rccl.hip) on a
+    world of 1 — no torch, no callback: plonk_fft2_prepare(ctx, id, NULL, NULL) exchanges through RCCL; all four modes, two
+    contexts with two communicators pipelined like bench.py's lanes; plus the point all-gather and the raw device collectives."""
+    from distributed_plonk_amd._ffi import PlonkError
+    from distributed_plonk_amd.dispatcher import RankProver
+    from distributed_plonk_amd.worker import PlonkWorker
+    lanes = [PlonkWorker(me=0, device=0, curve="bn254") for _ in range(2)]
+    try:
+        with pytest.raises(PlonkError) as e:
+            lanes[0].comm_info()                                   # no communicator yet
+        assert e.value.code == -4
+        for wk in lanes:                                           # one communicator per context, created in the same order everywhere
+            wk.comm_init(PlonkWorker.comm_unique_id(), 0, 1)
+        rank, world, ver = lanes[0].comm_info()
+        assert (rank, world) == (0, 1) and ver > 0
+        with pytest.raises(PlonkError):
+            lanes[0].comm_init(PlonkWorker.comm_unique_id(), 0, 1)  # already has one
+        log_n = 14
+        N = 1 << log_n
+        r, c = split_rc(N)
+        provers = []
+        for wk in lanes:
+            wk.init(None, N, 0)
+            provers.append(RankProver(wk, 0, 1, transport="rccl"))
+        K = 8
+        coeffs = [oracle.rand_fr(0, 700 + i, N) for i in range(K)]
+        ins, outs = [], []
+        for i in range(K):
+            wk = lanes[i % 2]
+            ins.append(wk.alloc(N * 32).upload(np.ascontiguousarray(coeffs[i].reshape(c, r, 4).transpose(1, 0, 2))))
+            outs.append(wk.alloc(N * 32))
+        for i in range(K):                                          # enqueue everything, no host sync in between
+            is_inv, is_coset = MODES[i % 4]
+            provers[i % 2].fft_dev(ins[i].ptr, outs[i].ptr, N, False, is_inv, is_coset, out_layout=1)
+        for wk in lanes:
+            wk.sync()
+        for i in range(K):
+            is_inv, is_coset = MODES[i % 4]
+            assert np.array_equal(outs[i].download((N, 4)), oracle.ntt(0, coeffs[i], is_inv, is_coset, threads=8)), i
+        # varMsm replies: all-gather of host points
+        pts = lanes[0].comm_allgather_host(np.arange(36, dtype=np.uint64).reshape(3, 12), 1)
+        assert pts.shape == (1, 3, 12) and np.array_equal(pts[0], np.arange(36, dtype=np.uint64).reshape(3, 12))
+        # raw device collectives (the class prover's two data-path exchanges)
+        a, b = lanes[0].alloc(4096), lanes[0].alloc(4096)
+        a.upload(np.arange(512, dtype=np.uint64))
+        lanes[0].comm_alltoall_dev(a.ptr, b.ptr, 4096)
+        lanes[0].sync()
+        assert np.array_equal(b.download((512,)), np.arange(512, dtype=np.uint64))
+        lanes[0].memset_dev(b.ptr, 0, 4096)
+        lanes[0].comm_allgather_dev(a.ptr, b.ptr, 4096)
+        lanes[0].sync()
+        assert np.array_equal(b.download((512,)), np.arange(512, dtype=np.uint64))
+        # a workload list that disagrees with the communicator is an error, not a hang
+        wl = make_fft_workloads(N, 2)
+        lanes[0].fft_init(99, wl, False, False, False)
+        d = lanes[0].alloc(N * 16)
+        lanes[0].fft1_dev(99, d.ptr)
+        with pytest.raises(PlonkError):
+            lanes[0].fft2_prepare(99, None)
+        lanes[0].comm_destroy()
+        with pytest.raises(PlonkError):
+            lanes[0].comm_info()
+    finally:
+        for wk in lanes:
+            wk.close()

@@ -49,32 +49,10 @@ def test_msm_full_size_tiled_bases_exact(gpu_workers, oracle, curve, cid, log_n)
         b.free()
 
 
-def _limbs_from_halves(halves, p):
-    out = np.zeros((halves.shape[0], 4), dtype=np.uint64)
-    for j in range(halves.shape[0]):
-        v = sum(int(halves[j, k]) << (32 * k) for k in range(8)) % p
-        out[j] = [(v >> (64 * k)) & (2**64 - 1) for k in range(4)]
-    return out
-
-
 def distinct_bases_expected(oracle, cid, seed, sc, threads=8):
-    """The SRS-like distribution bench.py times by default (`plonk_synth_bases(unique = 0)`): P_i = A[i % 4096] + B[i / 4096] with
-    A = gen_bases(seed), B = gen_bases(seed + 1), pairwise distinct.  Then
-        sum_i s_i P_i = sum_a (sum_{i % 4096 = a} s_i) A_a + sum_b (sum_{i / 4096 = b} s_i) B_b
-    — two small oracle MSMs of aggregated scalars give the EXACT expected point at any n.  sc: canonical scalars (n, 4)."""
-    n, na = sc.shape[0], 4096
-    nbb = (n + na - 1) // na
-    p = int.from_bytes(oracle.field_const(cid, 0, 0).tobytes(), "little")
-    pad = nbb * na - n
-    h = sc.view(np.uint32).reshape(n, 8)
-    if pad:
-        h = np.vstack([h, np.zeros((pad, 8), dtype=np.uint32)])
-    h = h.reshape(nbb, na, 8).astype(np.uint64)
-    agg_a = _limbs_from_halves(h.sum(axis=0), p)                 # (na, 8) sums of 32-bit halves: < 2^32 * nbb, no overflow below 2^32 rows
-    agg_b = _limbs_from_halves(h.sum(axis=1), p)
-    A = oracle.gen_bases(cid, seed, na, na)
-    B = oracle.gen_bases(cid, seed + 1, nbb, nbb)
-    return oracle.jac_add(cid, oracle.msm(cid, A, agg_a, threads=threads), oracle.msm(cid, B, agg_b, threads=threads))
+    """Exact expected point for the SRS-like distribution bench.py times by default — see oracle/checks.py."""
+    from oracle import checks
+    return checks.msm_expected_distinct(cid, seed, sc, threads=threads)
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
