@@ -60,14 +60,62 @@ def parse():
                     help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
                          "on by default for N > 1, reported under next_rows, never part of `value`")
     ap.add_argument("--no-class-prover", action="store_true", help="N > 1: skip the coset-class prover leg")
+    ap.add_argument("--scheme", default="classes", choices=["classes", "reference2d"],
+                    help="N > 1: how the step's transforms are distributed.  'classes' (default): rank s evaluates every polynomial on ITS coset "
+                         "class (the points j = s mod N of the 8n-point coset) with a local zero-padding-aware (8n/N)-point transform - no "
+                         "exchange for the 25 forward coset FFTs; the quotient's coset iFFT is one class-local inverse transform + ONE all-to-all "
+                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs run on every rank.  'reference2d': every one "
+                         "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass) on dense "
+                         "inputs.  The other scheme is timed after the headline and reported as `other_scheme`")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: validate the arguments for this --gpus (divisibility of r and n, class count, buffer sizes per rank) and print the plan")
+    ap.add_argument("--multi-path", action="store_true",
+                    help="diagnostic: run the N > 1 code path (communicators, collectives, class scheme) on a world of ONE rank")
     ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
                     help="N > 1 data path: 'rccl' = the communicator inside libplonk_hip.so (plonk_comm_init; grouped ncclSend/ncclRecv on the "
                          "library's stream, no Python in the exchange), 'torch' = torch.distributed.all_to_all_single through the callback")
     return ap.parse_args()
 
 
+def plan(args, S):
+    """Everything that can be decided without a GPU: used by --dry-run (tools/preflight_multi.sh) and checked again at start-up."""
+    n, m = 1 << args.log_n, 8 << args.log_n
+    two_adicity = 28 if args.curve == "bn254" else 32
+    problems = []
+    if args.log_n + 3 > two_adicity:
+        problems.append(f"the quotient domain 2^{args.log_n + 3} exceeds the field's two-adicity {two_adicity} (DomainCreationError)")
+    if S & (S - 1):
+        problems.append(f"{S} ranks: the row / column / class partitions need a power of two")
+    sizes = {}
+    for name, N_ in (("n", n), ("8n", m)):
+        log = N_.bit_length() - 1
+        r_, c_ = 1 << (log >> 1), 1 << (log - (log >> 1))
+        if r_ % S or c_ % S:
+            problems.append(f"{S} ranks do not divide r = {r_} / c = {c_} of the 2^{log}-point 2-D transform")
+        sizes[name] = {"r": r_, "c": c_, "rows_per_rank": r_ // max(S, 1), "cols_per_rank": c_ // max(S, 1),
+                       "bytes_per_pair_per_exchange": (r_ // S) * (c_ // S) * 32 if S > 1 else 0}
+    if S > 8:
+        problems.append(f"{S} ranks: the coset-class scheme needs N <= 8n/n = 8 classes")
+    GiB = float(1 << 30)
+    q_bytes = 64 if args.curve == "bn254" else 96
+    limb_bytes = 72 if args.curve == "bn254" else 112
+    if S == 1:
+        hbm = 2 * n * 32 + 2 * m * 32 + (n + 3) * 32 + m * 32 + 2 * (n * limb_bytes) + n * q_bytes + 2 * m * 32    # buffers + scratch + SRS (two contexts) + planes
+    else:
+        hbm = (2 * 2 * (n // S) * 32 + 2 * 2 * (m // S) * 32            # reference2d lanes
+               + 2 * n * 32 + (n + 3) * 32 + 2 * (m // S) * 32 + 3 * m * 32     # classes: bn, poly, out/mine, contrib/recv/quot
+               + 2 * (n // S) * limb_bytes + (n // S) * q_bytes + (m // S) * 32 * 2)
+    return {"n": n, "m": m, "ranks": S, "scheme": args.scheme if S > 1 else "single", "transforms": sizes,
+            "msm_points_per_rank": n // S, "class_points_per_rank": m // S, "approx_hbm_GiB_per_rank_headline": round(hbm / GiB, 1),
+            "problems": problems, "ok": not problems}
+
+
 def main():
     args = parse()
+    if args.dry_run:
+        p_ = plan(args, max(args.gpus, args.simulate_ranks, 1))
+        print(json.dumps(p_))
+        raise SystemExit(0 if p_["ok"] else 2)
     # stdout carries exactly ONE JSON line: libraries that print there (RCCL's version banner at the first collective) are
     # sent to stderr by pointing fd 1 at fd 2 for the duration of the run; the result goes out through the saved descriptor
     sys.stdout.flush()
@@ -99,12 +147,14 @@ def main():
     sim = args.simulate_ranks if (world == 1 and args.simulate_ranks > 1) else 0
     if sim:
         S = sim
-    if (split_rc(n)[0] % S) or (n % S):
-        raise SystemExit(f"{S} ranks do not divide r = {split_rc(n)[0]}")
+    pl = plan(args, S)
+    if not pl["ok"]:
+        raise SystemExit("bench.py: " + "; ".join(pl["problems"]))
     dev = torch.device("cuda", local_rank)
     # N > 1: two contexts (two HIP streams) per rank, so that the all-to-all of one transform overlaps the
     # row / column passes of the next (the 26 size-8n transforms of a proof are independent polynomials)
-    n_lanes = 2 if S > 1 else 1
+    multi = S > 1 or args.multi_path
+    n_lanes = 2 if multi else 1
     # always two contexts for the commitments: the 13 MSMs of a proof are independent, and a second stream fills the sort /
     # reduction phases and the wave tail of one MSM with the bucket accumulation of the next (measured: 29.3 -> 26.8 ms per
     # 2^24-point commit, 4.9 -> 4.0 ms at the 2^21 points of an 8-rank shard; tools/msm_overlap.py)
@@ -112,9 +162,13 @@ def main():
     w = workers[0]
     q64 = w.q64
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
-    transport = args.transport if world > 1 else "torch"
+    transport = args.transport if (world > 1 or args.multi_path) else "torch"
     rccl_info = None
-    if world > 1 and transport == "rccl":
+    if args.multi_path and world == 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29655")
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    if (world > 1 or args.multi_path) and transport == "rccl" and not sim:
         # one RCCL communicator per context (two streams -> two communicators), created in the same order on every rank; the
         # 128-byte ids travel once through the launcher's rendezvous — nothing else of the data path touches torch
         ids = [PlonkWorker.comm_unique_id() for _ in workers] if rank == 0 else [None] * len(workers)
@@ -134,7 +188,7 @@ def main():
         w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
     # the coefficient vectors the 25 forward coset transforms start from: n + 3 coefficients (the blinded permutation polynomial's
     # length; wires have n + 2, selectors n), which the reference zero-pads to 8n (dispatcher2.rs:746)
-    padded = (S == 1) and not args.dense_coset
+    padded = (S == 1) and not multi and not args.dense_coset
     poly_len = n + 3
     gen_limbs = None
     buf_p = None
@@ -197,7 +251,7 @@ def main():
             t_.join()
         if errs:
             raise errs[0]
-        if S == 1 or sim:
+        if not multi or sim:
             return parts[-1]
         flat = np.concatenate(parts)                                         # one collective for all partial points
         gathered = list(w.comm_allgather_host(flat, world)) if transport == "rccl" else gather_points(flat, None, dev)
@@ -219,6 +273,59 @@ def main():
         # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
         #  distorting the per-launch NTT timings the roofline is computed from)
         return commits_finish(commits_start(N_MSM))
+
+    # ---- N > 1, scheme "classes": the step with the coset-class decomposition.  Every rank holds the coefficient
+    # vectors (the size-n iNTTs that produce them run on every rank: 2.6 ms each, cheaper than gathering them), evaluates all 25
+    # polynomials on its OWN class of the 8n-point coset with a local zero-padding-aware (8n/N)-point transform, and the quotient's
+    # coset iFFT is the class-local inverse + one all-to-all (sum) + one all-gather.  Same work as the reference's 33 distributed
+    # transforms, two data-path collectives instead of 33.
+    cls = None
+    if multi:
+        from distributed_plonk_amd import fr as _fr
+        f_ = _fr.FIELDS[args.curve]
+        G = S
+        mL = m // G
+        cls = dict(
+            bn=[w.alloc(n * 32), w.alloc(n * 32)], poly=w.alloc(poly_len * 32), out=w.alloc(mL * 32),
+            contrib=w.alloc(m * 32), recv=w.alloc(m * 32), mine=w.alloc(mL * 32), quot=w.alloc(m * 32),
+            shift=f_.to_limbs(f_.generator * pow(f_.root_of_unity(m), rank, f_.p) % f_.p), inv_g=f_.to_limbs(pow(G, -1, f_.p)),
+            ones=np.tile(f_.to_limbs(1), (G, 1)))
+        w.synth_fr(0xD15EA5E, cls["bn"][0].ptr, n)             # the same vectors on every rank
+        w.synth_fr(0xC0EFF, cls["poly"].ptr, poly_len)
+        w.synth_fr(0x5EC7, cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
+
+    def step_classes():
+        c = cls
+        for _ in range(N_NTT_SMALL):
+            w.ntt_dev(c["bn"][0].ptr, c["bn"][1].ptr, n, True, False)
+            c["bn"][0], c["bn"][1] = c["bn"][1], c["bn"][0]
+        for _ in range(N_NTT_BIG - 1):
+            w.coset_eval_dev(c["poly"].ptr, poly_len, mL, c["shift"], c["out"].ptr)
+        # quotient coefficients: this class's additive share of every coefficient, summed across ranks, then replicated
+        w.coset_interp_dev(c["out"].ptr, mL, c["shift"], c["inv_g"], 0, m, c["contrib"].ptr)
+        if not sim:
+            if transport == "rccl":
+                w.comm_alltoall_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
+            else:
+                torch_comm.all_to_all_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
+        w.poly_lincomb_dev([(c["recv"].ptr + p_ * mL * 32, mL) for p_ in range(G)], c["ones"], c["mine"].ptr, mL)
+        if not sim:
+            if transport == "rccl":
+                w.comm_allgather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
+            else:
+                torch_comm.all_gather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
+        for x in workers:
+            x.sync()
+        return commits_finish(commits_start(N_MSM))
+
+    torch_comm = None
+    if multi and transport == "torch" and not sim:
+        from distributed_plonk_amd.class_prover import TorchComm
+        torch_comm = TorchComm(w, dev)
+    scheme = args.scheme if multi else "single"
+    step_ref2d = step
+    if scheme == "classes":
+        step = step_classes
 
     def full_sync():
         for x in set(workers) | set(cworkers):
@@ -245,6 +352,29 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n / (dt / args.steps)
 
+    # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
+    other_scheme = None
+    if multi and not sim:
+        try:
+            other = step_ref2d if scheme == "classes" else step_classes
+            other()
+            full_sync()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                other()
+            full_sync()
+            dt2 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            other_scheme = {"scheme": "reference2d" if scheme == "classes" else "classes", "steps": 2, "ms_per_step": round(dt2 / 2 * 1e3, 3),
+                            "constraints_per_s": round(n / (dt2 / 2), 1),
+                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform on dense inputs (33 RCCL "
+                                    "all-to-alls per step); classes = rank-local coset classes, 2 data-path collectives per step"}
+        except Exception as ex:
+            other_scheme = {"error": repr(ex)}
+
     # ---- roofline of the dominant kernel (HIP events recorded around every launch in the timed region)
     kernels = {}
     for name in ["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order",
@@ -255,7 +385,10 @@ def main():
     aff_bytes = 16 * q64
     # algorithmic bytes: NTT(N) = 2*N*32 per transform, spread over its pass launches;
     # MSM(n) = n*(sizeof(affine)+32) per MSM, attributed to the bucket-accumulation launch.
-    ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + N_NTT_BIG * m_loc)
+    if scheme == "classes":      # per rank: the 7 size-n iNTTs in full (they run on every rank), its class (8n/N points) of the 26 big ones
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n + N_NTT_BIG * m_loc)
+    else:
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + N_NTT_BIG * m_loc)
     msm_alg_total = args.steps * N_MSM * n_loc * (aff_bytes + 32.0)
     roof = {}
     if "ntt_pass_kernel" in kernels:
@@ -308,7 +441,7 @@ def main():
 
     # ---- result checks, after and outside the timed region (rank 0, N == 1): the oracle as CHECKER of what was just timed
     verified, verification = None, None
-    if rank == 0 and world == 1 and not sim and not args.no_verify:
+    if rank == 0 and world == 1 and not multi and not sim and not args.no_verify:
         verification = {}
         try:
             from oracle import checks, oracle as O
@@ -372,7 +505,7 @@ def main():
 
     # ---- next row, measured on its own, NOT part of `value`: quotient coset evaluations over 8n points
     next_rows = None
-    if rank == 0 and world == 1 and not sim and not args.no_next_rows:
+    if rank == 0 and world == 1 and not multi and not sim and not args.no_next_rows:
         try:
             vecs = [w.alloc(m * 32) for _ in range(25)]
             for j, b in enumerate(vecs):
@@ -485,7 +618,7 @@ def main():
 
     # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
     class_row = None
-    if (args.class_prover or world > 1) and not args.no_class_prover and not sim:
+    if (args.class_prover or multi) and not args.no_class_prover and not sim:
         from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -506,7 +639,7 @@ def main():
         consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
         ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
         bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-        if transport == "rccl" and world > 1:
+        if transport == "rccl" and multi:
             def _boot(obj):
                 out_ = [None] * world
                 dist.all_gather_object(out_, obj)
@@ -540,7 +673,7 @@ def main():
     # WITHOUT its "parallel" feature and ark-ec WITH it (Cargo.toml:31-34): its NTTs are single-threaded, its MSM runs its
     # windows on the rayon pool.  `value` is that configuration; the all-threads OpenMP NTT of the oracle is reported beside it.
     cpu = None
-    if rank == 0 and world == 1 and not sim and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not multi and not sim and not args.no_cpu_baseline:
         from oracle import oracle as O
         cid = O.CURVE_IDS[args.curve]
         ls = min(args.cpu_sample_log_n, args.log_n)
@@ -585,9 +718,13 @@ def main():
             "data": "synthetic",
             "config": {"workload": f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof",
                        "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
-                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic)" if sim else "single GPU") if world == 1
-                                      else f"{world} ranks: 2-D NTT with RCCL all-to-all ({'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}), "
-                                           f"index-sharded MSM",
+                       "scheme": scheme,
+                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
+                                       ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}")) if world == 1
+                                      else (f"{world} ranks, scheme {scheme}: " +
+                                            ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
+                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each, dense inputs") +
+                                            f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
                        "coset_inputs": "n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else "dense 8n (plonk_ntt_dev / distributed 2-D transform)",
                        "rccl": rccl_info},
             "roofline": roofline_entry(dominant) if dominant else None,
@@ -595,6 +732,7 @@ def main():
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
                         for k, v in sorted(kernels.items())},
             "cpu_baseline": cpu,
+            "other_scheme": other_scheme,
             "verified": verified,
             "verification": verification,
             "next_rows": dict(next_rows or {}, class_prover=class_row) if class_row else next_rows,
@@ -605,6 +743,11 @@ def main():
     bases.free()
     if buf_p is not None:
         buf_p.free()
+    if cls is not None:
+        for k_ in ("poly", "out", "contrib", "recv", "mine", "quot"):
+            cls[k_].free()
+        for b in cls["bn"]:
+            b.free()
     for x in workers:
         x.close()
     if dist.is_initialized():
@@ -612,7 +755,7 @@ def main():
     if rank == 0:
         # ---- BASELINE.json's other single-GPU configurations, each as its own short run of this script AFTER the headline
         # measurement has released the GPU (never part of `value`): configs[1] and configs[3]
-        if world == 1 and not sim and not args.no_other_configs and args.log_n == 24 and args.curve == "bn254" and not args.dense_coset:
+        if world == 1 and not multi and not sim and not args.no_other_configs and args.log_n == 24 and args.curve == "bn254" and not args.dense_coset:
             import subprocess
             other = []
             for label, extra in (("configs[1]: 2^20-gate BN254, 1 GPU", ["--log-n", "20", "--curve", "bn254"]),

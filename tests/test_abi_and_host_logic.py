@@ -31,6 +31,28 @@ def test_library_exports_every_header_symbol():
     assert sorted(_ffi.SIGNATURES) == syms, "ctypes binding and header disagree"
 
 
+def _c_arity(text, name):
+    m = re.search(r"\b" + name + r"\s*\(([^;]*?)\)\s*;", text, flags=re.S)
+    args = m.group(1).strip()
+    return 0 if args in ("", "void") else args.count(",") + 1
+
+
+def test_rust_binding_declares_every_header_symbol_with_the_same_arity():
+    """ffi/plonk_hip.rs is source, not compiled here (no Rust toolchain): keep it in lock-step with the header mechanically —
+    every function of include/plonk_hip.h is declared in the `extern "C"` block with the same number of parameters, and the
+    ctypes binding has that arity too."""
+    htext = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "plonk_hip.h")).read(), flags=re.S)
+    rtext = re.sub(r"//[^\n]*", "", open(os.path.join(ROOT, "ffi", "plonk_hip.rs")).read())
+    for s in _header_symbols():
+        m = re.search(r"pub fn " + s + r"\s*\(([^;]*?)\)\s*(->\s*[^;]+)?;", rtext, flags=re.S)
+        assert m, f"{s} is not declared in ffi/plonk_hip.rs"
+        rargs = m.group(1).strip()
+        r_arity = 0 if not rargs else len([a for a in rargs.split(",") if a.strip()])
+        assert r_arity == _c_arity(htext, s), (s, r_arity, _c_arity(htext, s))
+        assert len(_ffi.SIGNATURES[s][1]) == r_arity, s
+    assert "PLONK_COMM_ID_BYTES: usize = 128" in rtext and "#[repr(C)]" in rtext
+
+
 def test_header_cites_reference_interfaces():
     text = open(os.path.join(ROOT, "include", "plonk_hip.h")).read()
     for cite in ["worker.rs:126-157", "worker.rs:159-185", "worker.rs:187-233", "worker.rs:235-278", "worker.rs:280-345",
@@ -104,5 +126,6 @@ def test_decimate_undecimate_are_the_reference_transposes():
 
 
 def test_bench_and_entry_contract_files_exist():
-    for f in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/plonk_hip.h", "oracle/plonk_oracle.c"]:
+    for f in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/plonk_hip.h", "oracle/plonk_oracle.c", "ffi/plonk_hip.rs",
+              "tools/preflight_multi.sh"]:
         assert os.path.exists(os.path.join(ROOT, f)), f
