@@ -132,6 +132,82 @@ FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
     return r;
 }
 
+// Sum of up to three products with ONE Montgomery reduction:  (a0*b0 + a1*b1 + a2*b2) / 2^261 mod p.
+// Every operand must be normalised (limbs 0..7 < 2^29, top limb < 2^29): a column then holds at most 27 products below 2^58 plus
+// the 9 reduction products — 36 * 2^58 < 2^63.2 fits the 64-bit accumulator.  Result normalised, value < sum(a_i*b_i)/2^261 + p.
+// Saves 81 + 9 mads per fused product: the quotient kernel's selector sums (dispatcher2.rs:459-477) are dot products.
+template <int T>
+FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
+    static_assert(T >= 1 && T <= 3, "at most three products fit one accumulator");
+    uint64_t acc = 0;
+    uint32_t m[9];
+    F29 r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) { acc += (uint64_t)a[t].l[i] * b[t].l[k - i]; F29_CHAIN(acc); }
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
+        m[k] = ((uint32_t)acc * P.inv) & F29_MASK;
+        acc += (uint64_t)m[k] * P.p[0];
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int t = 0; t < T; t++) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a[t].l[i] * b[t].l[k - i]; F29_CHAIN(acc); }
+        }
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
+        r.l[k - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+// Montgomery square x*x/2^261: the cross products x_i*x_j (i != j) are taken once against the doubled limb (45 + 81 mads).
+// x normalised (limbs < 2^29; the doubled top limb must stay below 2^31).  Result normalised, < x^2/2^261 + p.
+FP_HD F29 f29_sqr(const F29& x, const F29Params& P) {
+    uint64_t acc = 0;
+    uint32_t m[9], x2[9];
+    F29 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) x2[i] = x.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) { acc += (uint64_t)x.l[i] * x2[k - i]; F29_CHAIN(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)x.l[k / 2] * x.l[k / 2]; F29_CHAIN(acc); }
+#pragma unroll
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
+        m[k] = ((uint32_t)acc * P.inv) & F29_MASK;
+        acc += (uint64_t)m[k] * P.p[0];
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) { acc += (uint64_t)x.l[i] * x2[k - i]; F29_CHAIN(acc); }
+        if ((k & 1) == 0) { acc += (uint64_t)x.l[k / 2] * x.l[k / 2]; F29_CHAIN(acc); }
+#pragma unroll
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
+        r.l[k - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
+
 // normalised a < 2p  ->  a mod p (canonical), still normalised
 FP_HD F29 f29_canon(const F29& a, const F29Params& P) {
     F29 d;

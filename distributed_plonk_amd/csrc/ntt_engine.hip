@@ -323,20 +323,28 @@ static TwoLevelScale make_scale(const NttTables& T, const ScaleSpec& s, uint64_t
 static int g_ntt_ept = 4;      // elements per lane: 8 (radix-8 steps) or 4 (radix-4 steps, twice the waves per tile)
 void ntt_set_ept(int v) { g_ntt_ept = (v == 4 || v == 2) ? v : 8; }
 
-template <int LOG_R, int EPT>
+template <int LOG_R, int EPT, bool SWZ = false>
 static hipError_t launch_one_e(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT, SWZ>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
+    hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT, SWZ>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
     return hipGetLastError();
+}
+static bool swizzle_on() {
+    static const bool on = getenv("PLONK_NTT_NO_SWIZZLE") == nullptr;
+    return on;
 }
 template <int LOG_R>
 static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
+    // the bank swizzle (ntt_kernels.cuh: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
+    if constexpr (LOG_R >= 7) {
+        if (g_ntt_ept == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
+    }
     if (g_ntt_ept == 4) return launch_one_e<LOG_R, 4>(P, grid, threads, lds, stream);
     if (g_ntt_ept == 2) return launch_one_e<LOG_R, 2>(P, grid, threads, lds, stream);
     return launch_one_e<LOG_R, 8>(P, grid, threads, lds, stream);

@@ -147,9 +147,22 @@ struct LdsTile {
     }
 };
 
+// Row swizzle for 8-column tiles: word(l, row, t) sits in bank (row % 4) * 8 + t, so a wave whose 8 rows differ only ABOVE bit 1 —
+// the bit-reversed rows of the load phase, the stride-4 rows of the first step — hits 8 banks 8 lanes deep (PMC, round 1: 58 % of
+// the LDS-active cycles of the pass kernels were bank-conflict cycles).  XOR-folding all higher 2-bit groups of the row into its
+// low two bits spreads every access pattern of the kernel over all 32 banks (2 lanes per bank: the floor for 64 lanes).  The
+// map is an involution on rows and XOR-linear, so row a0 ^ (k << s0) costs one fold of a0 per step plus scalar constants.
+template <bool SWZ> __device__ __forceinline__ uint32_t sw_fold(uint32_t row) {
+    if (!SWZ) return 0;
+    uint32_t y = row >> 2;
+    y ^= y >> 4;
+    y ^= y >> 2;
+    return y & 3;
+}
+
 // K radix-2 decimation-in-time stages (s0 .. s0+K-1 of a size-2^LOG_R transform whose input sits in
 // bit-reversed order) on the EPT elements a lane holds.  Tile contents are normalised on entry and exit.
-template <int LOG_R, int K, int EPT, bool FIRST>
+template <int LOG_R, int K, int EPT, bool FIRST, bool SWZ>
 __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw_lds, int s0, uint32_t w, uint32_t t,
                                          uint32_t pitch, const F29Params& fp) {
     constexpr int R = 1 << LOG_R;
@@ -164,8 +177,9 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
         const uint32_t lo = G & (h - 1), hi = G >> s0;
         const uint32_t a0 = (hi << (s0 + K)) | lo;
         F29 v[RADIX];
+        const uint32_t fa = sw_fold<SWZ>(a0);
 #pragma unroll
-        for (int k = 0; k < RADIX; k++) v[k] = tile.get((a0 + k * h) * pitch + t);
+        for (int k = 0; k < RADIX; k++) v[k] = tile.get(((a0 + k * h) ^ fa ^ sw_fold<SWZ>(k * h)) * pitch + t);
 #pragma unroll
         for (int ds = 0; ds < K; ds++) {
             const int span = 1 << ds;
@@ -200,11 +214,11 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
             }
         }
 #pragma unroll
-        for (int k = 0; k < RADIX; k++) tile.put((a0 + k * h) * pitch + t, v[k]);
+        for (int k = 0; k < RADIX; k++) tile.put(((a0 + k * h) ^ fa ^ sw_fold<SWZ>(k * h)) * pitch + t, v[k]);
     }
 }
 
-template <int LOG_R, int EPT_REQ>
+template <int LOG_R, int EPT_REQ, bool SWZ = false>
 __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(const NttPassParams P) {
     constexpr int R = 1 << LOG_R;
     constexpr int EPT = (R >= EPT_REQ) ? EPT_REQ : R;
@@ -267,7 +281,8 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             const F29 s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
             v = f29_mul(v, s, P.fp);
         }
-        tile.put(brev(a, LOG_R) * pitch + t, v);
+        const uint32_t row = brev(a, LOG_R);
+        tile.put((row ^ sw_fold<SWZ>(row)) * pitch + t, v);
     }
     __syncthreads();
 
@@ -278,20 +293,20 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         constexpr int KREM = LOG_R % KMAX;
         constexpr int SFULL = LOG_R - KREM;          // stages covered by full groups
         if constexpr (R <= EPT) {
-            ntt_step<LOG_R, LOG_R, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            ntt_step<LOG_R, LOG_R, EPT, true, SWZ>(tile, tw_lds, 0, w, t, pitch, P.fp);
             __syncthreads();
         } else {
             if constexpr (SFULL > 0) {
-                ntt_step<LOG_R, KMAX, EPT, true>(tile, tw_lds, 0, w, t, pitch, P.fp);
+                ntt_step<LOG_R, KMAX, EPT, true, SWZ>(tile, tw_lds, 0, w, t, pitch, P.fp);
                 __syncthreads();
 #pragma unroll 1
                 for (int s = KMAX; s < SFULL; s += KMAX) {
-                    ntt_step<LOG_R, KMAX, EPT, false>(tile, tw_lds, s, w, t, pitch, P.fp);
+                    ntt_step<LOG_R, KMAX, EPT, false, SWZ>(tile, tw_lds, s, w, t, pitch, P.fp);
                     __syncthreads();
                 }
             }
             if constexpr (KREM != 0) {
-                ntt_step<LOG_R, KREM, EPT, SFULL == 0>(tile, tw_lds, SFULL, w, t, pitch, P.fp);
+                ntt_step<LOG_R, KREM, EPT, SFULL == 0, SWZ>(tile, tw_lds, SFULL, w, t, pitch, P.fp);
                 __syncthreads();
             }
         }
@@ -316,7 +331,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
     for (int i = 0; i < EPT; i++) {
         const uint32_t e = u + i * nthreads;
         const uint32_t t = e & (T - 1), idx = e >> P.log_t;
-        F29 v = tile.get(idx * pitch + t);
+        F29 v = tile.get((idx ^ sw_fold<SWZ>(idx)) * pitch + t);
         if (!P.is_last) {
             const uint64_t b = b0 + (uint64_t)t * P.tb;
             if (P.tw_plane != nullptr) {

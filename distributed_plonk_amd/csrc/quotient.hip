@@ -4,12 +4,14 @@
 //
 // What it replaces: the serial loop of /root/reference/src/dispatcher2.rs:435-504 (gate equation :459-477,
 // permutation argument :479-495, L1 term :497-503, 1/Z_H factor :372-379).  Streaming kernel: 26 loads + 2 table
-// loads and one store of 32 B per point, ~60 modular products (fp29.cuh lazy arithmetic).
+// loads and one store of 32 B per point; 52 limb products + 8 squarings but only 50 Montgomery reductions: the selector sums and
+// the final combination are three-term dot products with one reduction each (fp29.cuh: f29_dot<3>).
 //
 // Representation bookkeeping (mont(a, b) = a*b/2^261): inputs arrive in the reference's R = 2^256 Montgomery form.
 //   wires, z            R  --(* 2^266)-->  R' = 2^261 form        (products of R' values stay in R')
 //   selector * (R' value) -> R form ;  sigma * (beta*2^266) -> R' ;  (R' value) * (alpha*2^256) -> R form
 // so every term of the final sum is back in R form without a dedicated conversion.
+#include <cstdlib>
 #include <cstring>
 
 #include "constants.h"
@@ -35,9 +37,9 @@ struct QuotParams {
     F29 gamma_rp;          // gamma * 2^261
     F29 kbeta_rp[5];       // k_j * beta * 2^261
     F29 beta_fix;          // beta * 2^266     : sigma (R) -> sigma*beta (R')
-    F29 alpha_r;           // alpha * 2^256    : (R') -> R
     F29 a2n_r;             // alpha^2/n * 2^256
     F29 zh_inv_rp[8];      // 1/Z_H(x_i) * 2^261, i < m/n
+    F29 zh_alpha_r[8];     // alpha/Z_H(x_i) * 2^256
 };
 
 struct LazySum {           // sum of normalised values; limbs re-normalised every third addition
@@ -53,7 +55,7 @@ struct LazySum {           // sum of normalised values; limbs re-normalised ever
 
 __device__ __forceinline__ F29 ldq(const Fr* p, uint64_t i) { return f29_from_sat(load_fr(p + i)); }
 
-__global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P) {
+__device__ __forceinline__ void quotient_evals_body(const QuotParams& P) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // local index k
     if (i >= P.m_local) return;
     const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
@@ -66,26 +68,42 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
     const F29 zc = f29_mul(ldq(P.z, i), P.r2fix, fp);
     const F29 zn = f29_mul(ldq(P.z, (i + P.ratio / P.cls_stride) & (P.m_local - 1)), P.r2fix, fp);     // z(w x): point j + ratio, same class
 
-    // ---- gate equation (dispatcher2.rs:459-477)
-    const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+    // ---- gate equation (dispatcher2.rs:459-477).  The thirteen selector * monomial terms are a dot product: they are taken three at a
+    // time with ONE Montgomery reduction per triple (f29_dot<3>), and the fifth powers use the dedicated squaring.
+    // (ordered so that few monomials are alive at a time: the kernel runs at a 128-VGPR budget, four waves per SIMD)
     LazySum g;
     g.init(ldq(P.sel[11], i));                                   // q_c
     g.add(ldq(P.pi, i));                                         // + pub_input
-    g.add(f29_mul(ldq(P.sel[0], i), a, fp));                     // q_lc
-    g.add(f29_mul(ldq(P.sel[1], i), b, fp));
-    g.add(f29_mul(ldq(P.sel[2], i), c, fp));
-    g.add(f29_mul(ldq(P.sel[3], i), d, fp));
-    g.add(f29_mul(ldq(P.sel[4], i), ab, fp));                    // q_mul
-    g.add(f29_mul(ldq(P.sel[5], i), cd, fp));
-    g.add(f29_mul(ldq(P.sel[12], i), f29_mul(f29_mul(ab, cd, fp), e, fp), fp));      // q_ecc * ab * cd * e
-#pragma unroll
-    for (int j = 0; j < 4; j++) {                                // q_hash[j] * w^5
-        const F29 w2 = f29_mul(w5[j], w5[j], fp);
-        const F29 w4 = f29_mul(w2, w2, fp);
-        g.add(f29_mul(ldq(P.sel[6 + j], i), f29_mul(w4, w5[j], fp), fp));
+    {
+        const F29 s0[3] = {ldq(P.sel[0], i), ldq(P.sel[1], i), ldq(P.sel[2], i)}, m0[3] = {a, b, c};             // q_lc[0..2]
+        g.add(f29_dot<3>(s0, m0, fp));
     }
-    F29 gate = f29_sub2p(g.get(), f29_mul(ldq(P.sel[10], i), e, fp), fp);           // - q_o * e
-    f29_norm(gate);
+    __builtin_amdgcn_sched_barrier(0);
+    F29 abcde;
+    {
+        const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+        const F29 s1[3] = {ldq(P.sel[3], i), ldq(P.sel[4], i), ldq(P.sel[5], i)}, m1[3] = {d, ab, cd};           // q_lc[3], q_mul[0..1]
+        g.add(f29_dot<3>(s1, m1, fp));
+        abcde = f29_mul(f29_mul(ab, cd, fp), e, fp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const F29 h0 = f29_mul(f29_sqr(f29_sqr(a, fp), fp), a, fp), h1 = f29_mul(f29_sqr(f29_sqr(b, fp), fp), b, fp);   // w^5 (q_hash terms)
+        const F29 s2[3] = {ldq(P.sel[12], i), ldq(P.sel[6], i), ldq(P.sel[7], i)}, m2[3] = {abcde, h0, h1};      // q_ecc, q_hash[0..1]
+        g.add(f29_dot<3>(s2, m2, fp));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        const F29 h2 = f29_mul(f29_sqr(f29_sqr(c, fp), fp), c, fp), h3 = f29_mul(f29_sqr(f29_sqr(d, fp), fp), d, fp);
+        F29 neg_qo = ldq(P.sel[10], i);
+#pragma unroll
+        for (int l = 0; l < 9; l++) neg_qo.l[l] = fp.c2p[l] - neg_qo.l[l];          // 2p - q_o : the - q_o * e term joins the dot product
+        f29_norm(neg_qo);
+        const F29 s3[3] = {ldq(P.sel[8], i), ldq(P.sel[9], i), neg_qo}, m3[3] = {h2, h3, e};                     // q_hash[2..3], -q_o
+        g.add(f29_dot<3>(s3, m3, fp));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const F29 gate = g.get();                                    // normalised, < 7 p
 
     // ---- evaluation point x_i = g * w_m^i and the permutation argument (:479-495)
     const uint64_t E = j << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
@@ -100,25 +118,28 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel(const QuotParams P)
         acc2 = f29_mul(v, acc2, fp);
     }
     F29 diff = f29_sub2p(acc1, acc2, fp);
-    f29_norm(diff);
-    const F29 perm = f29_mul(diff, P.alpha_r, fp);                                   // alpha * (acc1 - acc2), R form
+    f29_norm(diff);                                                                  // acc1 - acc2, R' form, < 3.4 p
 
-    // ---- (z(x) - 1) * alpha^2 / (n (x - 1))  (:497-503)
+    // ---- 1/Z_H(x) * (gate + alpha * (acc1 - acc2)) + alpha^2/n * (z(x) - 1)/(x - 1)   (:497-503, :372-379) as ONE three-term dot
+    // product: the constants 1/Z_H (2^261 form: R -> R), alpha/Z_H and alpha^2/n (2^256 form: R' -> R) are per-launch, indexed by
+    // the point's coset of H_n
     F29 one_rp;
 #pragma unroll
     for (int l = 0; l < 9; l++) one_rp.l[l] = fp.one[l];
     F29 zm1 = f29_sub2p(zc, one_rp, fp);
     f29_norm(zm1);
-    const F29 l1 = f29_mul(f29_mul(zm1, ldq(P.inv_xm1, i), fp), P.a2n_r, fp);
-
-    // ---- z_h_inv * (gate + perm) + l1
-    F29 s = f29_add(gate, perm);
-    f29_norm(s);
-    F29 r = f29_add(f29_mul(s, P.zh_inv_rp[j & (P.ratio - 1)], fp), l1);
-    f29_norm(r);                                                                     // < 2.8 p
-    r = f29_canon(f29_canon(r, fp), fp);
+    const uint32_t ci = (uint32_t)(j & (P.ratio - 1));
+    const F29 da[3] = {gate, diff, f29_mul(zm1, ldq(P.inv_xm1, i), fp)}, db[3] = {P.zh_inv_rp[ci], P.zh_alpha_r[ci], P.a2n_r};
+    F29 r = f29_canon(f29_dot<3>(da, db, fp), fp);                                   // < 1.1 p before the conditional subtraction
     store_fr(P.out + i, f29_to_sat(r));
 }
+
+// The same body at three register budgets (waves per SIMD): the fused dot products keep six operands alive, and whether fewer
+// resident waves with no spills beat more waves with spills on this streaming kernel is a measurement;
+// PLONK_QUOT_WAVES selects, the default is the measured best.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel_w4(const QuotParams P) { quotient_evals_body(P); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) quotient_evals_kernel(const QuotParams P) { quotient_evals_body(P); }
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) quotient_evals_kernel_w2(const QuotParams P) { quotient_evals_body(P); }
 
 // 1/(x_i - 1) for all m points: Montgomery batch inversion over 16 consecutive points per lane, one Fermat
 // inversion per lane.  One-time per domain.
@@ -223,7 +244,6 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     Fr b32 = be;                                        // (32 beta) in Montgomery form -> constant form = beta * 2^266
     for (int i = 0; i < 5; i++) b32 = fp_add(b32, b32, P);
     q.beta_fix = host_const(b32, P);
-    q.alpha_r = f29_from_sat(al);                       // alpha * 2^256 as a plain residue
     Fr nm = fp_zero<8>();
     nm.l[0] = (uint32_t)n; nm.l[1] = (uint32_t)((uint64_t)n >> 32);
     nm = fp_to_mont(nm, P);
@@ -233,7 +253,9 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     Fr x = g_mont;
     for (uint32_t i = 0; i < q.ratio; i++) {
         const Fr zh = fp_sub(fp_pow_u64(x, (uint64_t)n, P), one, P);
-        q.zh_inv_rp[i] = host_const(fp_inv(zh, P), P);
+        const Fr zhi = fp_inv(zh, P);
+        q.zh_inv_rp[i] = host_const(zhi, P);
+        q.zh_alpha_r[i] = f29_from_sat(fp_mul(zhi, al, P));        // Montgomery form of alpha/Z_H = its 2^256 multiple as a plain residue
         x = fp_mul(x, wm, P);
     }
     for (int j = 0; j < 13; j++) q.sel[j] = (const Fr*)in->selectors[j];
@@ -243,7 +265,11 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        hipLaunchKernelGGL(quotient_evals_kernel, dim3((uint32_t)((m_local + 255) / 256)), dim3(256), 0, stream, q);
+        static const int waves = getenv("PLONK_QUOT_WAVES") ? atoi(getenv("PLONK_QUOT_WAVES")) : 3;
+        const dim3 grid((uint32_t)((m_local + 255) / 256));
+        if (waves == 4) hipLaunchKernelGGL(quotient_evals_kernel_w4, grid, dim3(256), 0, stream, q);
+        else if (waves == 2) hipLaunchKernelGGL(quotient_evals_kernel_w2, grid, dim3(256), 0, stream, q);
+        else hipLaunchKernelGGL(quotient_evals_kernel, grid, dim3(256), 0, stream, q);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "quotient_evals launch: %s", hipGetErrorString(e));
