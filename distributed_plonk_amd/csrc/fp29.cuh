@@ -137,7 +137,7 @@ FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
 // the 9 reduction products — 36 * 2^58 < 2^63.2 fits the 64-bit accumulator.  Result normalised, value < sum(a_i*b_i)/2^261 + p.
 // Saves 81 + 9 mads per fused product: the quotient kernel's selector sums (dispatcher2.rs:459-477) are dot products.
 template <int T>
-FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
+FP_HD F29 f29_dot_n(const F29& a0, const F29& b0, const F29& a1, const F29& b1, const F29& a2, const F29& b2, const F29Params& P) {
     static_assert(T >= 1 && T <= 3, "at most three products fit one accumulator");
     uint64_t acc = 0;
     uint32_t m[9];
@@ -145,9 +145,14 @@ FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)a0.l[i] * b0.l[k - i]; F29_CHAIN(acc); }
+        if (T > 1) {
 #pragma unroll
-            for (int i = 0; i <= k; i++) { acc += (uint64_t)a[t].l[i] * b[t].l[k - i]; F29_CHAIN(acc); }
+            for (int i = 0; i <= k; i++) { acc += (uint64_t)a1.l[i] * b1.l[k - i]; F29_CHAIN(acc); }
+        }
+        if (T > 2) {
+#pragma unroll
+            for (int i = 0; i <= k; i++) { acc += (uint64_t)a2.l[i] * b2.l[k - i]; F29_CHAIN(acc); }
         }
 #pragma unroll
         for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
@@ -159,9 +164,14 @@ FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
 #pragma unroll
     for (int k = 9; k < 17; k++) {
 #pragma unroll
-        for (int t = 0; t < T; t++) {
+        for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a0.l[i] * b0.l[k - i]; F29_CHAIN(acc); }
+        if (T > 1) {
 #pragma unroll
-            for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a[t].l[i] * b[t].l[k - i]; F29_CHAIN(acc); }
+            for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a1.l[i] * b1.l[k - i]; F29_CHAIN(acc); }
+        }
+        if (T > 2) {
+#pragma unroll
+            for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)a2.l[i] * b2.l[k - i]; F29_CHAIN(acc); }
         }
 #pragma unroll
         for (int i = k - 8; i <= 8; i++) { acc += (uint64_t)m[i] * P.p[k - i]; F29_CHAIN(acc); }
@@ -171,6 +181,14 @@ FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
     }
     r.l[8] = (uint32_t)acc;
     return r;
+}
+FP_HD F29 f29_dot2(const F29& a0, const F29& b0, const F29& a1, const F29& b1, const F29Params& P) { return f29_dot_n<2>(a0, b0, a1, b1, a1, b1, P); }
+FP_HD F29 f29_dot3(const F29& a0, const F29& b0, const F29& a1, const F29& b1, const F29& a2, const F29& b2, const F29Params& P) {
+    return f29_dot_n<3>(a0, b0, a1, b1, a2, b2, P);
+}
+template <int T>
+FP_HD F29 f29_dot(const F29* a, const F29* b, const F29Params& P) {
+    return f29_dot_n<T>(a[0], b[0], a[T > 1 ? 1 : 0], b[T > 1 ? 1 : 0], a[T > 2 ? 2 : 0], b[T > 2 ? 2 : 0], P);
 }
 
 // Montgomery square x*x/2^261: the cross products x_i*x_j (i != j) are taken once against the doubled limb (45 + 81 mads).

@@ -7,10 +7,16 @@
 // loads and one store of 32 B per point; 52 limb products + 8 squarings but only 50 Montgomery reductions: the selector sums and
 // the final combination are three-term dot products with one reduction each (fp29.cuh: f29_dot<3>).
 //
-// Representation bookkeeping (mont(a, b) = a*b/2^261): inputs arrive in the reference's R = 2^256 Montgomery form.
+// Representation bookkeeping (mont(a, b) = a*b/2^261; inputs arrive in the reference's R = 2^256 Montgomery form, the kernel's
+// radix is R' = 2^261).  Default kernel (quotient_evals_kernel): NOTHING is lifted.  A product of two R-form values comes out as
+// (ab)*R*2^-5, so a monomial of depth k carries 2^-5k: the gate's terms fall into three classes — q_lc*w and q_o*e (2^-5),
+// q_mul*w*w (2^-10), q_hash*w^5 and q_ecc*abcde (2^-25) — each summed lazily and brought back to R form by ONE product with
+// 2^(261+5k); the permutation products carry 2^-25 on both sides of the difference and the factor is folded into the alpha/Z_H
+// constant; every other constant is stored in whichever of the two forms makes its product land in R form.  56 products (8 of
+// them squarings) per point instead of 60 with lifted wires.
+// The fused variants (quotient_evals_kernel_f2/f3, option "quotient_fuse") work on lifted (R') wires:
 //   wires, z            R  --(* 2^266)-->  R' = 2^261 form        (products of R' values stay in R')
 //   selector * (R' value) -> R form ;  sigma * (beta*2^266) -> R' ;  (R' value) * (alpha*2^256) -> R form
-// so every term of the final sum is back in R form without a dedicated conversion.
 #include <cstdlib>
 #include <cstring>
 
@@ -40,6 +46,14 @@ struct QuotParams {
     F29 a2n_r;             // alpha^2/n * 2^256
     F29 zh_inv_rp[8];      // 1/Z_H(x_i) * 2^261, i < m/n
     F29 zh_alpha_r[8];     // alpha/Z_H(x_i) * 2^256
+    // unlifted kernel
+    F29 fix5, fix10, fix25;   // 2^(261+5), 2^(261+10), 2^(261+25): (value * R * 2^-5k) -> value * R
+    F29 gamma_r;              // gamma * 2^256
+    F29 kbeta_r[5];           // k_j * beta * 2^256    : x (2^261 form) -> k_j beta x in R form
+    F29 beta_c;               // beta * 2^261          : sigma (R) -> sigma beta (R)
+    F29 zh_alpha_25[8];       // alpha/Z_H(x_i) * 2^(261+25)
+    F29 a2n_c;                // alpha^2/n * 2^261
+    F29 one_r;                // 2^256
 };
 
 struct LazySum {           // sum of normalised values; limbs re-normalised every third addition
@@ -55,91 +69,202 @@ struct LazySum {           // sum of normalised values; limbs re-normalised ever
 
 __device__ __forceinline__ F29 ldq(const Fr* p, uint64_t i) { return f29_from_sat(load_fr(p + i)); }
 
+__device__ __forceinline__ void quotient_evals_unlifted(const QuotParams& P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // local index k
+    if (i >= P.m_local) return;
+    const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
+    const F29Params& fp = P.fp;
+    F29 w5[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) w5[q] = ldq(P.wire[q], i);                   // R form, canonical
+    const F29 &a = w5[0], &b = w5[1], &c = w5[2], &d = w5[3], &e = w5[4];
+
+    // ---- gate equation (dispatcher2.rs:459-477), three depth classes; each class is folded into the sum as soon as it is complete
+    // so that few partial values stay alive (the kernel runs four waves per SIMD: 128 VGPRs)
+    LazySum g;
+    g.init(ldq(P.sel[11], i));                                               // q_c
+    g.add(ldq(P.pi, i));                                                     // + pub_input
+    {
+        LazySum t1;                                                          // depth 1: * R * 2^-5
+        t1.init(f29_mul(ldq(P.sel[0], i), a, fp));
+        t1.add(f29_mul(ldq(P.sel[1], i), b, fp));
+        t1.add(f29_mul(ldq(P.sel[2], i), c, fp));
+        t1.add(f29_mul(ldq(P.sel[3], i), d, fp));
+        F29 s1 = f29_sub2p(t1.get(), f29_mul(ldq(P.sel[10], i), e, fp), fp); // - q_o * e
+        f29_norm(s1);
+        g.add(f29_mul(s1, P.fix5, fp));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    F29 abcde;
+    {
+        const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);            // * R * 2^-5
+        F29 s2 = f29_add(f29_mul(ldq(P.sel[4], i), ab, fp), f29_mul(ldq(P.sel[5], i), cd, fp));     // depth 2: * R * 2^-10
+        f29_norm(s2);
+        g.add(f29_mul(s2, P.fix10, fp));
+        abcde = f29_mul(f29_mul(ab, cd, fp), e, fp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+        LazySum t3;                                                          // depth 5: * R * 2^-25
+        t3.init(f29_mul(ldq(P.sel[12], i), abcde, fp));                      // q_ecc * ab * cd * e
+#pragma unroll
+        for (int q = 0; q < 4; q++) t3.add(f29_mul(ldq(P.sel[6 + q], i), f29_mul(f29_sqr(f29_sqr(w5[q], fp), fp), w5[q], fp), fp));   // q_hash * w^5
+        g.add(f29_mul(t3.get(), P.fix25, fp));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const F29 gate = g.get();                                                // R form, < 6.2 p
+
+    // ---- permutation argument (:479-495): both products carry 2^-25
+    const F29 zc = ldq(P.z, i);
+    const uint64_t E = j << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
+    const F29 x = f29_mul(load_f29(P.x_lo + (E & mask)), load_f29(P.x_hi + ((E >> P.lt) & mask)), fp);       // x * 2^261
+    F29 acc1 = zc, acc2 = ldq(P.z, (i + P.ratio / P.cls_stride) & (P.m_local - 1));     // z(x), z(w x): point j + ratio, same class
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+        const F29 t = f29_add(w5[q], P.gamma_r);                                         // limbs < 2^30
+        const F29 u = f29_add(t, f29_mul(x, P.kbeta_r[q], fp));                          // w + gamma + k_j x beta   (< 3.4 p)
+        const F29 v = f29_add(t, f29_mul(ldq(P.sig[q], i), P.beta_c, fp));               // w + gamma + sigma_j beta
+        acc1 = f29_mul(u, acc1, fp);
+        acc2 = f29_mul(v, acc2, fp);
+    }
+    F29 diff = f29_sub2p(acc1, acc2, fp);
+    f29_norm(diff);                                                                      // (acc1 - acc2) * R * 2^-25, < 3.4 p
+
+    // ---- 1/Z_H(x) * (gate + alpha * (acc1 - acc2)) + alpha^2/n * (z(x) - 1)/(x - 1)   (:497-503, :372-379)
+    F29 zm1 = f29_sub2p(zc, P.one_r, fp);
+    f29_norm(zm1);
+    const uint32_t ci = (uint32_t)(j & (P.ratio - 1));
+    LazySum r;
+    r.init(f29_mul(gate, P.zh_inv_rp[ci], fp));
+    r.add(f29_mul(diff, P.zh_alpha_25[ci], fp));
+    r.add(f29_mul(f29_mul(zm1, ldq(P.inv_xm1, i), fp), P.a2n_c, fp));
+    F29 out = r.get();                                                                   // < 4.1 p
+    out = f29_canon_lazy(out, fp);
+    store_fr(P.out + i, f29_to_sat(out));
+}
+
+// FUSE = 1: one Montgomery reduction per product (60 of them).  FUSE = 2 / 3: the twelve selector * monomial terms of the gate
+// equation and the final combination are taken two / three at a time with ONE reduction per group (f29_dot2 / f29_dot3): 54 / 50
+// reductions for the same 60 limb products, at the price of 4 / 6 operands alive per group.
+template <int FUSE>
 __device__ __forceinline__ void quotient_evals_body(const QuotParams& P) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // local index k
     if (i >= P.m_local) return;
     const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
     const F29Params& fp = P.fp;
-    // wires and z in R' form
+    // wires in R' form
     F29 w5[5];
 #pragma unroll
-    for (int j = 0; j < 5; j++) w5[j] = f29_mul(ldq(P.wire[j], i), P.r2fix, fp);
-    const F29 a = w5[0], b = w5[1], c = w5[2], d = w5[3], e = w5[4];
-    const F29 zc = f29_mul(ldq(P.z, i), P.r2fix, fp);
-    const F29 zn = f29_mul(ldq(P.z, (i + P.ratio / P.cls_stride) & (P.m_local - 1)), P.r2fix, fp);     // z(w x): point j + ratio, same class
+    for (int q = 0; q < 5; q++) w5[q] = f29_mul(ldq(P.wire[q], i), P.r2fix, fp);
+    const F29 &a = w5[0], &b = w5[1], &c = w5[2], &d = w5[3], &e = w5[4];
 
-    // ---- gate equation (dispatcher2.rs:459-477).  The thirteen selector * monomial terms are a dot product: they are taken three at a
-    // time with ONE Montgomery reduction per triple (f29_dot<3>), and the fifth powers use the dedicated squaring.
-    // (ordered so that few monomials are alive at a time: the kernel runs at a 128-VGPR budget, four waves per SIMD)
+    // ---- gate equation (dispatcher2.rs:459-477); ordered so that few monomials are alive at a time (128-VGPR budget)
     LazySum g;
     g.init(ldq(P.sel[11], i));                                   // q_c
     g.add(ldq(P.pi, i));                                         // + pub_input
-    {
-        const F29 s0[3] = {ldq(P.sel[0], i), ldq(P.sel[1], i), ldq(P.sel[2], i)}, m0[3] = {a, b, c};             // q_lc[0..2]
-        g.add(f29_dot<3>(s0, m0, fp));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    F29 abcde;
-    {
-        const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
-        const F29 s1[3] = {ldq(P.sel[3], i), ldq(P.sel[4], i), ldq(P.sel[5], i)}, m1[3] = {d, ab, cd};           // q_lc[3], q_mul[0..1]
-        g.add(f29_dot<3>(s1, m1, fp));
-        abcde = f29_mul(f29_mul(ab, cd, fp), e, fp);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const F29 h0 = f29_mul(f29_sqr(f29_sqr(a, fp), fp), a, fp), h1 = f29_mul(f29_sqr(f29_sqr(b, fp), fp), b, fp);   // w^5 (q_hash terms)
-        const F29 s2[3] = {ldq(P.sel[12], i), ldq(P.sel[6], i), ldq(P.sel[7], i)}, m2[3] = {abcde, h0, h1};      // q_ecc, q_hash[0..1]
-        g.add(f29_dot<3>(s2, m2, fp));
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const F29 h2 = f29_mul(f29_sqr(f29_sqr(c, fp), fp), c, fp), h3 = f29_mul(f29_sqr(f29_sqr(d, fp), fp), d, fp);
-        F29 neg_qo = ldq(P.sel[10], i);
+    F29 neg_qo = ldq(P.sel[10], i);
 #pragma unroll
-        for (int l = 0; l < 9; l++) neg_qo.l[l] = fp.c2p[l] - neg_qo.l[l];          // 2p - q_o : the - q_o * e term joins the dot product
-        f29_norm(neg_qo);
-        const F29 s3[3] = {ldq(P.sel[8], i), ldq(P.sel[9], i), neg_qo}, m3[3] = {h2, h3, e};                     // q_hash[2..3], -q_o
-        g.add(f29_dot<3>(s3, m3, fp));
+    for (int l = 0; l < 9; l++) neg_qo.l[l] = fp.c2p[l] - neg_qo.l[l];              // 2p - q_o : the - q_o * e term joins the sums
+    f29_norm(neg_qo);
+    if (FUSE == 3) {
+        g.add(f29_dot3(ldq(P.sel[0], i), a, ldq(P.sel[1], i), b, ldq(P.sel[2], i), c, fp));                      // q_lc[0..2]
+        __builtin_amdgcn_sched_barrier(0);
+        F29 abcde;
+        {
+            const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+            g.add(f29_dot3(ldq(P.sel[3], i), d, ldq(P.sel[4], i), ab, ldq(P.sel[5], i), cd, fp));                // q_lc[3], q_mul[0..1]
+            abcde = f29_mul(f29_mul(ab, cd, fp), e, fp);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const F29 h0 = f29_mul(f29_sqr(f29_sqr(a, fp), fp), a, fp), h1 = f29_mul(f29_sqr(f29_sqr(b, fp), fp), b, fp);   // w^5
+            g.add(f29_dot3(ldq(P.sel[12], i), abcde, ldq(P.sel[6], i), h0, ldq(P.sel[7], i), h1, fp));           // q_ecc, q_hash[0..1]
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const F29 h2 = f29_mul(f29_sqr(f29_sqr(c, fp), fp), c, fp), h3 = f29_mul(f29_sqr(f29_sqr(d, fp), fp), d, fp);
+            g.add(f29_dot3(ldq(P.sel[8], i), h2, ldq(P.sel[9], i), h3, neg_qo, e, fp));                          // q_hash[2..3], -q_o
+        }
+    } else if (FUSE == 2) {
+        g.add(f29_dot2(ldq(P.sel[0], i), a, ldq(P.sel[1], i), b, fp));
+        g.add(f29_dot2(ldq(P.sel[2], i), c, ldq(P.sel[3], i), d, fp));
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+            g.add(f29_dot2(ldq(P.sel[4], i), ab, ldq(P.sel[5], i), cd, fp));
+            const F29 abcde = f29_mul(f29_mul(ab, cd, fp), e, fp);
+            g.add(f29_dot2(ldq(P.sel[12], i), abcde, neg_qo, e, fp));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const F29 h0 = f29_mul(f29_sqr(f29_sqr(a, fp), fp), a, fp), h1 = f29_mul(f29_sqr(f29_sqr(b, fp), fp), b, fp);
+            g.add(f29_dot2(ldq(P.sel[6], i), h0, ldq(P.sel[7], i), h1, fp));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const F29 h2 = f29_mul(f29_sqr(f29_sqr(c, fp), fp), c, fp), h3 = f29_mul(f29_sqr(f29_sqr(d, fp), fp), d, fp);
+            g.add(f29_dot2(ldq(P.sel[8], i), h2, ldq(P.sel[9], i), h3, fp));
+        }
+    } else {
+        const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);
+        g.add(f29_mul(ldq(P.sel[0], i), a, fp));
+        g.add(f29_mul(ldq(P.sel[1], i), b, fp));
+        g.add(f29_mul(ldq(P.sel[2], i), c, fp));
+        g.add(f29_mul(ldq(P.sel[3], i), d, fp));
+        g.add(f29_mul(ldq(P.sel[4], i), ab, fp));
+        g.add(f29_mul(ldq(P.sel[5], i), cd, fp));
+        g.add(f29_mul(ldq(P.sel[12], i), f29_mul(f29_mul(ab, cd, fp), e, fp), fp));
+#pragma unroll
+        for (int q = 0; q < 4; q++) g.add(f29_mul(ldq(P.sel[6 + q], i), f29_mul(f29_sqr(f29_sqr(w5[q], fp), fp), w5[q], fp), fp));
+        g.add(f29_mul(neg_qo, e, fp));
     }
     __builtin_amdgcn_sched_barrier(0);
-    const F29 gate = g.get();                                    // normalised, < 7 p
+    const F29 gate = g.get();                                    // normalised, < 8 p
 
     // ---- evaluation point x_i = g * w_m^i and the permutation argument (:479-495)
+    const F29 zc = f29_mul(ldq(P.z, i), P.r2fix, fp);
+    const F29 zn = f29_mul(ldq(P.z, (i + P.ratio / P.cls_stride) & (P.m_local - 1)), P.r2fix, fp);     // z(w x): point j + ratio, same class
     const uint64_t E = j << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
     const F29 x = f29_mul(load_f29(P.x_lo + (E & mask)), load_f29(P.x_hi + ((E >> P.lt) & mask)), fp);
     F29 acc1 = zc, acc2 = zn;
 #pragma unroll
-    for (int j = 0; j < 5; j++) {
-        const F29 t = f29_add(w5[j], P.gamma_rp);                                    // limbs < 2^30
-        const F29 u = f29_add(t, f29_mul(x, P.kbeta_rp[j], fp));                     // w + gamma + k_j x beta
-        const F29 v = f29_add(t, f29_mul(ldq(P.sig[j], i), P.beta_fix, fp));         // w + gamma + sigma_j beta
+    for (int q = 0; q < 5; q++) {
+        const F29 t = f29_add(w5[q], P.gamma_rp);                                    // limbs < 2^30
+        const F29 u = f29_add(t, f29_mul(x, P.kbeta_rp[q], fp));                     // w + gamma + k_j x beta
+        const F29 v = f29_add(t, f29_mul(ldq(P.sig[q], i), P.beta_fix, fp));         // w + gamma + sigma_j beta
         acc1 = f29_mul(u, acc1, fp);
         acc2 = f29_mul(v, acc2, fp);
     }
     F29 diff = f29_sub2p(acc1, acc2, fp);
     f29_norm(diff);                                                                  // acc1 - acc2, R' form, < 3.4 p
 
-    // ---- 1/Z_H(x) * (gate + alpha * (acc1 - acc2)) + alpha^2/n * (z(x) - 1)/(x - 1)   (:497-503, :372-379) as ONE three-term dot
-    // product: the constants 1/Z_H (2^261 form: R -> R), alpha/Z_H and alpha^2/n (2^256 form: R' -> R) are per-launch, indexed by
-    // the point's coset of H_n
+    // ---- 1/Z_H(x) * (gate + alpha * (acc1 - acc2)) + alpha^2/n * (z(x) - 1)/(x - 1)   (:497-503, :372-379).  The constants 1/Z_H
+    // (2^261 form: R -> R), alpha/Z_H and alpha^2/n (2^256 form: R' -> R) are per-launch, indexed by the point's coset of H_n.
     F29 one_rp;
 #pragma unroll
     for (int l = 0; l < 9; l++) one_rp.l[l] = fp.one[l];
     F29 zm1 = f29_sub2p(zc, one_rp, fp);
     f29_norm(zm1);
     const uint32_t ci = (uint32_t)(j & (P.ratio - 1));
-    const F29 da[3] = {gate, diff, f29_mul(zm1, ldq(P.inv_xm1, i), fp)}, db[3] = {P.zh_inv_rp[ci], P.zh_alpha_r[ci], P.a2n_r};
-    F29 r = f29_canon(f29_dot<3>(da, db, fp), fp);                                   // < 1.1 p before the conditional subtraction
+    const F29 l1 = f29_mul(zm1, ldq(P.inv_xm1, i), fp);
+    F29 r;
+    if (FUSE == 3) {
+        r = f29_dot3(gate, P.zh_inv_rp[ci], diff, P.zh_alpha_r[ci], l1, P.a2n_r, fp);          // < 1.2 p
+    } else {
+        r = f29_add(f29_dot2(gate, P.zh_inv_rp[ci], diff, P.zh_alpha_r[ci], fp), f29_mul(l1, P.a2n_r, fp));
+        f29_norm(r);                                                                           // < 2.5 p
+        r = f29_canon(r, fp);
+    }
+    r = f29_canon(r, fp);
     store_fr(P.out + i, f29_to_sat(r));
 }
 
-// The same body at three register budgets (waves per SIMD): the fused dot products keep six operands alive, and whether fewer
-// resident waves with no spills beat more waves with spills on this streaming kernel is a measurement;
-// PLONK_QUOT_WAVES selects, the default is the measured best.
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel_w4(const QuotParams P) { quotient_evals_body(P); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) quotient_evals_kernel(const QuotParams P) { quotient_evals_body(P); }
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) quotient_evals_kernel_w2(const QuotParams P) { quotient_evals_body(P); }
+// Variants: how many products share a reduction.  PLONK_QUOT_FUSE selects; the default is the measured best.
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel(const QuotParams P) { quotient_evals_unlifted(P); }
+__global__ void __launch_bounds__(256) quotient_evals_kernel_u3(const QuotParams P) { quotient_evals_unlifted(P); }      // uncapped registers: 3 waves
+__global__ void __launch_bounds__(256) quotient_evals_kernel_f1(const QuotParams P) { quotient_evals_body<1>(P); }
+__global__ void __launch_bounds__(256) quotient_evals_kernel_f2(const QuotParams P) { quotient_evals_body<2>(P); }
+__global__ void __launch_bounds__(256) quotient_evals_kernel_f3(const QuotParams P) { quotient_evals_body<3>(P); }
 
 // 1/(x_i - 1) for all m points: Montgomery batch inversion over 16 consecutive points per lane, one Fermat
 // inversion per lane.  One-time per domain.
@@ -178,6 +303,8 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------- host
+static int g_quotient_fuse = 0;       // 0: the unlifted kernel (default); 1, 2, 3: lifted wires with 1 / 2 / 3 products per reduction (experiments)
+void quotient_set_fuse(int v) { g_quotient_fuse = (v >= 0 && v <= 4) ? v : 0; }
 static F29 host_const(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }
 
 int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
@@ -258,6 +385,28 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
         q.zh_alpha_r[i] = f29_from_sat(fp_mul(zhi, al, P));        // Montgomery form of alpha/Z_H = its 2^256 multiple as a plain residue
         x = fp_mul(x, wm, P);
     }
+    // constants of the unlifted kernel
+    auto pow2_const = [&](int k) {                      // 2^(261+k) mod p as normalised canonical limbs
+        Fr t = one;                                     // Montgomery one = 2^256 as a plain residue
+        for (int i = 0; i < 5 + k; i++) t = fp_add(t, t, P);
+        return f29_from_sat(t);
+    };
+    q.fix5 = pow2_const(5); q.fix10 = pow2_const(10); q.fix25 = pow2_const(25);
+    q.gamma_r = f29_from_sat(ga);
+    for (int j = 0; j < 5; j++) q.kbeta_r[j] = f29_from_sat(fp_mul(fp_from_limbs<8>((const uint32_t*)k + 8 * j), be, P));
+    q.beta_c = host_const(be, P);
+    q.a2n_c = host_const(fp_mul(fp_sqr(al, P), fp_inv(nm, P), P), P);
+    q.one_r = f29_from_sat(one);
+    {
+        Fr x2 = g_mont;
+        for (uint32_t i = 0; i < q.ratio; i++) {
+            const Fr zh = fp_sub(fp_pow_u64(x2, (uint64_t)n, P), one, P);
+            Fr za = fp_mul(fp_inv(zh, P), al, P);       // Montgomery form of alpha/Z_H
+            for (int t = 0; t < 25; t++) za = fp_add(za, za, P);
+            q.zh_alpha_25[i] = host_const(za, P);       // (alpha/Z_H * 2^25) * 2^261
+            x2 = fp_mul(x2, wm, P);
+        }
+    }
     for (int j = 0; j < 13; j++) q.sel[j] = (const Fr*)in->selectors[j];
     for (int j = 0; j < 5; j++) { q.sig[j] = (const Fr*)in->sigmas[j]; q.wire[j] = (const Fr*)in->wires[j]; }
     q.z = (const Fr*)in->perm;
@@ -265,10 +414,12 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        static const int waves = getenv("PLONK_QUOT_WAVES") ? atoi(getenv("PLONK_QUOT_WAVES")) : 3;
+        const int fuse = g_quotient_fuse;
         const dim3 grid((uint32_t)((m_local + 255) / 256));
-        if (waves == 4) hipLaunchKernelGGL(quotient_evals_kernel_w4, grid, dim3(256), 0, stream, q);
-        else if (waves == 2) hipLaunchKernelGGL(quotient_evals_kernel_w2, grid, dim3(256), 0, stream, q);
+        if (fuse == 1) hipLaunchKernelGGL(quotient_evals_kernel_f1, grid, dim3(256), 0, stream, q);
+        else if (fuse == 2) hipLaunchKernelGGL(quotient_evals_kernel_f2, grid, dim3(256), 0, stream, q);
+        else if (fuse == 3) hipLaunchKernelGGL(quotient_evals_kernel_f3, grid, dim3(256), 0, stream, q);
+        else if (fuse == 4) hipLaunchKernelGGL(quotient_evals_kernel_u3, grid, dim3(256), 0, stream, q);
         else hipLaunchKernelGGL(quotient_evals_kernel, grid, dim3(256), 0, stream, q);
     }
     hipError_t e = hipGetLastError();

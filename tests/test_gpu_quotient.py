@@ -51,3 +51,34 @@ def test_quotient_evals_structured_inputs(gpu_workers, oracle):
         want = oracle.quotient_evals(0, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8])
         assert np.array_equal(out.download((m, 4)), want)
     buf.free(); out.free()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+def test_quotient_kernel_variants_agree_with_oracle(gpu_workers, oracle, curve, cid, variant):
+    """The experimental formulations kept behind the `quotient_fuse` option (lifted wires with 1 / 2 / 3 products per Montgomery
+    reduction, and the unlifted kernel at an uncapped register budget) compute the same values as the default kernel, bit for bit,
+    on random and on extreme inputs (all p-1: the largest lazy sums the bound bookkeeping allows)."""
+    w = gpu_workers(curve)
+    log_n = 7
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    vecs = oracle.rand_fr(cid, 5000, 25 * m).reshape(25, m, 4)
+    pm1 = oracle.field_const(cid, 0, 0) - np.array([1, 0, 0, 0], dtype=np.uint64)
+    vecs[:, : m // 4] = pm1
+    vecs[:, m // 4: m // 2: 2] = 0
+    ch = oracle.rand_fr(cid, 79, 8)
+    ch[0] = pm1                                              # alpha = p - 1 as well
+    buf = w.alloc(25 * m * 32).upload(vecs)
+    out = w.alloc(m * 32)
+    ptr = [buf.ptr + j * m * 32 for j in range(25)]
+    want = oracle.quotient_evals(cid, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8], threads=8)
+    try:
+        for v in (0, variant):
+            w.set_option("quotient_fuse", v)
+            w.memset_dev(out.ptr, 0, m * 32)
+            w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
+            assert np.array_equal(out.download((m, 4)), want), v
+    finally:
+        w.set_option("quotient_fuse", 0)
+    buf.free(); out.free()

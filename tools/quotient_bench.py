@@ -14,12 +14,17 @@ for log_n in [int(a) for a in sys.argv[1:]]:
     ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 5
     ptr = [b.ptr for b in bufs]
     w.profile_enable(True)
-    for it in range(3):
-        w.profile_reset()
-        w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
-        w.sync()
-    ms, cnt = w.profile_get("quotient_evals_kernel")
     alg = 27 * 32 * m          # 26 input reads (z twice) + 1 write of 32 B per point
-    print(log_n, "quotient ms", round(ms, 3), "algorithmic GB/s", round(alg / ms / 1e6, 1), "frac of 8 TB/s", round(alg / ms / 1e6 / 8000, 4), flush=True)
+    names = {0: "unlifted, 4 waves (default)", 4: "unlifted, uncapped registers (3 waves)", 1: "lifted wires, 1 product / reduction",
+             2: "lifted, 2 products / reduction", 3: "lifted, 3 products / reduction"}
+    for variant in (0, 4, 1, 2, 3):
+        w.set_option("quotient_fuse", variant)
+        for it in range(3):
+            w.profile_reset()
+            w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
+            w.sync()
+        ms, cnt = w.profile_get("quotient_evals_kernel")
+        print(f"2^{log_n} quotient_fuse={variant} ({names[variant]}): {ms:.3f} ms, algorithmic {alg / ms / 1e6:.1f} GB/s = {alg / ms / 1e6 / 8000:.4f} of 8 TB/s", flush=True)
+    w.set_option("quotient_fuse", 0)
     for b in bufs + [out]:
         b.free()
