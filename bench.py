@@ -619,7 +619,7 @@ def main():
     # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
     class_row = None
     if (args.class_prover or multi) and not args.no_class_prover and not sim:
-        from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm
+        from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
         if world == 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29653")
@@ -627,9 +627,10 @@ def main():
         n_ck = ((n + 3 + 31) >> 5) << 5
         ck = w.alloc(n_ck * 16 * q64)
         w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
-        w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # same key on every rank
-        for x in workers:
-            x.init_dev(ck.ptr, n_ck, n, m)
+        w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # the same key generated on every rank ...
+        klo, khi = key_shard_range(n_ck, rank, world)                                         # ... of which a rank KEEPS only its slice
+        for x in workers:                                                                     # (the SRS sharding of dispatcher2.rs:260-266)
+            x.init_dev(ck.ptr + klo * 16 * q64, khi - klo, n, m)
         key = w.alloc(18 * n * 32)
         circ = w.alloc(11 * n * 32)
         w.synth_fr(0xC1AC, key.ptr, 18 * n)
@@ -647,7 +648,7 @@ def main():
             comm = LibComm(w, bootstrap=_boot)
         else:
             comm = TorchComm(w, dev)
-        cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1])
+        cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
         cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
         t_cls = None
         for it in range(2):

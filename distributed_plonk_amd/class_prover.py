@@ -156,13 +156,23 @@ def shard_range(length: int, rank: int, size: int):
     return rank * length // size, (rank + 1) * length // size
 
 
+def key_shard_range(key_len: int, rank: int, size: int):
+    """The slice of the commit key rank `rank` keeps resident: [rank*K/S, (rank+1)*K/S) of the K (padded) bases — the SRS sharding
+    of dispatcher2.rs:260-266.  Every polynomial is committed against bases [0, len), so a rank's share of ANY polynomial is the
+    coefficients whose index falls inside its key slice."""
+    return rank * key_len // size, (rank + 1) * key_len // size
+
+
 class ClassProver(Prover):
     """Rank `comm.rank` of `comm.size` (a power of two <= 8).  Same calls, same results as `Prover`; every rank must make them.
-    `worker.init(ck, n, 8n)` with the WHOLE commit key on every rank (72 B per point resident: replicated, not sharded, because
-    a coefficient shard of the split quotient polynomials needs bases from anywhere in the key)."""
+    key_range = None: `worker.init(ck, n, 8n)` was given the WHOLE commit key (replicated), each polynomial's coefficients are split
+    evenly.  key_range = (lo, hi): the worker (and the commit_helper) hold only bases [lo, hi) — `key_shard_range(len(ck), rank, G)` —
+    and this rank commits, for every polynomial, the coefficients with index in [lo, hi): the key is sharded G ways like the
+    reference's (dispatcher2.rs:260-266), 72 / 112 B per point resident."""
 
-    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None):
+    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None):
         super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper)
+        self.key_range = None if key_range is None else (int(key_range[0]), int(key_range[1]))
         G = comm.size
         if G & (G - 1) or G > self.m // self.n:
             raise ValueError(f"{G} ranks: coset classes need a power of two <= m/n = {self.m // self.n}")
@@ -182,8 +192,13 @@ class ClassProver(Prover):
         is set), then one collective for all partial points and the host reduce(a + b) per commitment."""
         shards = []
         for ptr, ln in items:
-            lo, hi = shard_range(ln, self.s, self.G)
-            shards.append((ptr + lo * 32, lo, hi - lo))
+            if self.key_range is None:
+                lo, hi = shard_range(ln, self.s, self.G)
+                shards.append((ptr + lo * 32, lo, hi - lo))
+            else:                                                # sharded key: coefficient i pairs with LOCAL base i - key_lo
+                klo, khi = self.key_range
+                lo, hi = min(klo, ln), min(khi, ln)
+                shards.append((ptr + lo * 32, lo - klo, hi - lo))
         parts = [None] * len(shards)
         lanes = [self.w] + ([self.commit_helper] if self.commit_helper is not None and len(shards) > 1 else [])
         if len(lanes) == 1:

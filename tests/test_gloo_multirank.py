@@ -179,7 +179,7 @@ def test_two_rank_coset_class_exchange(log_m, cid):
 
 
 # --------------------------------------------------------------------------------------------- the whole class prover, SPMD over gloo
-def _prover_rank_main(rank, world, port, log_n, cid, result_q):
+def _prover_rank_main(rank, world, port, log_n, cid, result_q, shard_key=False):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -187,7 +187,7 @@ def _prover_rank_main(rank, world, port, log_n, cid, result_q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from cpu_worker import CpuWorker
-        from distributed_plonk_amd.class_prover import ClassProver, TorchComm
+        from distributed_plonk_amd.class_prover import ClassProver, TorchComm, key_shard_range
         from oracle import oracle as O
         from oracle import prover_ref as P
         curve = {0: "bn254", 1: "bls12_381"}[cid]
@@ -195,13 +195,15 @@ def _prover_rank_main(rank, world, port, log_n, cid, result_q):
         circ = P.make_circuit(cid, log_n, seed=77)                      # identical on every rank
         ck, inf = P.make_ck(cid, n, seed=78, unique=8)
         bl = dict(wires=O.rand_fr(cid, 1, 10).reshape(5, 2, 4), perm=O.rand_fr(cid, 2, 3))
+        key_range = key_shard_range(len(ck), rank, world) if shard_key else None      # SRS sharded like dispatcher2.rs:260-266
+        my_ck = ck[key_range[0]:key_range[1]] if shard_key else ck
         w = CpuWorker(curve, me=rank)
-        w.init(ck, n, 8 * n)
+        w.init(my_ck, n, 8 * n)
         helper = None
         if rank % 2 == 0:                                               # half of the ranks use two commitment lanes
             helper = CpuWorker(curve, me=rank, share=w)
-            helper.init(ck, n, 8 * n)
-        pv = ClassProver(w, log_n, TorchComm(w, device=None), commit_helper=helper)
+            helper.init(my_ck, n, 8 * n)
+        pv = ClassProver(w, log_n, TorchComm(w, device=None), commit_helper=helper, key_range=key_range)
         pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
         fs = pv.fiat_shamir(circ["pub_input"][:2])                      # every rank runs its own transcript
         got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, fs, keep=True)
@@ -218,15 +220,15 @@ def _prover_rank_main(rank, world, port, log_n, cid, result_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,cid", [(2, 4, 0), (4, 5, 1)])
-def test_class_prover_spmd_over_gloo(world, log_n, cid):
+@pytest.mark.parametrize("world,log_n,cid,shard_key", [(2, 4, 0, False), (4, 5, 1, True), (2, 5, 0, True)])
+def test_class_prover_spmd_over_gloo(world, log_n, cid, shard_key):
     """distributed_plonk_amd.class_prover.ClassProver end to end as `world` processes over gloo: the product's SPMD orchestration
     and torch.distributed calls run for real (host-staged tensors); each rank's device work is done by the oracle through the
     test-only stand-in tests/cpu_worker.py.  Every rank must produce the oracle prover's proof and draw the same challenges."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_prover_rank_main, args=(rk, world, port, log_n, cid, q)) for rk in range(world)]
+    procs = [ctx.Process(target=_prover_rank_main, args=(rk, world, port, log_n, cid, q, shard_key)) for rk in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in procs]

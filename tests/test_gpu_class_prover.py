@@ -4,7 +4,7 @@ transport makes.  Every rank must end up with the proof the oracle's restatement
 import numpy as np
 import pytest
 
-from distributed_plonk_amd.class_prover import ClassProver, TorchComm, run_local_ranks, shard_range
+from distributed_plonk_amd.class_prover import ClassProver, TorchComm, key_shard_range, run_local_ranks, shard_range
 
 pytestmark = pytest.mark.gpu
 
@@ -60,6 +60,36 @@ def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
     for got, timings in results:
         _check(got, want)
         assert "round3_exchange" in timings
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,G", [(5, 2), (8, 4), (9, 8)])
+def test_class_prover_sharded_commit_key(oracle, curve, cid, log_n, G):
+    """The SRS sharded G ways like the reference's (dispatcher2.rs:260-266): rank s holds only bases [s*K/G, (s+1)*K/G) and commits
+    the coefficients of every polynomial whose index falls in that slice — incl. polynomials shorter than the key (n, n + 2, n + 3
+    coefficients against a key padded to a multiple of 32) and the five split-quotient polynomials.  Same proof as the oracle's."""
+    P, circ, ck, inf, bl, ch = _instance(oracle, cid, log_n, 900 + log_n)
+    n = 1 << log_n
+    K = len(ck)
+
+    def rank_main(comm, w):
+        klo, khi = key_shard_range(K, comm.rank, comm.size)
+        w.init(ck[klo:khi], n, 8 * n)                      # this rank's slice only
+        pv = ClassProver(w, log_n, comm, key_range=(klo, khi))
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            fs = pv.fiat_shamir(circ["pub_input"][:2])      # verifying-key commitments through the sharded key too
+            return pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True), fs.drawn
+        finally:
+            pv.close()
+
+    results = run_local_ranks(G, rank_main, curve=curve)
+    want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=8)
+    for got, _ in results:
+        _check(got, want)
+    for _, drawn in results[1:]:
+        for k in results[0][1]:
+            assert np.array_equal(drawn[k], results[0][1][k])
 
 
 def test_class_prover_with_transcript_and_bad_witness(oracle):
