@@ -111,6 +111,15 @@ static int get_scaled_lo(NttTables& T, int log_m, F29** out, hipStream_t stream)
     return PLONK_OK;
 }
 
+// A transform that cannot get its factor plane still runs (two table gathers + an extra product per element: ~15 % slower); the
+// switch is a performance cliff, so it is announced once per process instead of happening silently.
+static void plane_fallback_notice(const char* why, size_t bytes) {
+    static bool said = false;
+    if (said) return;
+    said = true;
+    fprintf(stderr, "[plonk_hip] notice: no NTT factor plane of %zu MiB (%s): inter-pass twiddles are formed on the fly (slower)\n", bytes >> 20, why);
+}
+
 // Inter-pass factor plane (ntt_gen_plane_kernel) for pass `p` of a size-2^log_m transform, cached per
 // (log_m, r_prev, r_p, direction, inverse-scale folded, coset folded).  Returns nullptr (no error) when the plane
 // budget is exhausted — the pass then forms its factors on the fly.
@@ -123,14 +132,14 @@ static int get_plane(NttTables& T, int log_m, int log_rprev, int log_rp, int dir
     if (it != T.planes.end()) { *out = it->second; return PLONK_OK; }
     const uint64_t r_prev = (uint64_t)1 << log_rprev;
     const size_t bytes = r_prev * sizeof(Fr);
-    if (T.plane_bytes + bytes > T.plane_budget) return PLONK_OK;
+    if (T.plane_bytes + bytes > T.plane_budget) { plane_fallback_notice("the plane budget is exhausted", bytes); return PLONK_OK; }
     F29* lo = T.tw_lo[dir];
     if (fold_scale) {
         int rc = get_scaled_lo(T, log_m, &lo, stream);
         if (rc) return rc;
     }
     Fr* d = nullptr;
-    if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipGetLastError(); return PLONK_OK; }     // out of memory: just no plane
+    if (hipMalloc((void**)&d, bytes) != hipSuccess) { (void)hipGetLastError(); plane_fallback_notice("hipMalloc failed", bytes); return PLONK_OK; }
     hipLaunchKernelGGL(ntt_gen_plane_kernel, dim3((uint32_t)((r_prev + 255) / 256)), dim3(256), 0, stream, d, r_prev, (uint64_t)1 << log_rp, lo,
                        T.tw_hi[dir], (uint32_t)T.lt, (uint32_t)(T.two_adicity - log_rprev), fold_coset ? T.g_lo[0] : (const F29*)nullptr,
                        fold_coset ? T.g_hi[0] : (const F29*)nullptr, (uint64_t)1 << log_coset_mult, T.fp29);
