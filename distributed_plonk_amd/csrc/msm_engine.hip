@@ -68,14 +68,24 @@ __device__ __forceinline__ uint32_t scalar_raw_digit(const uint32_t* s, int bit0
 }
 
 // ---- 1: digits, planar: dig[w*n + i] = magnitude | sign << 31   (magnitude 0 = no contribution)
+// scalars_mont != 0: the scalars are Fr in Montgomery form and `into_repr` (commit_polynomial, worker.rs:117-123) is taken here,
+// on the fly, instead of in a separate pass that wrote 32 B per scalar to HBM and read them back.
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
-                                                         uint32_t* __restrict__ dig) {
+                                                         uint32_t* __restrict__ dig, int scalars_mont, const FpParams<8> FR) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t s[8];
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + 8 * i);
     const uint4 lo = sp[0], hi = sp[1];
     s[0] = lo.x; s[1] = lo.y; s[2] = lo.z; s[3] = lo.w; s[4] = hi.x; s[5] = hi.y; s[6] = hi.z; s[7] = hi.w;
+    if (scalars_mont) {
+        Fp<8> v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = s[k];
+        v = fp_from_mont(v, FR);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[k] = v.l[k];
+    }
     const uint32_t half = 1u << (c - 1);
     uint32_t carry = 0;
     for (int w = 0; w < W; w++) {
@@ -790,7 +800,7 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 template <int NQ>
-static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
+static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
                      int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
@@ -877,7 +887,8 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
 
     const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
     { ProfScope ps("msm_digits_kernel", stream);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, dig); }
+    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, dig, scalars_mont ? 1 : 0,
+                       fr_params(curve)); }
     { ProfScope ps("msm_sort", stream);
     hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_hist);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums);
@@ -968,7 +979,7 @@ static int g_msm_slice_log = 26;
 void msm_set_slice_log(int v) { g_msm_slice_log = v < 8 ? 8 : (v > 26 ? 26 : v); }
 
 template <int NQ>
-static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
+static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
                      const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     XyzzPt<NQ> total = xyzz_inf<NQ>();
@@ -976,7 +987,7 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, 
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
         XyzzPt<NQ> part;
-        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, m, &part, ws, window_bits, tab, stream);
+        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, scalars_mont, m, &part, ws, window_bits, tab, stream);
         if (rc) return rc;
         total = xyzz_add(total, part, P);
     }
@@ -985,10 +996,10 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, 
     return PLONK_OK;
 }
 
-int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
+int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
             const MsmTable& tab, hipStream_t stream) {
-    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, tab, stream);
-    return msm_run_t<12>(curve, d_bases, d_scalars, n, h_out_jac, ws, window_bits, tab, stream);
+    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
+    return msm_run_t<12>(curve, d_bases, d_scalars, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
 }
 
 template <int NQ> static void jac_add_host_t(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out) {

@@ -297,14 +297,14 @@ extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_b
 }
 
 // ---------------------------------------------------------------------------------------------- varMsm @1
-static int msm_device(plonk_ctx* ctx, size_t start, size_t n, const uint32_t* d_scalars, uint64_t* out_jac) {
+static int msm_device(plonk_ctx* ctx, size_t start, size_t n, const uint32_t* d_scalars, uint64_t* out_jac, bool scalars_mont = false) {
     if (n == 0) {       // empty MSM = zero (1,1,0)
         uint64_t a[18], b[18];
         memset(a, 0, sizeof a); memset(b, 0, sizeof b);
         return msm_jac_add_host(ctx->curve, (uint32_t*)a, (uint32_t*)b, (uint32_t*)out_jac);
     }
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * msm_limb_base_bytes(ctx->curve), d_scalars, n, (uint32_t*)out_jac, ctx->msm_ws,
+    int rc = msm_run(ctx->curve, (const char*)ctx->d_bases + start * msm_limb_base_bytes(ctx->curve), d_scalars, scalars_mont, n, (uint32_t*)out_jac, ctx->msm_ws,
                      ctx->msm_window, ctx->msm_table, ctx->stream);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
@@ -336,10 +336,7 @@ extern "C" int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_
     CHECK_CTX(ctx);
     if (!out_jacobian || (n_coeffs && !d_coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_dev: null argument");
     const size_t n = std::min(n_coeffs, ctx->n_bases);
-    int rc = ensure_scratch2(ctx, std::max<size_t>(n, 1) * 32);
-    if (rc) return rc;
-    if ((rc = fr_from_mont_dev(ctx->curve, (const Fr*)d_coeffs_mont, (Fr*)ctx->d_scratch2, n, ctx->stream))) return rc;
-    return msm_device(ctx, 0, n, (const uint32_t*)ctx->d_scratch2, out_jacobian);
+    return msm_device(ctx, 0, n, (const uint32_t*)d_coeffs_mont, out_jacobian, /*scalars_mont=*/true);     // into_repr inside the digit kernel
 }
 
 extern "C" int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t start, size_t count, uint64_t* out_jacobian) {
@@ -347,10 +344,7 @@ extern "C" int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont,
     if (!out_jacobian || (count && !d_coeffs_mont)) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_range_dev: null argument");
     if (start > ctx->n_bases) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_range_dev: start %zu beyond the %zu resident bases", start, ctx->n_bases);
     const size_t n = std::min(count, ctx->n_bases - start);
-    int rc = ensure_scratch2(ctx, std::max<size_t>(n, 1) * 32);
-    if (rc) return rc;
-    if ((rc = fr_from_mont_dev(ctx->curve, (const Fr*)d_coeffs_mont, (Fr*)ctx->d_scratch2, n, ctx->stream))) return rc;
-    return msm_device(ctx, start, n, (const uint32_t*)ctx->d_scratch2, out_jacobian);
+    return msm_device(ctx, start, n, (const uint32_t*)d_coeffs_mont, out_jacobian, /*scalars_mont=*/true);
 }
 
 extern "C" int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian) {

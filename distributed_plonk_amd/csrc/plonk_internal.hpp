@@ -144,8 +144,9 @@ struct MsmTable {
 };
 // bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point); with a table,
 // the pointer addresses plane 0 (+ the range start) and the other planes follow at multiples of tab.stride.
-// scalars: device, canonical 8xu32.  out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
-int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, size_t n, uint32_t* h_out_jac,
+// scalars: device, canonical 8xu32 — or Montgomery-form Fr when scalars_mont (into_repr is then taken inside the digit kernel).
+// out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
+int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac,
             MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream);
 int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out);
 int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream);
