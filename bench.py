@@ -158,7 +158,8 @@ def main():
     # always two contexts for the commitments: the 13 MSMs of a proof are independent, and a second stream fills the sort /
     # reduction phases and the wave tail of one MSM with the bucket accumulation of the next (measured: 29.3 -> 26.8 ms per
     # 2^24-point commit, 4.9 -> 4.0 ms at the 2^21 points of an 8-rank shard; tools/msm_overlap.py)
-    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(2)]
+    n_commit_lanes = max(2, int(os.environ.get("PLONK_BENCH_COMMIT_LANES", "2")))      # experiment knob; 2 is the measured choice
+    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_commit_lanes)]
     w = workers[0]
     q64 = w.q64
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
@@ -234,12 +235,12 @@ def main():
 
         def run(lane):
             try:
-                for i in range(lane, count, 2):
+                for i in range(lane, count, n_commit_lanes):
                     parts[i] = cworkers[lane].commit_dev(src, n_loc)
             except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
                 errs.append(ex)
 
-        th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
+        th = [threading.Thread(target=run, args=(lane,)) for lane in range(n_commit_lanes)]
         for t_ in th:
             t_.start()
         return th, parts, errs

@@ -122,6 +122,8 @@ struct SortGeom {
     int W, cb, lp, low_bits;
     uint32_t nblk;               // slices per window
     uint32_t nreal;              // W << lp : real partitions; the W "digit == 0" partitions follow them
+    uint32_t idx_bits;           // > 0: level-1 entries carry the FULL point index in idx_bits bits (low_bits + 1 + idx_bits <= 32), so the
+                                 // level-2 workgroup needs no search for the slice; 0: index within the slice only (wide windows / huge n)
 };
 
 __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blk_hist) {
@@ -148,8 +150,9 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restri
 // write transaction per 4-byte entry (measured WRITE_SIZE 7x the payload).  Instead the slice is first ordered by
 // partition in LDS (counts -> exclusive scan -> ranks), then copied out with consecutive lanes writing consecutive
 // addresses of each partition's run.
-__global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blk_off,
-                                                           uint32_t* __restrict__ tmp) {
+#define SCATTER_THREADS 1024     // 16 waves on a ~74 KiB LDS footprint: two workgroups = eight waves per SIMD hide the LDS-atomic and HBM latency
+__global__ void __launch_bounds__(SCATTER_THREADS) sort_scatter_kernel(const uint32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blk_off,
+                                                                       uint32_t* __restrict__ tmp) {
     extern __shared__ uint32_t sm[];
     const uint32_t np = (1u << g.lp) + 1;                 // last bin: zero digits (dropped)
     uint32_t* cnt = sm;                                   // [np]   counts, then running cursors
@@ -165,15 +168,15 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __res
         atomicAdd(&cnt[mag ? ((mag - 1) >> g.low_bits) : (np - 1)], 1u);
     }
     __syncthreads();
-    // exclusive scan of the np counts (np <= 8193): 256 lanes, each a contiguous strip, then a strip-sum scan
-    __shared__ uint32_t strip[256];
+    // exclusive scan of the np counts (np <= 8193): every lane a contiguous strip, then a strip-sum scan
+    __shared__ uint32_t strip[SCATTER_THREADS];
     const uint32_t per = (np + blockDim.x - 1) / blockDim.x;
-    const uint32_t s0 = threadIdx.x * per, s1 = s0 + per < np ? s0 + per : np;
+    const uint32_t s0 = threadIdx.x * per < np ? threadIdx.x * per : np, s1 = s0 + per < np ? s0 + per : np;
     uint32_t acc = 0;
     for (uint32_t k = s0; k < s1; k++) acc += cnt[k];
     strip[threadIdx.x] = acc;
     __syncthreads();
-    for (int dd = 1; dd < 256; dd <<= 1) {
+    for (int dd = 1; dd < SCATTER_THREADS; dd <<= 1) {
         const uint32_t t = (int)threadIdx.x >= dd ? strip[threadIdx.x - dd] : 0;
         __syncthreads();
         strip[threadIdx.x] += t;
@@ -183,23 +186,41 @@ __global__ void __launch_bounds__(256) sort_scatter_kernel(const uint32_t* __res
     for (uint32_t k = s0; k < s1; k++) { const uint32_t v = cnt[k]; loc[k] = run; cnt[k] = run; run += v; }
     if (threadIdx.x == blockDim.x - 1) loc[np] = strip[blockDim.x - 1];
     __syncthreads();
-    // rank into LDS
+    // rank into LDS.  While the packed entry leaves room (low_bits + 15 + lp <= 32, i.e. windows up to 18 bits) the partition
+    // number rides in the entry's top bits, so the copy-out below needs no search.
     const uint32_t low_mask = (1u << g.low_bits) - 1;
+    const uint32_t ebits = (uint32_t)g.low_bits + SORT_SLICE_LOG + 1;
+    const bool packed = ebits + (uint32_t)g.lp <= 32;
     for (uint64_t i = beg + threadIdx.x; i < end; i += blockDim.x) {
         const uint32_t e = d[i], mag = e & 0x7fffffffu;
         if (!mag) continue;
-        const uint32_t key = mag - 1;
-        const uint32_t pos = atomicAdd(&cnt[key >> g.low_bits], 1u);
-        buf[pos] = ((key & low_mask) << (SORT_SLICE_LOG + 1)) | ((e >> 31) << SORT_SLICE_LOG) | (uint32_t)(i - beg);
+        const uint32_t key = mag - 1, part = key >> g.low_bits;
+        const uint32_t pos = atomicAdd(&cnt[part], 1u);
+        uint32_t v = ((key & low_mask) << (SORT_SLICE_LOG + 1)) | ((e >> 31) << SORT_SLICE_LOG) | (uint32_t)(i - beg);
+        if (packed && g.lp) v |= part << ebits;
+        buf[pos] = v;
     }
     __syncthreads();
     // copy out: position j of the ordered slice belongs to the partition whose [loc[k], loc[k+1]) contains it
     const uint32_t nreal_local = loc[np - 1];             // entries with a non-zero digit
+    const uint32_t emask = ebits >= 32 ? 0xffffffffu : ((1u << ebits) - 1);
     for (uint32_t j = threadIdx.x; j < nreal_local; j += blockDim.x) {
-        uint32_t lo = 0, hi = np - 1;                     // largest k with loc[k] <= j
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (loc[mid] <= j) lo = mid; else hi = mid; }
+        const uint32_t v = buf[j];
+        uint32_t lo;
+        if (packed) {
+            lo = g.lp ? (v >> ebits) : 0;
+        } else {
+            lo = 0;
+            uint32_t hi = np - 1;                         // largest k with loc[k] <= j
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (loc[mid] <= j) lo = mid; else hi = mid; }
+        }
         const uint64_t pid = ((uint64_t)w << g.lp) + lo;
-        tmp[blk_off[pid * g.nblk + blk] + (j - loc[lo])] = buf[j];
+        uint32_t out = packed ? (v & emask) : v;
+        if (g.idx_bits) {                                 // re-pack with the full point index: low | sign | (slice start + index in slice)
+            const uint32_t in = out & (SORT_SLICE - 1), sg = (out >> SORT_SLICE_LOG) & 1u, lowb = out >> (SORT_SLICE_LOG + 1);
+            out = (lowb << (g.idx_bits + 1)) | (sg << g.idx_bits) | (uint32_t)(beg + in);
+        }
+        tmp[blk_off[pid * g.nblk + blk] + (j - loc[lo])] = out;
     }
 }
 
@@ -216,7 +237,7 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
     for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) cnt[k] = 0;
     for (uint32_t k = threadIdx.x; k < g.nblk; k += blockDim.x) run0[k] = po[k];
     __syncthreads();
-    const int sh = SORT_SLICE_LOG + 1;
+    const int sh = g.idx_bits ? (int)g.idx_bits + 1 : SORT_SLICE_LOG + 1;
     for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) atomicAdd(&cnt[tmp[j] >> sh], 1u);
     __syncthreads();
     if (threadIdx.x == 0) {                    // nlow <= 2048: a serial exclusive scan is negligible
@@ -233,6 +254,15 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
     // partition) it costs 6.3 ms.  Ordering the partition in LDS first was measured and rejected: 64 KiB of staging per
     // workgroup leaves one workgroup per CU (7.3 ms), and 4096-entry partitions that would stage in 16 KiB double the
     // level-1 kernels instead (profiles/r01_msm_table_experiment.txt).
+    if (g.idx_bits) {                          // entries carry the full point index: no slice search
+        const uint32_t imask = (1u << g.idx_bits) - 1;
+        for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
+            const uint32_t e = tmp[j];
+            const uint32_t pos = atomicAdd(&cnt[e >> sh], 1u);
+            sorted[pos] = (e & imask) | (((e >> g.idx_bits) & 1u) << 31);
+        }
+        return;
+    }
     for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
         const uint32_t e = tmp[j];
         uint32_t lo = 0, hi = g.nblk;          // slice = largest b with run0[b] <= j
@@ -830,6 +860,11 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     g.low_bits = cb - g.lp;
     g.nblk = (uint32_t)((n + SORT_SLICE - 1) / SORT_SLICE);
     g.nreal = (uint32_t)W << g.lp;
+    {
+        uint32_t ln = 1;
+        while (((uint64_t)1 << ln) < (uint64_t)n) ln++;
+        g.idx_bits = ((uint32_t)g.low_bits + 1 + ln <= 32) ? ln : 0;
+    }
     const uint64_t nhist = ((uint64_t)g.nreal + W) * g.nblk;
     const uint64_t nscan_blocks = (nhist + SCAN_CHUNK - 1) / SCAN_CHUNK;
 
@@ -901,7 +936,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
             attr_set = true;
         }
     }
-    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(256), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(SCATTER_THREADS), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
                        blk_off, tmp);
     hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets); }
     { ProfScope ps("msm_bucket_order", stream);
