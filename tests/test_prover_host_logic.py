@@ -108,3 +108,25 @@ def test_dispatcher_call_sequence_on_cpu_stand_in(oracle, S):
     xy, isinf = d.commit_polynomial(poly)
     want = oracle.jac_to_affine(cid, oracle.commit_polynomial(cid, bases, poly))
     assert isinf == bool(want[1]) and np.array_equal(xy, want[0])
+
+
+def test_bench_dry_run_plans_every_rank_count():
+    """bench.py --dry-run (tools/preflight_multi.sh): no GPU, validates divisibility / sizes for the rank counts the scaling run uses,
+    and refuses what the library would refuse (the 8n domain of a 2^28-gate BN254 circuit does not exist)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for gpus in (1, 2, 4, 8):
+        for scheme in ("classes", "reference2d"):
+            res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--scheme", scheme, "--dry-run"],
+                                 capture_output=True, text=True, timeout=120)
+            assert res.returncode == 0, res.stderr
+            plan = json.loads(res.stdout.strip().splitlines()[-1])
+            assert plan["ok"] and plan["ranks"] == gpus and plan["msm_points_per_rank"] == (1 << 24) // gpus
+            assert plan["transforms"]["8n"]["r"] % gpus == 0 and plan["class_points_per_rank"] == (8 << 24) // gpus
+    bad = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--log-n", "28", "--dry-run"], capture_output=True, text=True, timeout=120)
+    assert bad.returncode == 2 and "two-adicity" in bad.stdout
+    odd = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True, text=True, timeout=120)
+    assert odd.returncode == 2
