@@ -212,10 +212,22 @@ def main():
             provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
 
+    # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
+    # c/8 + 1 coefficients can be non-zero (dispatcher2.rs:746, 754) — plonk_fft1_dev_compact
+    rows_compact, row_len_m = None, 0
+    if multi and not args.dense_coset:
+        r_m, c_m = split_rc(m)
+        row_len_m = (poly_len + r_m - 1) // r_m
+        rows_compact = w.alloc((r_m // S) * row_len_m * 32)
+        w.synth_fr(0xC0EFF + 7 * rank, rows_compact.ptr, (r_m // S) * row_len_m)
+
     def coset_fft_8n(lane):
         """quot_domain.coset_fft of one polynomial (dispatcher2.rs:387-424)."""
         if padded:
             w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[lane][0].ptr)
+        elif rows_compact is not None:
+            provers[lane].fft_dev(rows_compact.ptr, buf_m[lane][1].ptr, m, True, False, True, out_layout=1, row_len=row_len_m)
+            buf_m[lane][0], buf_m[lane][1] = buf_m[lane][1], buf_m[lane][0]
         else:
             ntt(lane, buf_m[lane], m, False, True, True)
 
@@ -371,8 +383,9 @@ def main():
                 dt2 = float(t.item())
             other_scheme = {"scheme": "reference2d" if scheme == "classes" else "classes", "steps": 2, "ms_per_step": round(dt2 / 2 * 1e3, 3),
                             "constraints_per_s": round(n / (dt2 / 2), 1),
-                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform on dense inputs (33 RCCL "
-                                    "all-to-alls per step); classes = rank-local coset classes, 2 data-path collectives per step"}
+                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform (33 RCCL all-to-alls per step; the 25 "
+                                    "forward coset FFTs take zero-padded rows, plonk_fft1_dev_compact, unless --dense-coset); classes = rank-local "
+                                    "coset classes, 2 data-path collectives per step"}
         except Exception as ex:
             other_scheme = {"error": repr(ex)}
 
@@ -725,7 +738,7 @@ def main():
                                        ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}")) if world == 1
                                       else (f"{world} ranks, scheme {scheme}: " +
                                             ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
-                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each, dense inputs") +
+                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs")) +
                                             f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
                        "coset_inputs": "n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else "dense 8n (plonk_ntt_dev / distributed 2-D transform)",
                        "rccl": rccl_info},
@@ -745,6 +758,8 @@ def main():
     bases.free()
     if buf_p is not None:
         buf_p.free()
+    if rows_compact is not None:
+        rows_compact.free()
     if cls is not None:
         for k_ in ("poly", "out", "contrib", "recv", "mine", "quot"):
             cls[k_].free()

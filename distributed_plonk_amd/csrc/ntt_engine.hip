@@ -392,14 +392,18 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     if (NP > 1 && !c.shared_in && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: in == out needs a single pass");
     const NttTables::ShiftSet* sset = nullptr;
     if (c.shared_in) {
-        if (interleaved || c.inverse || c.pro.kind || c.epi.kind || c.split_log >= 0 || c.in_len == 0 || c.in_len > 4 * M)
-            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, unscaled, 1 <= len <= 4M");
+        const bool epi_ok = c.epi.kind == 0 || ((c.epi.kind == 3 || c.epi.kind == 4) && c.epi.bq == 1 && c.epi.b0 == 0 && c.epi.aq == 0 && c.epi.a0 == 0);
+        if (interleaved || c.inverse || c.pro.kind || !epi_ok || c.in_len == 0 || c.in_len > 4 * M || c.in_rows == 0 || Bt % c.in_rows ||
+            (c.row_coset_const && c.epi.kind == 0))
+            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, 1 <= len <= 4M, batch = rows * classes");
         if (NP > 1 && (c.work == nullptr || (const void*)c.work == (const void*)c.out || (const void*)c.work == (const void*)c.in))
             return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation needs a separate work buffer");
         if (NP == 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation cannot run in place");
-        int rc = get_shift_set(T, c.shift, L, Bt, widths[0], NP, &sset, stream);
+        int rc = get_shift_set(T, c.shift, L, Bt / c.in_rows, widths[0], NP, &sset, stream);
         if (rc) return rc;
     }
+    const uint64_t n_cls = c.shared_in ? Bt / c.in_rows : 1;                 // classes per row (shared-input mode)
+    const int cls_log = ilog2(n_cls);
     Fr* const inplace = c.shared_in ? c.work : const_cast<Fr*>(c.in);      // where the non-last passes leave their output
     if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(c))
         return plonk_fail(PLONK_ERR_ARG, "ntt_run: in-place only for contiguous single pass");
@@ -414,9 +418,15 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     const int log_b0 = simple_coset ? ilog2(c.pro.b0) : 0;
     // the distributed row pass's output factor w_N^(+-(q+q0)*k)
     const bool row_twiddle = (c.epi.kind == 3 || c.epi.kind == 4) && c.epi.bq == 1 && c.epi.b0 == 0 && c.epi.aq == 0 && c.epi.a0 == 0;
-    const bool need_q_const = simple_coset && c.pro.aq == 1;      // only foldable into an output-factor plane
+    const bool need_q_const = (simple_coset && c.pro.aq == 1) || (c.shared_in && c.row_coset_const);      // only foldable into an output-factor plane
     Fr* epi_plane = nullptr;
-    if (planes_on_global() && row_twiddle && !interleaved && (!need_q_const || NP >= 2)) {
+    if (c.shared_in) {
+        if (row_twiddle) {          // the plane covers whole rows: 2^(L + cls_log) natural-order outputs per row, in_rows rows
+            int rc = get_epi_plane(T, c.epi.log_order, L + cls_log, c.in_rows, c.q_offset, c.epi.kind - 3, need_q_const, &epi_plane, stream);
+            if (rc) return rc;
+            if (epi_plane == nullptr) return plonk_fail(PLONK_ERR_HIP, "ntt_run: no room for the output-factor plane of the zero-padded row pass");
+        }
+    } else if (planes_on_global() && row_twiddle && !interleaved && (!need_q_const || NP >= 2)) {
         int rc = get_epi_plane(T, c.epi.log_order, L, Bt, c.q_offset, c.epi.kind - 3, need_q_const && NP >= 2, &epi_plane, stream);
         if (rc) return rc;
     }
@@ -439,7 +449,9 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         P.split_log = -1;
         P.is_last = last ? 1 : 0;
         P.in = (p == 0) ? c.in : inplace;
+        P.cls_log = (uint32_t)cls_log;
         if (sset != nullptr && p == 0) {
+            P.in_row_pitch = c.in_pitch;
             P.in_len = c.in_len;
             P.fold_m = M;
             P.nfold = (uint32_t)std::min<uint64_t>(4, (c.in_len + M - 1) / M);
@@ -501,7 +513,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         } else {
             P.out = c.out;
             P.kstride = M >> w;
-            if (sset != nullptr && NP >= 2 && c.out_layout == NTT_INTERLEAVED && Bt >= 2) {
+            if (sset != nullptr && NP >= 2 && n_cls >= 2) {
                 // the tile's columns are the ARRAYS (cosets): contiguous runs in, and for every output index k the T arrays' values
                 // leave as one T*32-byte piece of the interleaved (natural-order) result
                 avail = Bt;
@@ -556,13 +568,14 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
                 P.pa = 1;
                 grid = P.n0 * P.n1;
             }
-            if (c.out_layout == NTT_CONTIGUOUS) { P.oq = M; P.ok = 1; } else { P.oq = 1; P.ok = Bt; }
+            if (sset != nullptr) { P.oq = M * n_cls; P.ok = 1; }         // rows contiguous, a row's classes interleaved (kernel: k' = k << cls_log | class)
+            else if (c.out_layout == NTT_CONTIGUOUS) { P.oq = M; P.ok = 1; } else { P.oq = 1; P.ok = Bt; }
             P.split_log = c.split_log;
             P.split_blk = c.split_blk;
             if (c.inverse && NP == 1) { P.scale_const_enabled = 1; P.scale_const = f29_const_from_mont256(T.h_pow2_inv[L], T.fp); }
-            if (epi_plane != nullptr && (!need_q_const || coset_folded)) {
+            if (epi_plane != nullptr && (!need_q_const || coset_folded || sset != nullptr)) {
                 P.epi_plane = epi_plane;          // q here is the LOCAL array index: the plane was generated with q0 added
-                P.epi_qstride = M;
+                P.epi_qstride = M * n_cls;
             } else {
                 P.epi = make_scale(T, c.epi, c.q_offset);
             }

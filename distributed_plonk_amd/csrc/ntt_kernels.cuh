@@ -85,7 +85,13 @@ struct NttPassParams {
     uint64_t in_len;                      // 0: dense per-array input
     uint64_t fold_m;
     uint32_t nfold;
-    const F29* fold_c;                    // [array][4], constant form
+    const F29* fold_c;                    // [class][4], constant form
+    // Arrays = rows x classes, array A = row << cls_log | class: the classes of a row read that row's coefficients
+    // (in + row * in_row_pitch) and share the per-class tables; in the last pass the classes of a row interleave into that row's
+    // natural order: output index k' = k << cls_log | class, output array = row.  cls_log = 0: every array is its own row (the
+    // dense transforms), the formulas reduce to the identity.
+    uint32_t cls_log;
+    uint64_t in_row_pitch;
     const Fr* epi_plane;                  // last pass: precomputed output factors, index q*epi_qstride + k (nullable)
     uint64_t epi_qstride;
     uint32_t scale_const_enabled;         // multiply outputs by `scale_const` (1/N when P==1)
@@ -255,19 +261,22 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         if (P.load_a_fast) { a = e & (R - 1); t = e >> LOG_R; }
         else               { t = e & (T - 1); a = e >> P.log_t; }
         F29 v;
+        const uint64_t arr = q0 + (uint64_t)t * P.tq;                       // array index; its class selects the first-pass tables
+        const uint64_t cls = arr & (((uint64_t)1 << P.cls_log) - 1);
         if (P.in_len != 0) {
             const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
+            const Fr* src = P.in + (arr >> P.cls_log) * P.in_row_pitch;
             if (pos < P.in_len) {
-                v = f29_from_sat(load_fr(P.in + pos));
+                v = f29_from_sat(load_fr(src + pos));
             } else {
 #pragma unroll
                 for (int l = 0; l < 9; l++) v.l[l] = 0;
             }
             if (P.nfold > 1 && pos + P.fold_m < P.in_len) {       // a handful of elements per transform (n + 3 coefficients on n points)
-                const F29* fc = P.fold_c + 4 * (q0 + (uint64_t)t * P.tq);
+                const F29* fc = P.fold_c + 4 * cls;
                 for (uint32_t uu = 1; uu < P.nfold; uu++) {
                     const uint64_t j = pos + (uint64_t)uu * P.fold_m;
-                    if (j < P.in_len) v = f29_add(v, f29_mul(f29_from_sat(load_fr(P.in + j)), load_f29(fc + uu), P.fp));
+                    if (j < P.in_len) v = f29_add(v, f29_mul(f29_from_sat(load_fr(src + j)), load_f29(fc + uu), P.fp));
                 }
                 f29_norm(v);                                      // < p + 3 * 1.36 p
             }
@@ -275,10 +284,10 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));
         }
         if (P.pro_rowtab != nullptr) {
-            v = f29_mul(v, load_f29(P.pro_rowtab + (q0 + (uint64_t)t * P.tq) * P.rowtab_qstride + a), P.fp);
+            v = f29_mul(v, load_f29(P.pro_rowtab + cls * P.rowtab_qstride + a), P.fp);
         } else if (P.pro.enabled) {
             const uint64_t pos = (uint64_t)a * P.pa + x0 * P.ps0 + x1 * P.ps1 + (uint64_t)t * P.pt;
-            const F29 s = two_level(P.pro, pos, q0 + (uint64_t)t * P.tq, P.fp);
+            const F29 s = two_level(P.pro, pos, arr, P.fp);
             v = f29_mul(v, s, P.fp);
         }
         const uint32_t row = brev(a, LOG_R);
@@ -336,7 +345,8 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             const uint64_t b = b0 + (uint64_t)t * P.tb;
             if (P.tw_plane != nullptr) {
                 // streamed factor plane: one 256-bit-limb load replaces two table gathers and a product
-                v = f29_mul(v, f29_from_sat(load_fr(P.tw_plane + (q0 + (uint64_t)t * P.tq) * P.plane_qstride + (uint64_t)idx * P.plane_rp + b)), P.fp);
+                const uint64_t pcls = (q0 + (uint64_t)t * P.tq) & (((uint64_t)1 << P.cls_log) - 1);
+                v = f29_mul(v, f29_from_sat(load_fr(P.tw_plane + pcls * P.plane_qstride + (uint64_t)idx * P.plane_rp + b)), P.fp);
             } else {
                 const uint64_t ex = (b * idx) << P.tw_shift;
                 const uint64_t mask = ((uint64_t)1 << P.tw_lt) - 1;
@@ -347,8 +357,9 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             // < 1.36 p < 2^256: stored re-packed but not canonicalised (the next pass does not care)
             store_fr(P.out + sbase + (uint64_t)idx * P.s_istride + (uint64_t)t * P.s_tstride, f29_to_sat(v));
         } else {
-            const uint64_t q = q0 + (uint64_t)t * P.tq;
-            const uint64_t k = m0 + (uint64_t)t * P.tk + (uint64_t)idx * P.kstride;
+            const uint64_t arr = q0 + (uint64_t)t * P.tq;
+            const uint64_t q = arr >> P.cls_log;                                        // output array (row)
+            const uint64_t k = ((m0 + (uint64_t)t * P.tk + (uint64_t)idx * P.kstride) << P.cls_log) | (arr & (((uint64_t)1 << P.cls_log) - 1));
             bool lazy = false;
             if (P.epi_plane != nullptr) {
                 v = f29_mul(v, f29_from_sat(load_fr(P.epi_plane + q * P.epi_qstride + k)), P.fp);

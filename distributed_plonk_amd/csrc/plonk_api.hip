@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 
+#include "constants.h"
 #include "ec.cuh"
 #include "plonk_internal.hpp"
 
@@ -49,6 +50,8 @@ struct FftTask {          // reference FftTask, worker.rs:32-40
     uint64_t r = 0, c = 0, nrows = 0, ncols = 0;
     Fr* d_rows = nullptr;      // [nrows][c]      (owned unless rows_external)
     bool rows_external = false;
+    uint64_t compact_len = 0;  // > 0: d_rows is [nrows][compact_len], the leading coefficients of zero-padded rows (plonk_fft1_dev_compact)
+    Fr* d_work = nullptr;      // row-pass workspace of the compact form
     Fr* d_send = nullptr;      // S blocks of [nrows][ncols]
     Fr* d_recv = nullptr;      // [r][ncols]
     std::vector<uint8_t> row_present;
@@ -141,6 +144,8 @@ static int ensure_scratch2(plonk_ctx* ctx, size_t bytes) {
 static void free_task(plonk_ctx* ctx, FftTask& t) {
     const size_t tile_bytes = t.nrows * t.c * 32;
     if (t.d_rows && !t.rows_external) pool_put(ctx, tile_bytes, t.d_rows);
+    if (t.d_work) pool_put(ctx, tile_bytes, t.d_work);
+    t.d_work = nullptr;
     if (t.d_send) pool_put(ctx, tile_bytes, t.d_send);
     if (t.d_recv && t.d_recv != t.d_send) pool_put(ctx, tile_bytes, t.d_recv);
     t.d_rows = t.d_send = t.d_recv = nullptr;
@@ -508,6 +513,27 @@ extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows) {
     return PLONK_OK;
 }
 
+// The rows of a ZERO-PADDED vector: only the leading `row_len` coefficients of every decimated row are given ([num_rows][row_len],
+// row_len <= c); the rest of the row is zero by construction and is never materialised.  The reference pads n + 2 / n + 3
+// coefficients to the 8n-point domain before decimating (dispatcher2.rs:746, 754): row b of length c then has c/8 (+ 1 for b < 3)
+// leading non-zero entries.  Forward transforms only.  The buffer is not modified.
+extern "C" int plonk_fft1_dev_compact(plonk_ctx* ctx, uint64_t id, const void* d_rows, size_t row_len) {
+    CHECK_CTX(ctx);
+    FftTask* t;
+    int rc = get_task(ctx, id, &t);
+    if (rc) return rc;
+    if (!d_rows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev_compact: null");
+    if (t->prepared) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1_dev_compact: already prepared");
+    if (t->is_inv) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev_compact: zero-padded rows are a forward-transform input");
+    if (row_len == 0 || row_len > t->c) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1_dev_compact: row_len %zu outside [1, %llu]", row_len, (unsigned long long)t->c);
+    if (t->d_rows && !t->rows_external) pool_put(ctx, t->nrows * t->c * 32, t->d_rows);
+    t->d_rows = (Fr*)const_cast<void*>(d_rows);
+    t->rows_external = true;
+    t->compact_len = row_len;
+    t->rows_filled = t->nrows;
+    return PLONK_OK;
+}
+
 // ---------------------------------------------------------------------------------------------- RCCL transport
 extern "C" int plonk_comm_unique_id(void* out_id) {
     if (!out_id) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_unique_id: null");
@@ -594,6 +620,30 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     c.epi.log_order = t->log_n;
     c.split_log = ilog2_exact(t->ncols);
     c.split_blk = t->nrows * t->ncols;
+    if (t->compact_len) {
+        // zero-padded rows: row b's size-c transform is 2^k independent (c / 2^k)-point transforms of its leading coefficients on
+        // the sub-cosets (g^r * w_c^q) * <w_(c/2^k)> (the row's own constant g^b and the twiddle w_N^(b*k') ride in the output plane)
+        const uint64_t len = t->compact_len;
+        int k = 0;
+        while (k < 4 && c.log_m - k > 1 && 2 * len < 3 * (t->c >> (k + 1))) k++;       // same rule as coset_eval_run
+        if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_work))) return rc;
+        c.pro = ScaleSpec();
+        c.shared_in = true;
+        c.in_rows = t->nrows;
+        c.in_len = len;
+        c.in_pitch = len;
+        c.work = t->d_work;
+        c.log_m -= k;
+        c.batch = t->nrows << k;
+        const FrParams& FP = fr_params(ctx->curve);
+        Fr sh = fp_one(FP);
+        if (t->is_coset) {
+            sh = fp_from_limbs<8>(ctx->curve == PLONK_BN254 ? BN254_FR_GENERATOR_MONT : BLS12_381_FR_GENERATOR_MONT);
+            for (int i = 0; i < (t->log_n >> 1); i++) sh = fp_sqr(sh, FP);             // g^r
+        }
+        c.shift = sh;
+        c.row_coset_const = t->is_coset;
+    }
     if ((rc = ntt_run(ctx->tables, c, ctx->stream))) return rc;
     if (exchange) {          // also honoured for a single rank (all-to-all with oneself), so the transport is testable on one GPU
         if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_recv))) return rc;

@@ -121,6 +121,14 @@ struct NttCall {
     uint64_t in_len = 0;
     Fr shift;
     Fr* work = nullptr;
+    // Batched form (the distributed row pass on zero-padded rows): `in_rows` independent coefficient vectors of in_len coefficients,
+    // in_pitch elements apart; batch = in_rows * classes, array = row * classes + class; the classes of a row interleave into that
+    // row's natural order in the output (row r -> out + r * M * classes, or the split / epilogue addressing with q = r).  Allowed
+    // on top: the row-twiddle epilogue w_N^(+-(r + q_offset) * k) (epi.kind 3 / 4, bq = 1), the per-row coset constant g^(r + q_offset)
+    // (row_coset_const) and split_log / split_blk.
+    uint64_t in_rows = 1;
+    uint64_t in_pitch = 0;
+    bool row_coset_const = false;
 };
 
 int ntt_tables_create(NttTables& T, int curve, hipStream_t stream);

@@ -215,14 +215,19 @@ class RankProver:
             self._exchange = make_torch_exchange(group) if (world > 1 or force_exchange) else None
 
     def fft_dev(self, d_rows_ptr: int, d_out_ptr: int, domain_size: int, is_quot: bool, is_inv: bool, is_coset: bool,
-                out_layout: int = 1):
+                out_layout: int = 1, row_len: int = 0):
         """HBM-resident distributed NTT.  In: this rank's decimated rows [r/S][c] (row b = elements with
         index mod r == b) — CONSUMED (the row pass uses the buffer as its workspace, like plonk_ntt_dev's d_in).
-        Out (layout 1): [r][c/S], element (j, i) = X[(i + col_start) + j*c]."""
+        Out (layout 1): [r][c/S], element (j, i) = X[(i + col_start) + j*c].
+        row_len > 0: the rows belong to a zero-padded vector and hold only their leading row_len coefficients
+        ([r/S][row_len]; plonk_fft1_dev_compact) — the zero-padding-aware row pass, forward transforms only."""
         id = self._rng.getrandbits(64)
         wl = make_fft_workloads(domain_size, self.world)
         self.w.fft_init(id, wl, is_quot, is_inv, is_coset)
-        self.w.fft1_dev(id, d_rows_ptr)
+        if row_len:                                   # zero-padded input: [r/S][row_len] leading coefficients per row, not consumed
+            self.w.fft1_dev_compact(id, d_rows_ptr, row_len)
+        else:
+            self.w.fft1_dev(id, d_rows_ptr)
         self.w.fft2_prepare(id, self._exchange)
         self.w.fft2_dev(id, d_out_ptr, out_layout)
 

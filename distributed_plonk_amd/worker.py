@@ -180,6 +180,11 @@ class PlonkWorker:
         """All local rows at once; the buffer is consumed (must stay alive until fft2_prepare returns, contents destroyed)."""
         check(self.lib.plonk_fft1_dev(self.ctx, id, d_rows_ptr))
 
+    def fft1_dev_compact(self, id: int, d_rows_ptr: int, row_len: int):
+        """Rows of a zero-padded vector: [num_rows][row_len] leading coefficients, the rest of every row zero by construction
+        (forward transforms; the buffer is not modified)."""
+        check(self.lib.plonk_fft1_dev_compact(self.ctx, id, d_rows_ptr, row_len))
+
     def fft2_prepare(self, id: int, exchange: Optional[Callable] = None):
         """exchange(send_ptr, recv_ptr, bytes_per_peer, n_ranks, stream_ptr) -> int (0 = ok)."""
         if exchange is None:

@@ -155,6 +155,12 @@ int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t sta
  * alive until plonk_fft2_prepare returns, which runs the row pass with d_rows as its inter-pass workspace (c > 2^9) and leaves
  * garbage in it — like plonk_ntt_dev's d_in. */
 int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows);
+/* The same for the rows of a ZERO-PADDED vector (the reference pads n + 2 / n + 3 coefficients to the 8n-point domain before it
+ * decimates, dispatcher2.rs:746, 754): d_rows is [num_rows][row_len] — the leading row_len coefficients of every decimated row, the
+ * rest of each row being zero by construction and never materialised (row b of the padded 8n vector has c/8 leading entries, one
+ * more for b < 3).  Forward transforms only; the row pass then runs as 2^k independent (c/2^k)-point transforms per row.  The
+ * buffer is NOT modified and must stay alive until plonk_fft2_prepare returns. */
+int plonk_fft1_dev_compact(plonk_ctx* ctx, uint64_t id, const void* d_rows, size_t row_len);
 /* Result of fft2 left in HBM.  layout 0: [num_cols][r] (the reference's reply); layout 1:
  * [r][num_cols] (natural order restricted to this rank's columns: element (j, i) = X[(i + col_start) + j*c]). */
 int plonk_fft2_dev(plonk_ctx* ctx, uint64_t id, void* d_out, int layout);

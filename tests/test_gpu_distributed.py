@@ -264,3 +264,63 @@ def test_in_library_rccl_transport_single_rank(oracle):
     finally:
         for wk in lanes:
             wk.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_N,S,length_of", [
+    (11, 1, lambda N: N // 8 + 3), (11, 2, lambda N: N // 8 + 3),      # r = 32, c = 64: 9 leading coefficients per row, 8 classes of 8
+    (13, 4, lambda N: N // 8 + 3),                                      # odd log: c = 2r
+    (16, 2, lambda N: N // 8 + 2),                                      # c = 256: classes of 32 points
+    (19, 4, lambda N: N // 8 + 3),                                      # c = 1024, classes of 128
+    (22, 2, lambda N: N // 8 + 3),                                      # c = 2048: classes of 256 (single pass each)
+    (24, 4, lambda N: N // 8 + 3),                                      # c = 4096: classes of 512
+    (27 - 2, 2, lambda N: N // 8 + 3),                                  # c = 8192: two-pass classes (2^10)
+    (16, 1, lambda N: N // 2 + 1),                                      # half full: two classes
+    (16, 2, lambda N: N - 5),                                           # nearly dense: one class, zero tail only
+    (13, 2, lambda N: 7),                                               # almost everything zero: the class cap
+])
+def test_zero_padded_row_pass_matches_oracle(gpu_workers, oracle, curve, cid, log_N, S, length_of):
+    """plonk_fft1_dev_compact: the distributed forward transform of a ZERO-PADDED vector from only the leading coefficients of every
+    decimated row (what the reference pads and ships in full, dispatcher2.rs:746-766) == the oracle's transform of the explicitly
+    padded vector, plain and coset, for every class count, S in-process workers with the device-to-device block exchange."""
+    from distributed_plonk_amd.worker import PlonkWorker
+    N = 1 << log_N
+    length = length_of(N)
+    r, c = split_rc(N)
+    row_len = min(c, (length + r - 1) // r)
+    coeffs = oracle.rand_fr(cid, 8100 + log_N, length)
+    v = np.zeros((N, 4), dtype=np.uint64)
+    v[:length] = coeffs
+    t = np.ascontiguousarray(v.reshape(c, r, 4).transpose(1, 0, 2))                  # t[b][a] = v[a*r + b]  (dispatcher2.rs:754)
+    assert not t[:, row_len:].any()
+    workers = [gpu_workers(curve)] + [PlonkWorker(me=i, device=0, curve=curve) for i in range(1, S)]
+    try:
+        d = Dispatcher(workers)
+        d.init(None, N, 0)
+        wl = make_fft_workloads(N, S)
+        for is_coset in (False, True):
+            id = 4242 + int(is_coset)
+            keep = []
+            for s, w in enumerate(workers):
+                w.fft_init(id, wl, False, False, is_coset)
+                rows = np.ascontiguousarray(t[wl[s].row_start:wl[s].row_end, :row_len])
+                buf = w.alloc(rows.nbytes).upload(rows)
+                keep.append((buf, rows))
+                w.fft1_dev_compact(id, buf.ptr, row_len)
+            d._fft2_prepare_all(id)
+            u = np.empty((c, r, 4), dtype=np.uint64)
+            for s, w in enumerate(workers):
+                u[wl[s].col_start:wl[s].col_end] = w.fft2(id, r)
+            got = np.ascontiguousarray(u.transpose(1, 0, 2)).reshape(-1, 4)          # :786
+            want = oracle.ntt(cid, v, False, is_coset, threads=32)
+            assert np.array_equal(got, want), (is_coset, S)
+            for (buf, rows), w in zip(keep, workers):
+                assert np.array_equal(buf.download(rows.shape), rows)                # the compact rows are not modified
+                buf.free()
+        with pytest.raises(Exception):                                               # inverse transforms take dense rows
+            workers[0].fft_init(777, wl, False, True, False)
+            b = workers[0].alloc(64)
+            workers[0].fft1_dev_compact(777, b.ptr, 1)
+    finally:
+        for w in workers[1:]:
+            w.close()
