@@ -60,13 +60,14 @@ def parse():
                     help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
                          "on by default for N > 1, reported under next_rows, never part of `value`")
     ap.add_argument("--no-class-prover", action="store_true", help="N > 1: skip the coset-class prover leg")
-    ap.add_argument("--scheme", default="classes", choices=["classes", "reference2d"],
-                    help="N > 1: how the step's transforms are distributed.  'classes' (default): rank s evaluates every polynomial on ITS coset "
+    ap.add_argument("--scheme", default="reference2d", choices=["classes", "reference2d"],
+                    help="N > 1: how the step's transforms are distributed.  'classes': rank s evaluates every polynomial on ITS coset "
                          "class (the points j = s mod N of the 8n-point coset) with a local zero-padding-aware (8n/N)-point transform - no "
                          "exchange for the 25 forward coset FFTs; the quotient's coset iFFT is one class-local inverse transform + ONE all-to-all "
-                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs run on every rank.  'reference2d': every one "
-                         "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass) on dense "
-                         "inputs.  The other scheme is timed after the headline and reported as `other_scheme`")
+                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs run on every rank.  'reference2d' (default): every one "
+                         "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass), the 25 forward "
+                         "coset FFTs from zero-padded rows (plonk_fft1_dev_compact), two lanes so that exchanges overlap the next transform's passes.  "
+                         "The other scheme is timed after the headline and reported as `other_scheme`")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: validate the arguments for this --gpus (divisibility of r and n, class count, buffer sizes per rank) and print the plan")
     ap.add_argument("--multi-path", action="store_true",
