@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--dense-coset", action="store_true",
                     help="feed the 25 forward coset transforms dense random 8n-point inputs through plonk_ntt_dev (the round-1 bench line) "
                          "instead of the n+3 coefficients the prover actually has (zero-padded to 8n by the reference, dispatcher2.rs:746)")
+    ap.add_argument("--n-domain-only", action="store_true",
+                    help="BASELINE.json configs[4] (2^28-gate BN254: 'HBM-resident witness' sizing stress): the 8n quotient domain of such a circuit "
+                         "does not exist on BN254 (two-adicity 28), so only the n-domain part of the step runs - 7 iNTT(n) + 13 commitments(n)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run result checks (`verified` becomes null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY §8f rows measured after the headline (quotient kernel, prover rounds)")
@@ -83,12 +86,16 @@ def plan(args, S):
     n, m = 1 << args.log_n, 8 << args.log_n
     two_adicity = 28 if args.curve == "bn254" else 32
     problems = []
-    if args.log_n + 3 > two_adicity:
-        problems.append(f"the quotient domain 2^{args.log_n + 3} exceeds the field's two-adicity {two_adicity} (DomainCreationError)")
+    if args.n_domain_only:
+        if args.log_n > two_adicity:
+            problems.append(f"the domain 2^{args.log_n} exceeds the field's two-adicity {two_adicity} (DomainCreationError)")
+    elif args.log_n + 3 > two_adicity:
+        problems.append(f"the quotient domain 2^{args.log_n + 3} exceeds the field's two-adicity {two_adicity} (DomainCreationError); "
+                        f"--n-domain-only runs the n-domain part of the step")
     if S & (S - 1):
         problems.append(f"{S} ranks: the row / column / class partitions need a power of two")
     sizes = {}
-    for name, N_ in (("n", n), ("8n", m)):
+    for name, N_ in ((("n", n),) if args.n_domain_only else (("n", n), ("8n", m))):
         log = N_.bit_length() - 1
         r_, c_ = 1 << (log >> 1), 1 << (log - (log >> 1))
         if r_ % S or c_ % S:
@@ -100,12 +107,14 @@ def plan(args, S):
     GiB = float(1 << 30)
     q_bytes = 64 if args.curve == "bn254" else 96
     limb_bytes = 72 if args.curve == "bn254" else 112
+    me_ = 0 if args.n_domain_only else m
+    msm_ws = 3 * 4 * 15 * min(n // S, 1 << 26)                          # digit / sorted-index arrays of one MSM slice
     if S == 1:
-        hbm = 2 * n * 32 + 2 * m * 32 + (n + 3) * 32 + m * 32 + 2 * (n * limb_bytes) + n * q_bytes + 2 * m * 32    # buffers + scratch + SRS (two contexts) + planes
+        hbm = 2 * n * 32 + 2 * me_ * 32 + (n + 3) * 32 + me_ * 32 + 2 * (n * limb_bytes) + n * q_bytes + 2 * me_ * 32 + 2 * msm_ws + n * 32   # buffers + scratch + SRS (two contexts) + planes
     else:
-        hbm = (2 * 2 * (n // S) * 32 + 2 * 2 * (m // S) * 32            # reference2d lanes
-               + 2 * n * 32 + (n + 3) * 32 + 2 * (m // S) * 32 + 3 * m * 32     # classes: bn, poly, out/mine, contrib/recv/quot
-               + 2 * (n // S) * limb_bytes + (n // S) * q_bytes + (m // S) * 32 * 2)
+        hbm = (2 * 2 * (n // S) * 32 + 2 * 2 * (me_ // S) * 32           # reference2d lanes
+               + (2 * n * 32 + (n + 3) * 32 + 2 * (me_ // S) * 32 + 3 * me_ * 32 if me_ else 0)     # classes: bn, poly, out/mine, contrib/recv/quot
+               + 2 * (n // S) * limb_bytes + (n // S) * q_bytes + (me_ // S) * 32 * 2 + 2 * msm_ws + 3 * (n // S) * 32)
     return {"n": n, "m": m, "ranks": S, "scheme": args.scheme if S > 1 else "single", "transforms": sizes,
             "msm_points_per_rank": n // S, "class_points_per_rank": m // S, "approx_hbm_GiB_per_rank_headline": round(hbm / GiB, 1),
             "problems": problems, "ok": not problems}
@@ -144,6 +153,9 @@ def main():
 
     n = 1 << args.log_n
     m = 8 * n
+    nbig = 0 if args.n_domain_only else N_NTT_BIG          # size-8n transforms per step
+    if args.n_domain_only:
+        args.scheme, args.no_class_prover, args.no_next_rows, args.no_other_configs, args.no_cpu_baseline = "reference2d", True, True, True, True
     S = world
     sim = args.simulate_ranks if (world == 1 and args.simulate_ranks > 1) else 0
     if sim:
@@ -182,7 +194,7 @@ def main():
     provers = [RankProver(x, rank, S, exchange=noop_exchange, transport=transport) for x in workers[:n_lanes]]
 
     # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
-    n_loc, m_loc = n // S, m // S
+    n_loc, m_loc = n // S, (m // S if nbig else 8)
     buf_n = [[w.alloc(n_loc * 32), w.alloc(n_loc * 32)] for _ in range(n_lanes)]
     buf_m = [[w.alloc(m_loc * 32), w.alloc(m_loc * 32)] for _ in range(n_lanes)]
     for lane in range(n_lanes):
@@ -190,7 +202,7 @@ def main():
         w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
     # the coefficient vectors the 25 forward coset transforms start from: n + 3 coefficients (the blinded permutation polynomial's
     # length; wires have n + 2, selectors n), which the reference zero-pads to 8n (dispatcher2.rs:746)
-    padded = (S == 1) and not multi and not args.dense_coset
+    padded = (S == 1) and not multi and not args.dense_coset and nbig > 0
     poly_len = n + 3
     gen_limbs = None
     buf_p = None
@@ -203,7 +215,7 @@ def main():
     # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
     w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
     for x in workers:
-        x.init_dev(bases.ptr, n_loc, n, m)      # both contexts hold the SRS shard in the resident limb form
+        x.init_dev(bases.ptr, n_loc, n, m if nbig else 0)      # both contexts hold the SRS shard in the resident limb form
         x.sync()
 
     def ntt(lane, bufs, size, inv, coset, is_quot):
@@ -216,7 +228,7 @@ def main():
     # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
     # c/8 + 1 coefficients can be non-zero (dispatcher2.rs:746, 754) — plonk_fft1_dev_compact
     rows_compact, row_len_m = None, 0
-    if multi and not args.dense_coset:
+    if multi and not args.dense_coset and nbig:
         r_m, c_m = split_rc(m)
         row_len_m = (poly_len + r_m - 1) // r_m
         rows_compact = w.alloc((r_m // S) * row_len_m * 32)
@@ -279,9 +291,10 @@ def main():
     def step():
         for i in range(N_NTT_SMALL):
             ntt(i % n_lanes, buf_n[i % n_lanes], n, True, False, False)
-        for i in range(N_NTT_BIG - 1):
+        for i in range(nbig - 1):
             coset_fft_8n(i % n_lanes)
-        ntt(0, buf_m[0], m, True, True, True)
+        if nbig:
+            ntt(0, buf_m[0], m, True, True, True)
         for x in workers:
             x.sync()                              # the commitments read lane-0 buffers from both contexts
         # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
@@ -294,7 +307,7 @@ def main():
     # coset iFFT is the class-local inverse + one all-to-all (sum) + one all-gather.  Same work as the reference's 33 distributed
     # transforms, two data-path collectives instead of 33.
     cls = None
-    if multi:
+    if multi and nbig:
         from distributed_plonk_amd import fr as _fr
         f_ = _fr.FIELDS[args.curve]
         G = S
@@ -368,7 +381,7 @@ def main():
 
     # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
     other_scheme = None
-    if multi and not sim:
+    if multi and not sim and nbig:
         try:
             other = step_ref2d if scheme == "classes" else step_classes
             other()
@@ -401,9 +414,9 @@ def main():
     # algorithmic bytes: NTT(N) = 2*N*32 per transform, spread over its pass launches;
     # MSM(n) = n*(sizeof(affine)+32) per MSM, attributed to the bucket-accumulation launch.
     if scheme == "classes":      # per rank: the 7 size-n iNTTs in full (they run on every rank), its class (8n/N points) of the 26 big ones
-        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n + N_NTT_BIG * m_loc)
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n + nbig * m_loc)
     else:
-        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + N_NTT_BIG * m_loc)
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + nbig * m_loc)
     msm_alg_total = args.steps * N_MSM * n_loc * (aff_bytes + 32.0)
     roof = {}
     if "ntt_pass_kernel" in kernels:
@@ -476,7 +489,9 @@ def main():
             # (2) one 8n coset FFT as timed: sampled outputs against Horner evaluations by an unrelated kernel (plonk_poly_eval_dev,
             #     itself oracle-checked in tests/), then the coset iFFT must return the zero-padded coefficients everywhere
             CH = 1 << 22
-            if padded:
+            if not nbig:
+                pass                                   # --n-domain-only: there is no 8n transform to check
+            elif padded:
                 w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[0][0].ptr)
                 w_m = f_.root_of_unity(m)
                 ok = True
@@ -732,7 +747,8 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if args.curve == "bn254" else "u32x8 Fr / u32x12 Fq Montgomery",
             "data": "synthetic",
-            "config": {"workload": f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof",
+            "config": {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if nbig else
+                                    f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
                        "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
                        "scheme": scheme,
                        "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else

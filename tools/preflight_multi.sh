@@ -11,7 +11,9 @@ for cfg in "--log-n 24 --curve bn254" "--log-n 20 --curve bn254" "--log-n 22 --c
     python bench.py --gpus $n $cfg --scheme reference2d --dry-run > /dev/null
   done
 done
-echo "== 2^28-gate BN254 (configs[4]) must be refused: the 8n domain does not exist"
+echo "== configs[4]: 2^28-gate BN254, n-domain part only"
+python bench.py --gpus 8 --log-n 28 --n-domain-only --dry-run
+echo "== 2^28-gate BN254 with the quotient domain must be refused: the 8n domain does not exist"
 if python bench.py --gpus 8 --log-n 28 --dry-run; then echo "unexpected: accepted"; exit 1; fi
 echo "== world_size 2 / 4 CPU tests of the multi-rank path (gloo)"
 python -m pytest tests/test_gloo_multirank.py -q -x
