@@ -63,7 +63,8 @@ template <int NL, int B> FP_HD AffL<NL, B> affl_neg(const AffL<NL, B>& q, const 
 
 // acc += q without the exceptional cases: returns false (acc untouched) when q has the x of acc
 // (P + P or P + (-P)), which the caller hands to the complete out-of-line path.  q must not be infinity.
-template <int NL, int B>
+// FUSED_Y3: Y3 = R*T - Y1*PPP under one Montgomery reduction (fl_dot2) instead of two products and a lazy subtraction.
+template <int NL, int B, bool FUSED_Y3 = false>
 __device__ __forceinline__ bool xyzzl_madd_fast(XyzzL<NL, B>& a, const AffL<NL, B>& q, const FLParams<NL, B>& P) {
     if (fl_all_zero(a.zz)) {
         a.x = q.x; a.y = q.y;
@@ -85,8 +86,16 @@ __device__ __forceinline__ bool xyzzl_madd_fast(XyzzL<NL, B>& a, const AffL<NL, 
     fl_norm(x3);
     FL<NL, B> t = fl_sub(qq, x3, P.c8);
     fl_norm(t);
-    FL<NL, B> y3 = fl_sub(fl_mul(r, t, P), fl_mul(a.y, ppp, P), P.c2);
-    fl_norm(y3);
+    FL<NL, B> y3;
+    if (FUSED_Y3) {
+        // R*T + (4p - Y1)*PPP  (Y1 < 3.3p; result < (5.2*9.1 + 4*1.1) p * p/R' + p < 1.4p: inside the Y < 3.3p invariant)
+        FL<NL, B> ny = fl_sub(fl_zero<NL, B>(), a.y, P.c4);
+        fl_norm(ny);
+        y3 = fl_dot2(r, t, ny, ppp, P);
+    } else {
+        y3 = fl_sub(fl_mul(r, t, P), fl_mul(a.y, ppp, P), P.c2);
+        fl_norm(y3);
+    }
     a.zz = fl_mul(a.zz, pp, P);
     a.zzz = fl_mul(a.zzz, ppp, P);
     a.x = x3;

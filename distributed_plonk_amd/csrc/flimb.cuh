@@ -140,6 +140,44 @@ template <int NL, int B> FP_HD FL<NL, B> fl_mul(const FL<NL, B>& x, const FL<NL,
     return r;
 }
 
+// (x0*y0 + x1*y1) / R' mod p with ONE Montgomery reduction (saves NL^2 + NL mads against two products).  All four operands
+// normalised (limbs < 2^B; the top limbs may be larger as long as every column — 2*NL products below 2^(2B) plus NL reduction
+// products — stays below 2^64: 27 * 2^58 for NL = 9, B = 29; 42 * 2^56 for NL = 14, B = 28).  Result normalised, < sum/R' + p.
+template <int NL, int B> FP_HD FL<NL, B> fl_dot2(const FL<NL, B>& x0, const FL<NL, B>& y0, const FL<NL, B>& x1, const FL<NL, B>& y1,
+                                                 const FLParams<NL, B>& P) {
+    constexpr uint32_t MASK = (1u << B) - 1;
+    uint64_t acc = 0;
+    uint32_t m[NL];
+    FL<NL, B> r;
+#pragma unroll
+    for (int k = 0; k < NL; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)x0.l[i] * y0.l[k - i]; FL_CHAIN(acc); }
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)x1.l[i] * y1.l[k - i]; FL_CHAIN(acc); }
+#pragma unroll
+        for (int i = 0; i < k; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
+        m[k] = ((uint32_t)acc * P.inv) & MASK;
+        { acc += (uint64_t)m[k] * P.p[0]; FL_CHAIN(acc); }
+        acc >>= B;
+        FL_CHAIN(acc);
+    }
+#pragma unroll
+    for (int k = NL; k < 2 * NL - 1; k++) {
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)x0.l[i] * y0.l[k - i]; FL_CHAIN(acc); }
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)x1.l[i] * y1.l[k - i]; FL_CHAIN(acc); }
+#pragma unroll
+        for (int i = k - NL + 1; i < NL; i++) { acc += (uint64_t)m[i] * P.p[k - i]; FL_CHAIN(acc); }
+        r.l[k - NL] = (uint32_t)acc & MASK;
+        acc >>= B;
+        FL_CHAIN(acc);
+    }
+    r.l[NL - 1] = (uint32_t)acc;
+    return r;
+}
+
 // Montgomery square: the cross products x_i*x_j (i != j) are taken once against the doubled limb.
 // x normalised (limbs < 2^B, top limb may be larger but 2*x_top must stay below 2^31).
 template <int NL, int B> FP_HD FL<NL, B> fl_sqr(const FL<NL, B>& x, const FLParams<NL, B>& P) {

@@ -450,7 +450,7 @@ __device__ __forceinline__ void store_std(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<
 // Hot kernel: lane i owns bucket order[i] (size-sorted).  Exceptional additions (same x) abort the
 // bucket, which is queued for msm_accumulate_redo_kernel — keeps calls, scratch and the doubling
 // formula out of this kernel.
-template <int NQ>
+template <int NQ, bool FUSED_Y3>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ order, uint64_t nbuckets, uint64_t nb, uint32_t Wm, uint64_t tab_stride,
@@ -476,7 +476,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
             AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
             if (affl_is_inf(q)) continue;
             if (e >> 31) q = affl_neg(q, P);
-            if (!xyzzl_madd_fast(acc, q, P)) { ok = false; break; }
+            if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
         }
     }
     if (ok) store8(buckets + b, acc);
@@ -829,6 +829,9 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+static int g_msm_fused_y3 = 1;      // option "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.cuh); 0 = two products
+void msm_set_fused_y3(int v) { g_msm_fused_y3 = v ? 1 : 0; }
+
 template <int NQ>
 static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
                      int window_bits, const MsmTable& tab, hipStream_t stream) {
@@ -948,8 +951,12 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
     hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, bin_cursor, order); }
     { ProfScope ps("msm_accumulate_kernel", stream);
-    hipLaunchKernelGGL(msm_accumulate_kernel<NQ>, dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                       nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
+    if (g_msm_fused_y3)
+        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, true>), dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
+                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve));
+    else
+        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, false>), dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
+                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_heavy", stream);
     hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, nb, Wm, tab_stride,
                        heavy, heavy + 1, hpart, fl_params<NQ>(curve));

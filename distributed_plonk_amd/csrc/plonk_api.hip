@@ -12,6 +12,7 @@
 void ntt_set_max_log_r(int v);
 void msm_set_slice_log(int v);
 void quotient_set_fuse(int v);
+void msm_set_fused_y3(int v);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -202,6 +203,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
+    if (!strcmp(key, "msm_fused_y3")) { msm_set_fused_y3((int)value); return PLONK_OK; }          // process-wide; default 1
     if (!strcmp(key, "quotient_fuse")) { quotient_set_fuse((int)value); return PLONK_OK; }        // process-wide; experiments, see quotient.hip
     if (!strcmp(key, "msm_slice_log")) { msm_set_slice_log((int)value); return PLONK_OK; }          // process-wide; MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);
