@@ -9,7 +9,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libplonk_hip.so")
+LIB_PATH = os.environ.get("PLONK_HIP_LIB") or os.path.join(_HERE, "lib", "libplonk_hip.so")      # PLONK_HIP_LIB: an alternative build (A/B experiments)
 
 PLONK_BN254, PLONK_BLS12_381 = 0, 1
 PLONK_BASES_XY, PLONK_BASES_ARK = 0, 1

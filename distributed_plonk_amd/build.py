@@ -21,6 +21,12 @@ HEADERS = ["fp.cuh", "fp29.cuh", "flimb.cuh", "ec.cuh", "ec_lazy.cuh", "constant
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
+# The NTT pass kernel and the scans unroll nests of fully unrolled 9x9-limb products; with the pinned accumulation chains of
+# fp29.cuh (one empty asm per mad) the default `#pragma unroll` budget is exceeded, the butterfly loops stay loops and the per-lane
+# element arrays land in SCRATCH memory (160 B per lane, measured 1.6-2.8x slower in round 1).  With the budget raised the pinned
+# kernel needs 111 VGPRs, no scratch, no spills: 18.4 -> 16.3 ms per 8n coset FFT (profiles/r02_ntt_pins_experiment.txt).
+UNROLL = ["-mllvm", "-pragma-unroll-threshold=131072", "-mllvm", "-unroll-threshold=131072"]
+UNIT_FLAGS = {"ntt_engine.hip": UNROLL, "poly_ops.hip": UNROLL}
 
 
 def source_hash() -> str:
@@ -35,6 +41,7 @@ def source_hash() -> str:
             h.update(fh.read())
     with open(os.path.join(HERE, "..", "include", "plonk_hip.h"), "rb") as fh:
         h.update(fh.read())
+    h.update(repr((FLAGS, sorted(UNIT_FLAGS.items()))).encode())       # the compile flags shape the kernels too
     return h.hexdigest()[:16]
 
 
@@ -47,7 +54,7 @@ def _compile(unit, force):
     obj = os.path.join(OBJDIR, unit.replace(".hip", ".o"))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    subprocess.check_call([HIPCC, *FLAGS, "-c", src, "-o", obj])
+    subprocess.check_call([HIPCC, *FLAGS, *UNIT_FLAGS.get(unit, []), "-c", src, "-o", obj])
     return obj, True
 
 

@@ -36,9 +36,10 @@ struct F29Params {
 #define F29_MASK 0x1fffffffu
 // Pins a column accumulator after every v_mad_u64_u32 so a column's products stay ONE chain: otherwise hipcc
 // reassociates them into parallel partial sums and joins them with 64-bit adds that cost as much as the mads
-// (229 -> 213 VALU instructions per product).  F29_NO_PINS (set by ntt_engine.hip) turns the pins off: the NTT pass
-// kernel runs at a 128-VGPR budget (1024 lanes per tile) and the pinned form spills there (measured: 7.9 -> 12.6-22 ms
-// per 2^27-element pass); the quotient and MSM kernels have register headroom and keep them.
+// (229 -> 213 VALU instructions per product).  Round 1 had to switch the pins off for the NTT pass kernel (F29_NO_PINS: "the
+// pinned form spills at 128 VGPRs, 7.9 -> 12.6-22 ms per pass"); round 2 found the cause — not register pressure but the unroll
+// budget: with one asm per mad the butterfly loops were no longer unrolled and the lane's element array went to scratch memory.
+// build.py raises the budget for that translation unit and the pins are on everywhere (111 VGPRs, no scratch, -11.8 %).
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(F29_NO_PINS)
 #define F29_CHAIN(acc) asm("" : "+v"(acc))
 #else

@@ -4,7 +4,6 @@
 #include <cstdlib>
 #include <cstring>
 
-#define F29_NO_PINS 1
 #include "constants.h"
 #include "ntt_kernels.cuh"
 #include "plonk_internal.hpp"
