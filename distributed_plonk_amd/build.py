@@ -21,12 +21,12 @@ HEADERS = ["fp.cuh", "fp29.cuh", "flimb.cuh", "ec.cuh", "ec_lazy.cuh", "constant
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
-# The NTT pass kernel and the scans unroll nests of fully unrolled 9x9-limb products; with the pinned accumulation chains of
+# The NTT pass kernel unrolls nests of fully unrolled 9x9-limb products; with the pinned accumulation chains of
 # fp29.cuh (one empty asm per mad) the default `#pragma unroll` budget is exceeded, the butterfly loops stay loops and the per-lane
 # element arrays land in SCRATCH memory (160 B per lane, measured 1.6-2.8x slower in round 1).  With the budget raised the pinned
 # kernel needs 111 VGPRs, no scratch, no spills: 18.4 -> 16.3 ms per 8n coset FFT (profiles/r02_ntt_pins_experiment.txt).
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=131072", "-mllvm", "-unroll-threshold=131072"]
-UNIT_FLAGS = {"ntt_engine.hip": UNROLL, "poly_ops.hip": UNROLL}
+UNIT_FLAGS = {"ntt_engine.hip": UNROLL, "quotient.hip": UNROLL}      # quotient kernel: 55.1 -> 52.1 ms;      # poly_ops.hip measured WORSE with it (perm product 5.1 -> 6.8 ms, division 1.5 -> 2.9 ms)
 
 
 def source_hash() -> str:
