@@ -46,7 +46,8 @@ def source_hash() -> str:
 
 
 def _newest_header():
-    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+    # this file counts as a dependency of every object: the compile flags live here
+    return max([os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.getmtime(os.path.abspath(__file__))])
 
 
 def _compile(unit, force):
