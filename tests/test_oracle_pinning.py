@@ -246,3 +246,30 @@ def test_bls12_381_group_law_published_points():
     sc = np.array([[1, 0, 0, 0], [2, 0, 0, 0]], dtype=np.uint64)
     xy, inf = O.jac_to_affine(1, O.msm(1, bases, sc))
     assert zcash_compressed((fq.from_mont(B.from_limbs(xy[:6])), fq.from_mont(B.from_limbs(xy[6:])))) == published[3]
+
+
+@pytest.mark.parametrize("name,cid,cv", CURVES)
+def test_expected_msm_helpers_match_a_direct_oracle_msm(name, cid, cv):
+    """oracle/checks.py (bench.py's verification leg and the full-size GPU tests rely on it): the aggregated-scalar shortcuts for the
+    two synthetic base distributions equal a direct oracle MSM over the explicitly constructed bases."""
+    from oracle import checks
+    q = cv.fq.limbs64
+    one = O.field_const(cid, 1, 1)[:q]
+    # tiled: P_i = T[i % u]
+    n, u = 1536, 256
+    sc = O.from_mont(cid, O.rand_fr(cid, 31, n))
+    bases = O.gen_bases(cid, 77, u, n)
+    a = O.jac_to_affine(cid, O.msm(cid, bases, sc, threads=2))
+    b = O.jac_to_affine(cid, checks.msm_expected_tiled(cid, 77, u, sc, threads=2))
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
+    # distinct: P_i = A[i % 4096] + B[i / 4096]
+    n = 4096 + 900
+    sc = O.from_mont(cid, O.rand_fr(cid, 32, n))
+    A, Bp = O.gen_bases(cid, 5, checks.NA, checks.NA), O.gen_bases(cid, 6, 2, 2)
+    bases = np.zeros((n, 2 * q), dtype=np.uint64)
+    for i in range(n):
+        s = O.jac_add(cid, np.concatenate([A[i % checks.NA], one]), np.concatenate([Bp[i // checks.NA], one]))
+        bases[i] = O.jac_to_affine(cid, s)[0]
+    a = O.jac_to_affine(cid, O.msm(cid, bases, sc, threads=2))
+    b = O.jac_to_affine(cid, checks.msm_expected_distinct(cid, 5, sc, threads=2))
+    assert a[1] == b[1] and np.array_equal(a[0], b[0])
