@@ -238,6 +238,10 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
         host_powers_const(h_row, host_pow2k(hq[q], L - w0, P), R1, P);             // (h_q^r_1)^a
         host_powers_const(h_fold, host_pow2k(hq[q], L, P), 4, P);                  // (h_q^M)^u
     }
+    struct Guard {                 // frees whatever has been allocated unless the set is handed over
+        NttTables::ShiftSet* s; F29* extra = nullptr; bool armed = true;
+        ~Guard() { if (armed) { (void)hipFree(s->planes); (void)hipFree(s->rowtabs); (void)hipFree(s->foldc); } (void)hipFree(extra); }
+    } guard{&set};
     HIP_TRY(hipMalloc((void**)&set.rowtabs, h_row.size() * sizeof(F29)));
     HIP_TRY(hipMalloc((void**)&set.foldc, h_fold.size() * sizeof(F29)));
     HIP_TRY(hipMemcpyAsync(set.rowtabs, h_row.data(), h_row.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
@@ -246,7 +250,7 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
     if (NP > 1) {
         if (hipMalloc((void**)&set.planes, set.bytes) != hipSuccess) {
             (void)hipGetLastError();
-            (void)hipFree(set.rowtabs); (void)hipFree(set.foldc);
+            set.planes = nullptr;
             return plonk_fail(PLONK_ERR_HIP, "coset classes: out of memory for %zu bytes of first-pass planes", set.bytes);
         }
         const size_t n_hi = (size_t)std::max<uint64_t>(1, r1 >> 10);
@@ -258,6 +262,7 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
         }
         F29* d_pw = nullptr;
         HIP_TRY(hipMalloc((void**)&d_pw, h_pw.size() * sizeof(F29)));
+        guard.extra = d_pw;
         HIP_TRY(hipMemcpyAsync(d_pw, h_pw.data(), h_pw.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
         for (uint64_t q = 0; q < B; q++) {
             const F29* lo = d_pw + q * (1024 + n_hi);
@@ -266,12 +271,9 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
         }
         hipError_t e = hipGetLastError();
         hipError_t e2 = hipStreamSynchronize(stream);
-        (void)hipFree(d_pw);
-        if (e != hipSuccess || e2 != hipSuccess) {
-            (void)hipFree(set.planes); (void)hipFree(set.rowtabs); (void)hipFree(set.foldc);
-            return plonk_fail(PLONK_ERR_HIP, "ntt_gen_shift_plane: %s", hipGetErrorString(e != hipSuccess ? e : e2));
-        }
+        if (e != hipSuccess || e2 != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "ntt_gen_shift_plane: %s", hipGetErrorString(e != hipSuccess ? e : e2));
     }
+    guard.armed = false;
     T.plane_bytes += set.bytes;
     auto ins = T.shift_sets.emplace(key, set);
     *out = &ins.first->second;
