@@ -253,6 +253,23 @@ def main():
 
     cworkers = workers
 
+    # The 13 commitments of a proof come in rounds (dispatcher2.rs:313-321 five wires, :352-358 the permutation product, :519-531
+    # five quotient parts, :690-697 two openings); the commitments of one round are independent and go through
+    # plonk_commit_many_dev as ONE Pippenger problem, split over the commit lanes.  PLONK_BENCH_COMMIT_BATCH=0: one MSM at a time.
+    commit_batch = os.environ.get("PLONK_BENCH_COMMIT_BATCH", "1") != "0"
+    use_lanes = min(n_commit_lanes, max(1, int(os.environ.get("PLONK_BENCH_COMMIT_USE_LANES", str(n_commit_lanes)))))
+    ROUNDS = (5, 1, 5, 2)
+
+    def commit_groups(count):
+        groups, at = [], 0
+        while at < count:
+            for r in ROUNDS:
+                r = min(r, count - at)
+                if r:
+                    groups.append((at, r))
+                    at += r
+        return groups
+
     def commits_start(count):
         src = sim_scalars.ptr if sim else buf_n[0][0].ptr
         parts = [None] * count
@@ -260,12 +277,20 @@ def main():
 
         def run(lane):
             try:
-                for i in range(lane, count, n_commit_lanes):
+                if commit_batch:
+                    for at, r in commit_groups(count):
+                        mine = list(range(at + lane, at + r, use_lanes))
+                        if mine:
+                            pts = cworkers[lane].commit_many_dev([(src, n_loc)] * len(mine))
+                            for j, i in enumerate(mine):
+                                parts[i] = pts[j]
+                    return
+                for i in range(lane, count, use_lanes):
                     parts[i] = cworkers[lane].commit_dev(src, n_loc)
             except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
                 errs.append(ex)
 
-        th = [threading.Thread(target=run, args=(lane,)) for lane in range(n_commit_lanes)]
+        th = [threading.Thread(target=run, args=(lane,)) for lane in range(use_lanes)]
         for t_ in th:
             t_.start()
         return th, parts, errs
@@ -379,30 +404,6 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = n / (dt / args.steps)
 
-    # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
-    other_scheme = None
-    if multi and not sim and nbig:
-        try:
-            other = step_ref2d if scheme == "classes" else step_classes
-            other()
-            full_sync()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                other()
-            full_sync()
-            dt2 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt2 = float(t.item())
-            other_scheme = {"scheme": "reference2d" if scheme == "classes" else "classes", "steps": 2, "ms_per_step": round(dt2 / 2 * 1e3, 3),
-                            "constraints_per_s": round(n / (dt2 / 2), 1),
-                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform (33 RCCL all-to-alls per step; the 25 "
-                                    "forward coset FFTs take zero-padded rows, plonk_fft1_dev_compact, unless --dense-coset); classes = rank-local "
-                                    "coset classes, 2 data-path collectives per step"}
-        except Exception as ex:
-            other_scheme = {"error": repr(ex)}
-
     # ---- roofline of the dominant kernel (HIP events recorded around every launch in the timed region)
     kernels = {}
     for name in ["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order",
@@ -466,6 +467,96 @@ def main():
                 "valu_issue": valu_entry(name, r["avg_ms"])}
 
     dominant = max(roof, key=lambda k: roof[k]["total_ms"]) if roof else None
+
+    # ---- the result line exists from here on: the headline is measured, everything below only ADDS fields to it.  N > 1 has never
+    # run on more than one real GPU (gpurun grants one), so the optional legs that follow run under a watchdog: should one of them
+    # hang in a collective, rank 0 still prints the headline (with `aborted_optional_leg` naming the leg) and every rank exits 0.
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "constraints/sec (proof-equivalent MSM+NTT hot path; BN254 PLONK)" if args.curve == "bn254"
+                      else "constraints/sec (proof-equivalent MSM+NTT hot path; BLS12-381 PLONK)",
+            "value": round(value, 1), "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if args.curve == "bn254" else "u32x8 Fr / u32x12 Fq Montgomery",
+            "data": "synthetic",
+            "config": {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if nbig else
+                                    f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
+                       "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
+                       "scheme": scheme,
+                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
+                                       ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}")) if world == 1
+                                      else (f"{world} ranks, scheme {scheme}: " +
+                                            ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
+                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs")) +
+                                            f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
+                       "coset_inputs": "n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else "dense 8n (plonk_ntt_dev / distributed 2-D transform)",
+                       "commit_batching": "plonk_commit_many_dev per prover round (5, 1, 5, 2), split over two contexts" if commit_batch else "one MSM per commitment",
+                       "rccl": rccl_info},
+            "roofline": roofline_entry(dominant) if dominant else None,
+            "roofline_other": [roofline_entry(k) for k in roof if k != dominant],
+            "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
+                        for k, v in sorted(kernels.items())},
+            "cpu_baseline": None, "other_scheme": None, "verified": None, "verification": None, "next_rows": None,
+        }
+    emitted = threading.Event()
+    emit_lock = threading.Lock()
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not emitted.is_set():
+                os.write(json_fd, (json.dumps(out) + "\n").encode())
+            emitted.set()
+
+    leg = {"name": None, "deadline": None}
+
+    def arm(name, seconds):
+        """Start (or, with name None, stop) the watchdog clock of one optional leg."""
+        leg["name"], leg["deadline"] = name, (time.monotonic() + seconds if name else None)
+
+    def watchdog():
+        while True:                                  # daemon thread: ends with the process
+            time.sleep(1.0)
+            dl = leg["deadline"]
+            if dl is not None and time.monotonic() > dl:
+                if rank == 0:
+                    out["aborted_optional_leg"] = {"leg": leg["name"], "note": "the leg exceeded its watchdog budget (a collective that never completed?); "
+                                                   "the headline above was measured before it started and is unaffected"}
+                emit()
+                os._exit(0)
+
+    if world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
+        threading.Thread(target=watchdog, daemon=True).start()
+    LEG_BUDGET_S = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
+
+    # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
+    other_scheme = None
+    if multi and not sim and nbig:
+        arm("other_scheme", LEG_BUDGET_S)
+        try:
+            other = step_ref2d if scheme == "classes" else step_classes
+            other()
+            full_sync()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                other()
+            full_sync()
+            dt2 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt2 = float(t.item())
+            other_scheme = {"scheme": "reference2d" if scheme == "classes" else "classes", "steps": 2, "ms_per_step": round(dt2 / 2 * 1e3, 3),
+                            "constraints_per_s": round(n / (dt2 / 2), 1),
+                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform (33 RCCL all-to-alls per step; the 25 "
+                                    "forward coset FFTs take zero-padded rows, plonk_fft1_dev_compact, unless --dense-coset); classes = rank-local "
+                                    "coset classes, 2 data-path collectives per step"}
+        except Exception as ex:
+            other_scheme = {"error": repr(ex)}
+        arm(None, 0)
+        if rank == 0:
+            out["other_scheme"] = other_scheme
+
 
     # ---- result checks, after and outside the timed region (rank 0, N == 1): the oracle as CHECKER of what was just timed
     verified, verification = None, None
@@ -532,6 +623,7 @@ def main():
         except Exception as ex:                     # a failed check must be visible, never fatal to the measurement
             verification["error"] = repr(ex)
             verified = False
+        out["verified"], out["verification"] = verified, verification
 
     # ---- next row, measured on its own, NOT part of `value`: quotient coset evaluations over 8n points
     next_rows = None
@@ -649,56 +741,61 @@ def main():
     # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
     class_row = None
     if (args.class_prover or multi) and not args.no_class_prover and not sim:
-        from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
-        if world == 1 and not dist.is_initialized():
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29653")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-        n_ck = ((n + 3 + 31) >> 5) << 5
-        ck = w.alloc(n_ck * 16 * q64)
-        w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
-        w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # the same key generated on every rank ...
-        klo, khi = key_shard_range(n_ck, rank, world)                                         # ... of which a rank KEEPS only its slice
-        for x in workers:                                                                     # (the SRS sharding of dispatcher2.rs:260-266)
-            x.init_dev(ck.ptr + klo * 16 * q64, khi - klo, n, m)
-        key = w.alloc(18 * n * 32)
-        circ = w.alloc(11 * n * 32)
-        w.synth_fr(0xC1AC, key.ptr, 18 * n)
-        w.synth_fr(0xC1AD, circ.ptr, 10 * n)
-        w.memset_dev(circ.ptr + 10 * n * 32, 0, n * 32)
-        idx = w.alloc(5 * n * 8).upload((np.arange(5 * n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(5 * n))
-        consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-        ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
-        bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-        if transport == "rccl" and multi:
-            def _boot(obj):
-                out_ = [None] * world
-                dist.all_gather_object(out_, obj)
-                return out_
-            comm = LibComm(w, bootstrap=_boot)
-        else:
-            comm = TorchComm(w, dev)
-        cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
-        cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
-        t_cls = None
-        for it in range(2):
-            full_sync()
-            t0 = time.perf_counter()
-            cp.prove_dev([circ.ptr + j * n * 32 for j in range(5)], circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl,
-                         lambda label, _: ch[label], check_degree=False)
-            full_sync()
-            t_cls = (time.perf_counter() - t0) * 1e3
-        if world > 1:
-            tt = torch.tensor([t_cls], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            t_cls = float(tt.item())
-        class_row = {"n": n, "ranks": world, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
-                     "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
-                     "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round)",
-                     "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
-        cp.close()
-        for b in (ck, key, circ, idx):
-            b.free()
+        arm("class_prover", 2 * LEG_BUDGET_S)
+        try:
+            from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
+            if world == 1 and not dist.is_initialized():
+                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+                os.environ.setdefault("MASTER_PORT", "29653")
+                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+            n_ck = ((n + 3 + 31) >> 5) << 5
+            ck = w.alloc(n_ck * 16 * q64)
+            w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
+            w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # the same key generated on every rank ...
+            klo, khi = key_shard_range(n_ck, rank, world)                                         # ... of which a rank KEEPS only its slice
+            for x in workers:                                                                     # (the SRS sharding of dispatcher2.rs:260-266)
+                x.init_dev(ck.ptr + klo * 16 * q64, khi - klo, n, m)
+            key = w.alloc(18 * n * 32)
+            circ = w.alloc(11 * n * 32)
+            w.synth_fr(0xC1AC, key.ptr, 18 * n)
+            w.synth_fr(0xC1AD, circ.ptr, 10 * n)
+            w.memset_dev(circ.ptr + 10 * n * 32, 0, n * 32)
+            idx = w.alloc(5 * n * 8).upload((np.arange(5 * n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(5 * n))
+            consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
+            ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
+            bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
+            if transport == "rccl" and multi:
+                def _boot(obj):
+                    out_ = [None] * world
+                    dist.all_gather_object(out_, obj)
+                    return out_
+                comm = LibComm(w, bootstrap=_boot)
+            else:
+                comm = TorchComm(w, dev)
+            cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
+            cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
+            t_cls = None
+            for it in range(2):
+                full_sync()
+                t0 = time.perf_counter()
+                cp.prove_dev([circ.ptr + j * n * 32 for j in range(5)], circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl,
+                             lambda label, _: ch[label], check_degree=False)
+                full_sync()
+                t_cls = (time.perf_counter() - t0) * 1e3
+            if world > 1:
+                tt = torch.tensor([t_cls], dtype=torch.float64, device=dev)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                t_cls = float(tt.item())
+            class_row = {"n": n, "ranks": world, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
+                         "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
+                         "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round)",
+                         "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
+            cp.close()
+            for b in (ck, key, circ, idx):
+                b.free()
+        except Exception as ex:        # every rank raises or none does (same sizes everywhere); the headline must survive either way
+            class_row = {"error": repr(ex)}
+        arm(None, 0)
 
     # ---- CPU baseline (oracle = C restatement of the reference's arkworks path), bounded sample.  The reference builds ark-poly
     # WITHOUT its "parallel" feature and ark-ec WITH it (Cargo.toml:31-34): its NTTs are single-threaded, its MSM runs its
@@ -740,35 +837,11 @@ def main():
                "host_cores_online": os.cpu_count()}
 
     if rank == 0:
-        out = {
-            "metric": "constraints/sec (proof-equivalent MSM+NTT hot path; BN254 PLONK)" if args.curve == "bn254"
-                      else "constraints/sec (proof-equivalent MSM+NTT hot path; BLS12-381 PLONK)",
-            "value": round(value, 1), "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if args.curve == "bn254" else "u32x8 Fr / u32x12 Fq Montgomery",
-            "data": "synthetic",
-            "config": {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if nbig else
-                                    f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
-                       "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
-                       "scheme": scheme,
-                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
-                                       ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}")) if world == 1
-                                      else (f"{world} ranks, scheme {scheme}: " +
-                                            ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
-                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs")) +
-                                            f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
-                       "coset_inputs": "n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else "dense 8n (plonk_ntt_dev / distributed 2-D transform)",
-                       "rccl": rccl_info},
-            "roofline": roofline_entry(dominant) if dominant else None,
-            "roofline_other": [roofline_entry(k) for k in roof if k != dominant],
-            "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
-                        for k, v in sorted(kernels.items())},
-            "cpu_baseline": cpu,
-            "other_scheme": other_scheme,
-            "verified": verified,
-            "verification": verification,
-            "next_rows": dict(next_rows or {}, class_prover=class_row) if class_row else next_rows,
-        }
+        out["cpu_baseline"] = cpu
+        out["next_rows"] = dict(next_rows or {}, class_prover=class_row) if class_row else next_rows
+    if world > 1:
+        emit()                                   # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
+        arm("teardown", 120.0)
     for pair in buf_n + buf_m:
         for b in pair:
             b.free()
@@ -806,7 +879,7 @@ def main():
                 except Exception as ex:             # the extra lines must never break the headline
                     other.append({"config": label, "error": repr(ex)})
             out["other_configs"] = other
-        os.write(json_fd, (json.dumps(out) + "\n").encode())
+    emit()
 
 
 if __name__ == "__main__":

@@ -78,6 +78,7 @@ SIGNATURES = {
     "plonk_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),
     "plonk_commit_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "plonk_commit_range_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "plonk_commit_many_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "plonk_fft1_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p]),
     "plonk_fft1_dev_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     "plonk_fft2_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),

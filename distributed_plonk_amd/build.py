@@ -16,13 +16,13 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 OUT = os.path.join(LIBDIR, "libplonk_hip.so")
 UNITS = ["plonk_api.hip", "ntt_engine.hip", "msm_engine.hip", "synth.hip", "quotient.hip", "poly_ops.hip", "comm_rccl.hip"]
-HEADERS = ["fp.cuh", "fp29.cuh", "flimb.cuh", "ec.cuh", "ec_lazy.cuh", "constants.h", "ntt_kernels.cuh", "plonk_internal.hpp",
+HEADERS = ["fp.hpp", "fp29.hpp", "flimb.hpp", "ec.hpp", "ec_lazy.hpp", "constants.h", "ntt_kernels.hpp", "plonk_internal.hpp",
            "../../include/plonk_hip.h"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Wno-pass-failed"]
 # The NTT pass kernel unrolls nests of fully unrolled 9x9-limb products; with the pinned accumulation chains of
-# fp29.cuh (one empty asm per mad) the default `#pragma unroll` budget is exceeded, the butterfly loops stay loops and the per-lane
+# fp29.hpp (one empty asm per mad) the default `#pragma unroll` budget is exceeded, the butterfly loops stay loops and the per-lane
 # element arrays land in SCRATCH memory (160 B per lane, measured 1.6-2.8x slower in round 1).  With the budget raised the pinned
 # kernel needs 111 VGPRs, no scratch, no spills: 18.4 -> 16.3 ms per 8n coset FFT (profiles/r02_ntt_pins_experiment.txt).
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=131072", "-mllvm", "-unroll-threshold=131072"]
@@ -37,7 +37,7 @@ def source_hash() -> str:
     bench.py refuses to quote them for a library built from different sources."""
     import hashlib
     h = hashlib.sha256()
-    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".cuh", ".h", ".hpp")))
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".hpp")))
     for f in names:
         h.update(f.encode())
         with open(os.path.join(CSRC, f), "rb") as fh:

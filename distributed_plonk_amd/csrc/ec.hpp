@@ -1,4 +1,4 @@
-// ec.cuh — G1 (y^2 = x^3 + b, a = 0) point arithmetic in extended Jacobian "XYZZ" coordinates
+// ec.hpp — G1 (y^2 = x^3 + b, a = 0) point arithmetic in extended Jacobian "XYZZ" coordinates
 // (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2), host + device.
 //
 // Contract to match: only the GROUP ELEMENT of ark-ec 0.3.0's VariableBaseMSM::multi_scalar_mul
@@ -9,7 +9,7 @@
 // exactly: infinity bases (dispatcher2.rs:1101), duplicated bases => P+P (dispatcher.rs:194-196),
 // P + (-P).
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 template <int N> struct AffPt { Fp<N> x, y; };              // infinity: x == y == 0 (not on the curve, b != 0)
 template <int N> struct XyzzPt { Fp<N> x, y, zz, zzz; };    // infinity: zz == 0

@@ -1,6 +1,6 @@
-// ec_lazy.cuh — XYZZ mixed addition on unsaturated limbs with lazy reduction (hot loop of the MSM
-// bucket accumulation).  Same group law and the same exceptional-case handling as ec.cuh; only the
-// field representation differs (flimb.cuh).
+// ec_lazy.hpp — XYZZ mixed addition on unsaturated limbs with lazy reduction (hot loop of the MSM
+// bucket accumulation).  Same group law and the same exceptional-case handling as ec.hpp; only the
+// field representation differs (flimb.hpp).
 //
 // Invariants of an accumulator (X, Y, ZZ, ZZZ): limbs normalised, values bounded by
 //     X < 5.2 p,  Y < 3.3 p,  ZZ < 2 p,  ZZZ < 2 p ;   infinity <=> every limb of ZZ is exactly 0.
@@ -12,7 +12,7 @@
 //     T  = Q + 8p - X3 < 9.1p
 //     Y3 = R*T + 2p - Y1*PPP < 3.3p             (each product < 1.3p)
 #pragma once
-#include "flimb.cuh"
+#include "flimb.hpp"
 
 template <int NL, int B> struct AffL { FL<NL, B> x, y; };
 template <int NL, int B> struct XyzzL { FL<NL, B> x, y, zz, zzz; };

@@ -1,19 +1,19 @@
-// flimb.cuh — generic "unsaturated limb" Montgomery arithmetic: NL limbs of B bits in 32-bit registers,
+// flimb.hpp — generic "unsaturated limb" Montgomery arithmetic: NL limbs of B bits in 32-bit registers,
 // R' = 2^(B*NL).  Used for the base-field work of the MSM bucket accumulation:
 //     BN254 Fq      : NL = 9,  B = 29  (R' = 2^261)
 //     BLS12-381 Fq  : NL = 14, B = 28  (R' = 2^392)
-// Rationale and measurements: see fp29.cuh (v_mad_u64_u32 issues as fast as an add-with-carry on
+// Rationale and measurements: see fp29.hpp (v_mad_u64_u32 issues as fast as an add-with-carry on
 // gfx950, so carry-free product scanning halves the instruction count of a saturated CIOS multiply).
 //
 // Values are residues kept LAZILY: limbs normalised (< 2^B, excess in the top limb) but the integer
 // may exceed p by a small bounded factor.  Every subtraction a - b is computed as a + K*p - b with a
 // pre-lifted constant K*p (each limb raised by 2^31, borrowed from the next) so no limb underflows.
-// The curve formulas in ec_lazy.cuh carry the bound bookkeeping; results are canonicalised before
+// The curve formulas in ec_lazy.hpp carry the bound bookkeeping; results are canonicalised before
 // they leave the kernel, so what reaches HBM is the same fully reduced R = 2^(32N) Montgomery form
 // the reference uses (utils.rs:27-43).
 #pragma once
 #include <stdint.h>
-#include "fp.cuh"
+#include "fp.hpp"
 
 template <int NL, int B> struct FL { uint32_t l[NL]; };
 

@@ -1,4 +1,4 @@
-// fp.cuh — Montgomery prime-field arithmetic on N x u32 little-endian limbs (gfx950 VALU).
+// fp.hpp — Montgomery prime-field arithmetic on N x u32 little-endian limbs (gfx950 VALU).
 //
 // Semantics to match: ark-ff 0.3.0 Fp256/Fp384 as used by the reference's hot path
 // (/root/reference/src/worker.rs:79,82-93,105-113,122,179): R = 2^(32N) (identical to ark's

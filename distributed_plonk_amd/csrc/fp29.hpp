@@ -1,4 +1,4 @@
-// fp29.cuh — 9 x 29-bit "unsaturated" limb arithmetic for the 254/255-bit scalar fields, gfx950 VALU.
+// fp29.hpp — 9 x 29-bit "unsaturated" limb arithmetic for the 254/255-bit scalar fields, gfx950 VALU.
 //
 // Why: measured on MI355X (profiles/r01_valu_microbench.txt) v_mad_u64_u32 issues at the same rate
 // (~4.5 clk per wave-instruction) as v_add_co/v_addc/v_lshl_add_u64, so a saturated 8x32 CIOS
@@ -20,7 +20,7 @@
 // stage, so up to ~20 stages run between canonicalisations.
 #pragma once
 #include <stdint.h>
-#include "fp.cuh"
+#include "fp.hpp"
 
 struct F29 { uint32_t l[9]; };
 

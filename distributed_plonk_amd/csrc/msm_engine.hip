@@ -24,14 +24,14 @@
 //
 // Zero scalars and digit 0 never touch a bucket (the reference filters zeros too); scalar 1 needs no
 // special case (digit 1 in window 0).  Infinity bases are skipped, P+P and P+(-P) are handled in
-// ec_lazy.cuh (device) / ec.cuh (host fold).  No MFMA: ~10 Fq Montgomery products per (point, window) dominate everything — the
+// ec_lazy.hpp (device) / ec.hpp (host fold).  No MFMA: ~10 Fq Montgomery products per (point, window) dominate everything — the
 // kernel is v_mad_u64_u32 bound; algorithmic HBM bytes are n*(sizeof(affine)+32).
 #include <algorithm>
 #include <cstring>
 
 #include "constants.h"
-#include "ec.cuh"
-#include "ec_lazy.cuh"
+#include "ec.hpp"
+#include "ec_lazy.hpp"
 #include "plonk_internal.hpp"
 
 template <int NQ> static const FpParams<NQ>& fq_params(int curve);
@@ -70,10 +70,15 @@ __device__ __forceinline__ uint32_t scalar_raw_digit(const uint32_t* s, int bit0
 // ---- 1: digits, planar: dig[w*n + i] = magnitude | sign << 31   (magnitude 0 = no contribution)
 // scalars_mont != 0: the scalars are Fr in Montgomery form and `into_repr` (commit_polynomial, worker.rs:117-123) is taken here,
 // on the fly, instead of in a separate pass that wrote 32 B per scalar to HBM and read them back.
-__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, int c, int W,
+// `len` <= n scalars are valid; positions len .. n-1 get zero digits (a batch of commitments pads its shorter polynomials).
+__global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t len, int c, int W,
                                                          uint32_t* __restrict__ dig, int scalars_mont, const FpParams<8> FR) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (i >= len) {
+        for (int w = 0; w < W; w++) dig[(uint64_t)w * n + i] = 0;
+        return;
+    }
     uint32_t s[8];
     const uint4* sp = reinterpret_cast<const uint4*>(scalars + 8 * i);
     const uint4 lo = sp[0], hi = sp[1];
@@ -394,7 +399,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t
 }
 
 // ---------------------------------------------------------------------------------------------- 4: bucket accumulation
-// Limb geometry of the lazy base-field arithmetic per curve (flimb.cuh)
+// Limb geometry of the lazy base-field arithmetic per curve (flimb.hpp)
 template <int NQ> struct LimbGeom;
 template <> struct LimbGeom<8> { static constexpr int NL = 9, B = 29; };      // BN254 Fq, R' = 2^261
 template <> struct LimbGeom<12> { static constexpr int NL = 14, B = 28; };    // BLS12-381 Fq, R' = 2^392
@@ -574,7 +579,7 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
 //   acc = sum_t t * E_t  and  S = sum_t E_t  (2K point additions, no scalar multiplications);
 //   the S values are the next level's entries.  With A_l = sum of level l's acc values and Sigma = the single
 //   entry left at the top:  V_w = Sigma + sum_l K^l * A_l   (host: a handful of doublings per window).
-// All in lazy limb arithmetic (ec_lazy.cuh); only the W*(L+1) results are converted to the standard form.
+// All in lazy limb arithmetic (ec_lazy.hpp); only the W*(L+1) results are converted to the standard form.
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ in, uint64_t n_in,
                                                                uint32_t K, uint64_t nch, uint64_t total,
@@ -829,24 +834,33 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int g_msm_fused_y3 = 1;      // option "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.cuh); 0 = two products
+static int g_msm_slice_log = 26;
+void msm_set_slice_log(int v) { g_msm_slice_log = v < 8 ? 8 : (v > 26 ? 26 : v); }
+static int g_msm_batch_max = 32;    // option "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
+void msm_set_batch_max(int v) { g_msm_batch_max = v < 1 ? 1 : (v > 64 ? 64 : v); }
+static int g_msm_fused_y3 = 1;      // option "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
 void msm_set_fused_y3(int v) { g_msm_fused_y3 = v ? 1 : 0; }
 
+// K >= 1 scalar vectors against the SAME bases in one set of launches (the independent commitments of a prover round): vector k
+// supplies the windows k*W1 .. (k+1)*W1 - 1 of one big (window, bucket) problem, so the sort, the bucket accumulation and the
+// reduction pyramid each run once over K times the work — no per-MSM launch gaps, wave tails or host round trips, which is what
+// bounds small MSMs (2^20 - 2^21 points per rank / per configs[1]).  lens[k] <= n valid scalars in vector k.
 template <int NQ>
-static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws,
-                     int window_bits, const MsmTable& tab, hipStream_t stream) {
+static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont,
+                     size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
     // fixed-base table: use it when its window beats the best per-window plan for THIS n (small sub-ranges do not)
     bool merged = false;
-    if (window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
+    if (K == 1 && window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
         double plain = 0;
         choose_window(n, bits, false, &plain);
         merged = window_cost(n, bits, tab.c, true) < plain;
     }
     const int c = merged ? tab.c : (window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits));
-    const int W = (bits + 1 + c - 1) / c;              // signed digits: one spare bit for the last carry
-    if (merged && W != tab.W) return plonk_fail(PLONK_ERR_STATE, "msm: table built for %d windows, plan has %d", tab.W, W);
+    const int W1 = (bits + 1 + c - 1) / c;             // windows per scalar vector (signed digits: one spare bit for the last carry)
+    if (merged && W1 != tab.W) return plonk_fail(PLONK_ERR_STATE, "msm: table built for %d windows, plan has %d", tab.W, W1);
+    const int W = K * W1;                              // windows of the whole batch
     const int cb = c - 1;                              // 2^(c-1) buckets per window
     const uint64_t nb = (uint64_t)1 << cb;
     const uint32_t Wm = merged ? (uint32_t)W : 1u;     // windows merged into one bucket set
@@ -925,8 +939,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
 
     const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
     { ProfScope ps("msm_digits_kernel", stream);
-    hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars, (uint64_t)n, c, W, dig, scalars_mont ? 1 : 0,
-                       fr_params(curve)); }
+    for (int k = 0; k < K; k++)
+        hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars[k], (uint64_t)n, (uint64_t)lens[k], c, W1,
+                           dig + (size_t)k * W1 * n, scalars_mont ? 1 : 0, fr_params(curve)); }
     { ProfScope ps("msm_sort", stream);
     hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_hist);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums);
@@ -993,8 +1008,10 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * nsplit);
     HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    const int Wk = merged ? 1 : W1;                    // bucket sets per scalar vector
+    for (int kk = 0; kk < K; kk++) {
     XyzzPt<NQ> total = xyzz_inf<NQ>();
-    for (int w = Wr - 1; w >= 0; w--) {
+    for (int w = (kk + 1) * Wk - 1; w >= kk * Wk; w--) {
         // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
         const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1) * nsplit;
         auto part = [&](int l) {                     // the partial sums of (level l, window w)
@@ -1013,35 +1030,63 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
             for (int k = 0; k < c; k++) total = xyzz_dbl(total, P);
         total = xyzz_add(total, v, P);
     }
-    *h_result = total;
+    h_result[kk] = total;
+    }
     return PLONK_OK;
 }
 
-static int g_msm_slice_log = 26;
-void msm_set_slice_log(int v) { g_msm_slice_log = v < 8 ? 8 : (v > 26 ? 26 : v); }
 
+// K scalar vectors (lens[k] valid scalars each) against bases[0 .. n): out = K Jacobian points.  Vectors are batched as far as the
+// 32-bit entry indices of the sort allow (n * W * K < 2^32), points beyond the slice size are sliced as before.
 template <int NQ>
-static int msm_run_t(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
-                     const MsmTable& tab, hipStream_t stream) {
+static int msm_run_t(int curve, const void* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont, size_t n, uint32_t* h_out_jac,
+                     MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
-    XyzzPt<NQ> total = xyzz_inf<NQ>();
+    std::vector<XyzzPt<NQ>> total((size_t)K, xyzz_inf<NQ>());
     const size_t SLICE = (size_t)1 << g_msm_slice_log;      // default 2^26 points per slice (workspace sizing); "msm_slice_log" option for tests
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
-        XyzzPt<NQ> part;
-        int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, d_scalars + 8 * s, scalars_mont, m, &part, ws, window_bits, tab, stream);
-        if (rc) return rc;
-        total = xyzz_add(total, part, P);
+        // windows per vector for this slice size -> how many vectors fit one launch set
+        const int bits = fr_params(curve).bits;
+        const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(m, bits);
+        const int W1 = (bits + 1 + c - 1) / c;
+        const uint64_t per = (uint64_t)m * W1;
+        int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)K, (0xfffffff0ull / per)));
+        if ((uint64_t)group * W1 > 65535) group = 65535 / W1;                    // grid.y of the per-window launches
+        group = std::min(group, g_msm_batch_max);
+        for (int k0 = 0; k0 < K; k0 += group) {
+            const int kn = std::min(group, K - k0);
+            std::vector<const uint32_t*> ptrs(kn);
+            std::vector<size_t> ln(kn);
+            for (int k = 0; k < kn; k++) {
+                ptrs[k] = d_scalars[k0 + k] + 8 * s;
+                ln[k] = lens[k0 + k] > s ? std::min(lens[k0 + k] - s, m) : 0;
+            }
+            std::vector<XyzzPt<NQ>> part(kn);
+            int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, ptrs.data(), ln.data(), kn, scalars_mont, m, part.data(), ws,
+                                   window_bits, tab, stream);
+            if (rc) return rc;
+            for (int k = 0; k < kn; k++) total[k0 + k] = xyzz_add(total[k0 + k], part[k], P);
+        }
     }
-    JacPt<NQ> j = jac_from_xyzz_normalised(total, P);
-    memcpy(h_out_jac, &j, sizeof j);
+    for (int k = 0; k < K; k++) {
+        JacPt<NQ> j = jac_from_xyzz_normalised(total[k], P);
+        memcpy((char*)h_out_jac + (size_t)k * sizeof j, &j, sizeof j);
+    }
     return PLONK_OK;
+}
+
+int msm_run_many(int curve, const void* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont, size_t n, uint32_t* h_out_jac,
+                 MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
+    if (K <= 0) return PLONK_OK;
+    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, lens, K, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
+    return msm_run_t<12>(curve, d_bases, d_scalars, lens, K, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
 }
 
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits,
             const MsmTable& tab, hipStream_t stream) {
-    if (curve == PLONK_BN254) return msm_run_t<8>(curve, d_bases, d_scalars, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
-    return msm_run_t<12>(curve, d_bases, d_scalars, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
+    const size_t len = n;
+    return msm_run_many(curve, d_bases, &d_scalars, &len, 1, scalars_mont, n, h_out_jac, ws, window_bits, tab, stream);
 }
 
 template <int NQ> static void jac_add_host_t(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out) {

@@ -1,11 +1,11 @@
-// ntt_engine.hip — host-side planner / launcher for the LDS-tiled NTT passes (ntt_kernels.cuh),
+// ntt_engine.hip — host-side planner / launcher for the LDS-tiled NTT passes (ntt_kernels.hpp),
 // twiddle-table setup, and the Fr matrix transpose (transpose.rs:413 equivalent).
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
 #include "constants.h"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hpp"
 #include "plonk_internal.hpp"
 
 static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
@@ -351,7 +351,7 @@ static bool swizzle_on() {
 }
 template <int LOG_R>
 static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    // the bank swizzle (ntt_kernels.cuh: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
+    // the bank swizzle (ntt_kernels.hpp: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
     if constexpr (LOG_R >= 7) {
         if (g_ntt_ept == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
     }

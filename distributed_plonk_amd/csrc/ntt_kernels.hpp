@@ -1,4 +1,4 @@
-// ntt_kernels.cuh — radix-2 NTT over Fr as LDS-tiled multi-pass kernels for gfx950.
+// ntt_kernels.hpp — radix-2 NTT over Fr as LDS-tiled multi-pass kernels for gfx950.
 //
 // What it replaces (reference /root/reference/src): ark-poly Radix2EvaluationDomain::{fft,ifft}_in_place
 // at worker.rs:82,84 (row NTT), :105,107 (column NTT), :398 and dispatcher.rs:594,632,667,
@@ -15,7 +15,7 @@
 //              natural-order position  m + j*(M/R_P)  (m = mixed-radix digit reversal of the run index).
 //   One workgroup owns a tile of T columns x R_p elements: HBM is touched in T*32-byte (coalesced
 //   256-bit-limb) pieces, exactly once per pass, in the reference's 8x32-bit Montgomery layout.
-//   Inside the kernel elements live as 9 x 29-bit limbs (fp29.cuh): butterflies run out of LDS
+//   Inside the kernel elements live as 9 x 29-bit limbs (fp29.hpp): butterflies run out of LDS
 //   (limb-major SoA: consecutive lanes hit consecutive banks), 8 elements per lane are held in
 //   VGPRs for up to three decimation-in-time stages between LDS exchanges; reduction is lazy
 //   (bounds grow by 2p per stage), only the final store canonicalises.  The bit-reversed input
@@ -24,8 +24,8 @@
 // Roofline: algorithmic bytes 2*32 B per element per transform; the kernels are
 // VALU (v_mad_u64_u32) bound, not HBM bound — see DESIGN.md.
 #pragma once
-#include "fp.cuh"
-#include "fp29.cuh"
+#include "fp.hpp"
+#include "fp29.hpp"
 
 typedef Fp<8> Fr;
 typedef FpParams<8> FrParams;

@@ -6,13 +6,14 @@
 #include <memory>
 
 #include "constants.h"
-#include "ec.cuh"
+#include "ec.hpp"
 #include "plonk_internal.hpp"
 
 void ntt_set_max_log_r(int v);
 void msm_set_slice_log(int v);
 void quotient_set_fuse(int v);
 void msm_set_fused_y3(int v);
+void msm_set_batch_max(int v);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -64,7 +65,7 @@ struct plonk_ctx {
     int device = 0, curve = 0;
     hipStream_t stream = nullptr;
     NttTables tables;
-    // SRS (State.bases), kept in the MSM's resident limb form (flimb.cuh)
+    // SRS (State.bases), kept in the MSM's resident limb form (flimb.hpp)
     void* d_bases = nullptr;                    // plane 0 of the fixed-base window table (msm_table) when one is built
     size_t n_bases = 0;
     MsmTable msm_table;
@@ -203,6 +204,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
+    if (!strcmp(key, "msm_batch_max")) { msm_set_batch_max((int)value); return PLONK_OK; }        // process-wide; vectors per launch set of commit_many
     if (!strcmp(key, "msm_fused_y3")) { msm_set_fused_y3((int)value); return PLONK_OK; }          // process-wide; default 1
     if (!strcmp(key, "quotient_fuse")) { quotient_set_fuse((int)value); return PLONK_OK; }        // process-wide; experiments, see quotient.hip
     if (!strcmp(key, "msm_slice_log")) { msm_set_slice_log((int)value); return PLONK_OK; }          // process-wide; MSMs above 2^value points are sliced (8..26)
@@ -352,6 +354,41 @@ extern "C" int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont,
     if (start > ctx->n_bases) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_range_dev: start %zu beyond the %zu resident bases", start, ctx->n_bases);
     const size_t n = std::min(count, ctx->n_bases - start);
     return msm_device(ctx, start, n, (const uint32_t*)d_coeffs_mont, out_jacobian, /*scalars_mont=*/true);
+}
+
+// k independent commit_polynomial calls against the same key in one set of launches (the commitments of a prover round:
+// dispatcher2.rs:313-321 five wires, :519-531 five quotient parts, :690-697 two openings)
+extern "C" int plonk_commit_many_dev(plonk_ctx* ctx, size_t k, const void* const* d_coeffs_mont, const size_t* n_coeffs, size_t start, uint64_t* out_jacobians) {
+    CHECK_CTX(ctx);
+    if (k == 0) return PLONK_OK;
+    if (!d_coeffs_mont || !n_coeffs || !out_jacobians) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_many_dev: null argument");
+    if (k > 4096) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_many_dev: %zu polynomials", k);
+    if (start > ctx->n_bases) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_many_dev: start %zu beyond the %zu resident bases", start, ctx->n_bases);
+    std::vector<const uint32_t*> ptrs(k);
+    std::vector<size_t> lens(k);
+    size_t n = 0;
+    for (size_t i = 0; i < k; i++) {
+        if (n_coeffs[i] && !d_coeffs_mont[i]) return plonk_fail(PLONK_ERR_ARG, "plonk_commit_many_dev: polynomial %zu is null", i);
+        lens[i] = std::min(n_coeffs[i], ctx->n_bases - start);
+        ptrs[i] = (const uint32_t*)d_coeffs_mont[i];
+        n = std::max(n, lens[i]);
+    }
+    const size_t jb = jac_bytes(ctx->curve);
+    if (n == 0) {                       // every polynomial empty: k zeros
+        for (size_t i = 0; i < k; i++) {
+            int rc = msm_device(ctx, 0, 0, nullptr, (uint64_t*)((char*)out_jacobians + i * jb));
+            if (rc) return rc;
+        }
+        return PLONK_OK;
+    }
+    for (size_t i = 0; i < k; i++)
+        if (!ptrs[i]) ptrs[i] = ptrs[0] ? ptrs[0] : (const uint32_t*)ctx->d_bases;      // never dereferenced: its length is 0
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    int rc = msm_run_many(ctx->curve, (const char*)ctx->d_bases + start * msm_limb_base_bytes(ctx->curve), ptrs.data(), lens.data(), (int)k, /*scalars_mont=*/true, n,
+                          (uint32_t*)out_jacobians, ctx->msm_ws, ctx->msm_window, ctx->msm_table, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
 }
 
 extern "C" int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, uint64_t* out_jacobian) {

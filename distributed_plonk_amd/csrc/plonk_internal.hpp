@@ -8,8 +8,8 @@
 #include <unordered_map>
 #include <vector>
 
-#include "fp.cuh"
-#include "fp29.cuh"
+#include "fp.hpp"
+#include "fp29.hpp"
 #include "../../include/plonk_hip.h"
 
 typedef Fp<8> Fr;
@@ -62,7 +62,7 @@ struct NttTables {
     F29Params fp29;
     int two_adicity = 0;
     int lt = 0;                       // two-level table split: 2^lt entries per level, 2*lt >= two_adicity
-    // all device tables hold constants c*2^261 mod p as 9 x 29-bit limbs (fp29.cuh)
+    // all device tables hold constants c*2^261 mod p as 9 x 29-bit limbs (fp29.hpp)
     F29* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
     F29* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
     F29* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
@@ -109,7 +109,7 @@ struct NttCall {
     ScaleSpec pro;            // applied to inputs (idx = position in array)
     ScaleSpec epi;            // applied to outputs (idx = natural-order output index)
     uint64_t q_offset = 0;    // added to q in both scale specs
-    int split_log = -1;       // output re-blocking for the all-to-all send buffer (see ntt_kernels.cuh)
+    int split_log = -1;       // output re-blocking for the all-to-all send buffer (see ntt_kernels.hpp)
     uint64_t split_blk = 0;
     NttLayout out_layout = NTT_CONTIGUOUS;
     // Class-decomposed evaluation of ONE coefficient vector on the cosets h_q * <w_M>, h_q = shift * w_(M*batch)^q, q < batch
@@ -156,6 +156,9 @@ struct MsmTable {
 // out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.
 int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, bool scalars_mont, size_t n, uint32_t* h_out_jac,
             MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream);
+// K scalar vectors (lens[k] valid entries, zero beyond) against the same bases[0 .. n): h_out_jac receives K Jacobian triples.
+int msm_run_many(int curve, const void* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont, size_t n,
+                 uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream);
 int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out);
 int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream);
 int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);

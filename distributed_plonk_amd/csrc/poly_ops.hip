@@ -11,7 +11,7 @@
 //           blinding (rand(k-1) * Z_H + poly)               dispatcher2.rs:311-312,347-348
 //
 // Arithmetic: HBM keeps the reference's R = 2^256 Montgomery form, fully reduced.  Products run on 9 x 29-bit limbs
-// (fp29.cuh, mont(a, b) = a*b/2^261).  rep(x) = x*2^261 is the form in which products of DATA close under mont();
+// (fp29.hpp, mont(a, b) = a*b/2^261).  rep(x) = x*2^261 is the form in which products of DATA close under mont();
 // an R-form datum is rep(x * 2^-5) and the stray powers of two cancel where noted.  Every value stored is
 // canonical, so results are bit-identical to ark-ff's.
 //
@@ -24,7 +24,7 @@
 #include <vector>
 
 #include "constants.h"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hpp"
 #include "plonk_internal.hpp"
 
 #define PO_LANES 256

@@ -5,7 +5,7 @@
 // What it replaces: the serial loop of /root/reference/src/dispatcher2.rs:435-504 (gate equation :459-477,
 // permutation argument :479-495, L1 term :497-503, 1/Z_H factor :372-379).  Streaming kernel: 26 loads + 2 table
 // loads and one store of 32 B per point; 52 limb products + 8 squarings but only 50 Montgomery reductions: the selector sums and
-// the final combination are three-term dot products with one reduction each (fp29.cuh: f29_dot<3>).
+// the final combination are three-term dot products with one reduction each (fp29.hpp: f29_dot<3>).
 //
 // Representation bookkeeping (mont(a, b) = a*b/2^261; inputs arrive in the reference's R = 2^256 Montgomery form, the kernel's
 // radix is R' = 2^261).  Default kernel (quotient_evals_kernel): NOTHING is lifted.  A product of two R-form values comes out as
@@ -21,7 +21,7 @@
 #include <cstring>
 
 #include "constants.h"
-#include "ntt_kernels.cuh"
+#include "ntt_kernels.hpp"
 #include "plonk_internal.hpp"
 
 struct QuotParams {

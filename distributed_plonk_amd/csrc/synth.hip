@@ -4,7 +4,7 @@
 //   * seeded synthetic inputs (the reference draws from thread_rng: dispatcher.rs:187-200):
 //     uniform Fr, and SRS-like G1 bases (k_j*G tiled, or pairwise-distinct sums A_i + B_j)
 #include "constants.h"
-#include "ec.cuh"
+#include "ec.hpp"
 #include "plonk_internal.hpp"
 
 template <int N> static const FpParams<N>& field_params(int curve, int field);

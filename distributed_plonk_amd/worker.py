@@ -160,6 +160,18 @@ class PlonkWorker:
         check(self.lib.plonk_commit_dev(self.ctx, d_coeffs_ptr, n_coeffs, _ptr(out)))
         return out
 
+    def commit_many_dev(self, items, start: int = 0) -> np.ndarray:
+        """[(device pointer at coefficient `start`, count), ...] -> (k, 3*Q) Jacobian points: k commitments against bases
+        [start, start + count) in one set of launches (plonk_commit_many_dev)."""
+        k = len(items)
+        out = np.empty((k, 3 * self.q64), dtype=np.uint64)
+        if k == 0:
+            return out
+        ptrs = (C.c_void_p * k)(*[int(p) for p, _ in items])
+        lens = (C.c_size_t * k)(*[int(n) for _, n in items])
+        check(self.lib.plonk_commit_many_dev(self.ctx, k, ptrs, lens, start, _ptr(out)))
+        return out
+
     def commit_range_dev(self, d_coeffs_ptr: int, start: int, count: int) -> np.ndarray:
         """One shard of commit_polynomial: coefficients [start, start+count) against bases [start, start+count)."""
         out = np.empty(3 * self.q64, dtype=np.uint64)

@@ -102,6 +102,7 @@ extern "C" {
     pub fn plonk_msm_dev(ctx: *mut plonk_ctx, start: usize, end: usize, d_scalars: *const c_void, out_jacobian: *mut u64) -> c_int;
     pub fn plonk_commit_dev(ctx: *mut plonk_ctx, d_coeffs_mont: *const c_void, n_coeffs: usize, out_jacobian: *mut u64) -> c_int;
     pub fn plonk_commit_range_dev(ctx: *mut plonk_ctx, d_coeffs_mont: *const c_void, start: usize, count: usize, out_jacobian: *mut u64) -> c_int; // dispatcher2.rs:870-890
+    pub fn plonk_commit_many_dev(ctx: *mut plonk_ctx, k: usize, d_coeffs_mont: *const *const c_void, n_coeffs: *const usize, start: usize, out_jacobians: *mut u64) -> c_int; // the commitments of a round in one launch set
     pub fn plonk_fft1_dev(ctx: *mut plonk_ctx, id: u64, d_rows: *mut c_void) -> c_int;
     pub fn plonk_fft1_dev_compact(ctx: *mut plonk_ctx, id: u64, d_rows: *const c_void, row_len: usize) -> c_int; // dispatcher2.rs:746,754: zero-padded rows
     pub fn plonk_fft2_dev(ctx: *mut plonk_ctx, id: u64, d_out: *mut c_void, layout: c_int) -> c_int;

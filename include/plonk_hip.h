@@ -151,6 +151,13 @@ int plonk_commit_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t n_coeffs,
  * at coefficient `start`; out = sum_{i < count} into_repr(coeff[start + i]) * bases[start + i].  The shards' points add up to the
  * commitment. */
 int plonk_commit_range_dev(plonk_ctx* ctx, const void* d_coeffs_mont, size_t start, size_t count, uint64_t* out_jacobian);
+/* k commit_polynomial calls against the same key in ONE set of kernel launches — the independent commitments of a prover round
+ * (dispatcher2.rs:313-321: five wire polynomials; :519-531: five quotient parts; :690-697: two opening proofs).  Polynomial i has
+ * n_coeffs[i] Montgomery coefficients at d_coeffs_mont[i] (point at coefficient `start`), paired with bases [start, start + n_coeffs[i]);
+ * out_jacobians receives k Jacobian triples.  Same points as k calls of plonk_commit_range_dev(.., start, n_coeffs[i], ..): the scalar
+ * vectors become extra windows of one Pippenger problem (one sort, one bucket accumulation, one reduction), which removes the
+ * per-MSM launch gaps, wave tails and host round trips that bound small MSMs. */
+int plonk_commit_many_dev(plonk_ctx* ctx, size_t k, const void* const* d_coeffs_mont, const size_t* n_coeffs, size_t start, uint64_t* out_jacobians);
 /* All local rows at once, row-major [num_rows][c] in HBM (replaces num_rows fft1 calls).  d_rows is CONSUMED: the buffer must stay
  * alive until plonk_fft2_prepare returns, which runs the row pass with d_rows as its inter-pass workspace (c > 2^9) and leaves
  * garbage in it — like plonk_ntt_dev's d_in. */
@@ -253,7 +260,9 @@ int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_
 int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                          uint64_t* out, size_t n);
 /* tuning knobs: key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 9), "msm_slice_log" (8..26: MSMs above 2^value points are
- * computed slice by slice and the partial points added; default 26 — process-wide, for tests of the slicing path). */
+ * computed slice by slice and the partial points added; default 26 — process-wide, for tests of the slicing path), "msm_batch_max"
+ * (scalar vectors per launch set of plonk_commit_many_dev, default 32; 1 = one MSM at a time), "msm_fused_y3", "quotient_fuse"
+ * (kernel-formulation experiments). */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
 /* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP
  * events on the context's stream (milliseconds). */

@@ -1,4 +1,4 @@
-"""Device field arithmetic (fp.cuh) vs the oracle: bit-exact limbs."""
+"""Device field arithmetic (fp.hpp) vs the oracle: bit-exact limbs."""
 import numpy as np
 import pytest
 
