@@ -313,7 +313,10 @@ def main():
                 acc[i] = pt if acc[i] is None else w.g1_add(acc[i], pt)
         return acc[-1]
 
+    phase = {"ntt": 0.0, "msm": 0.0}              # host-clock split of the step at its one internal sync point (this rank)
+
     def step():
+        t_in = time.perf_counter()
         for i in range(N_NTT_SMALL):
             ntt(i % n_lanes, buf_n[i % n_lanes], n, True, False, False)
         for i in range(nbig - 1):
@@ -324,7 +327,11 @@ def main():
             x.sync()                              # the commitments read lane-0 buffers from both contexts
         # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
         #  distorting the per-launch NTT timings the roofline is computed from)
-        return commits_finish(commits_start(N_MSM))
+        t_mid = time.perf_counter()
+        res = commits_finish(commits_start(N_MSM))
+        phase["ntt"] += t_mid - t_in
+        phase["msm"] += time.perf_counter() - t_mid
+        return res
 
     # ---- N > 1, scheme "classes": the step with the coset-class decomposition.  Every rank holds the coefficient
     # vectors (the size-n iNTTs that produce them run on every rank: 2.6 ms each, cheaper than gathering them), evaluates all 25
@@ -347,6 +354,7 @@ def main():
         w.synth_fr(0x5EC7, cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
 
     def step_classes():
+        t_in = time.perf_counter()
         c = cls
         for _ in range(N_NTT_SMALL):
             w.ntt_dev(c["bn"][0].ptr, c["bn"][1].ptr, n, True, False)
@@ -368,7 +376,11 @@ def main():
                 torch_comm.all_gather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
         for x in workers:
             x.sync()
-        return commits_finish(commits_start(N_MSM))
+        t_mid = time.perf_counter()
+        res = commits_finish(commits_start(N_MSM))
+        phase["ntt"] += t_mid - t_in
+        phase["msm"] += time.perf_counter() - t_mid
+        return res
 
     torch_comm = None
     if multi and transport == "torch" and not sim:
@@ -391,11 +403,14 @@ def main():
     full_sync()
     w.profile_reset()
     w.profile_enable(True)
+    phase["ntt"] = phase["msm"] = 0.0
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     full_sync()
     dt = time.perf_counter() - t0
+    phases_ms = {"transforms": round(phase["ntt"] / args.steps * 1e3, 3), "commitments": round(phase["msm"] / args.steps * 1e3, 3),
+                 "note": "rank 0's host clock, split at the step's internal sync: the 33 transforms (with their exchanges), then the 13 commitments"}
     w.profile_enable(False)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -477,7 +492,7 @@ def main():
             "metric": "constraints/sec (proof-equivalent MSM+NTT hot path; BN254 PLONK)" if args.curve == "bn254"
                       else "constraints/sec (proof-equivalent MSM+NTT hot path; BLS12-381 PLONK)",
             "value": round(value, 1), "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 3), "phases_ms": phases_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if args.curve == "bn254" else "u32x8 Fr / u32x12 Fq Montgomery",
             "data": "synthetic",
             "config": {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if nbig else
