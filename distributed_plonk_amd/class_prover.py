@@ -201,17 +201,29 @@ class ClassProver(Prover):
                 shards.append((ptr + lo * 32, lo - klo, hi - lo))
         parts = [None] * len(shards)
         lanes = [self.w] + ([self.commit_helper] if self.commit_helper is not None and len(shards) > 1 else [])
+
+        def commit_shards(worker, idx):
+            """The shards idx of the round on one context: those that start at the same key index go through plonk_commit_many_dev as
+            ONE Pippenger problem (at 2^21 points per rank the fixed costs of an MSM exceed its bucket accumulation)."""
+            by_start = {}
+            for i in idx:
+                by_start.setdefault(shards[i][1], []).append(i)
+            for start, group in by_start.items():
+                if len(group) == 1:
+                    parts[group[0]] = worker.commit_range_dev(*shards[group[0]])
+                else:
+                    for i, j in zip(group, worker.commit_many_dev([(shards[i][0], shards[i][2]) for i in group], start=start)):
+                        parts[i] = j
+
         if len(lanes) == 1:
-            for i, sh in enumerate(shards):
-                parts[i] = self.w.commit_range_dev(*sh)
+            commit_shards(self.w, range(len(shards)))
         else:
             self.w.sync()
             errs = []
 
             def run(lane):
                 try:
-                    for i in range(lane, len(shards), 2):
-                        parts[i] = lanes[lane].commit_range_dev(*shards[i])
+                    commit_shards(lanes[lane], range(lane, len(shards), 2))
                 except BaseException as ex:     # noqa: BLE001 - re-raised below
                     errs.append(ex)
 

@@ -167,9 +167,13 @@ class Prover:
         return self.w.g1_to_affine(self.w.commit_dev(d_poly, length))
 
     def _commit_many(self, items):
-        """Independent commitments [(device pointer, length), ...] -> affine points, in order."""
-        if self.commit_helper is None or len(items) < 2:
+        """The independent commitments of a round [(device pointer, length), ...] -> affine points, in order: ONE Pippenger problem
+        per context (plonk_commit_many_dev: the polynomials become extra windows of the same sort / accumulation / reduction),
+        the round split over two contexts when a commit_helper is set."""
+        if len(items) < 2:
             return [self._commit(ptr, ln) for ptr, ln in items]
+        if self.commit_helper is None:
+            return [self.w.g1_to_affine(j) for j in self.w.commit_many_dev(items)]
         import threading
         lanes = [self.w, self.commit_helper]
         self.w.sync()                                   # the helper's stream reads what this context's stream wrote
@@ -178,8 +182,9 @@ class Prover:
 
         def run(lane):
             try:
-                for i in range(lane, len(items), 2):
-                    out[i] = lanes[lane].commit_dev(*items[i])
+                mine = list(range(lane, len(items), 2))
+                for i, j in zip(mine, lanes[lane].commit_many_dev([items[i] for i in mine])):
+                    out[i] = j
             except BaseException as ex:     # noqa: BLE001 - re-raised below
                 errs.append(ex)
 

@@ -194,6 +194,10 @@ class CpuWorker:
     def commit_dev(self, d_coeffs, n_coeffs):
         return self.commit_range_dev(d_coeffs, 0, n_coeffs)
 
+    def commit_many_dev(self, items, start=0):
+        """PlonkWorker.commit_many_dev: the same points as one commit_range_dev per polynomial."""
+        return np.stack([self.commit_range_dev(ptr, start, count) for ptr, count in items]) if items else np.empty((0, 0), dtype=np.uint64)
+
     def g1_add(self, a, b):
         return O.jac_add(self.curve, a, b)
 
