@@ -295,7 +295,7 @@ def main():
             t_.start()
         return th, parts, errs
 
-    def commits_finish(handle):
+    def commits_finish(handle, all_parts=False):
         th, parts, errs = handle
         count = len(parts)
         for t_ in th:
@@ -303,7 +303,7 @@ def main():
         if errs:
             raise errs[0]
         if not multi or sim:
-            return parts[-1]
+            return parts if all_parts else parts[-1]
         flat = np.concatenate(parts)                                         # one collective for all partial points
         gathered = list(w.comm_allgather_host(flat, world)) if transport == "rccl" else gather_points(flat, None, dev)
         acc = [None] * count
@@ -583,14 +583,18 @@ def main():
             f_ = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
             # (1) one commitment of the timed configuration (same bases, same scalars, same two-lane code path) against the exact
             #     expected point from small oracle MSMs of aggregated scalars (oracle/checks.py)
+            #     — a whole round of five, so that both contexts run a BATCHED problem (three and two scalar vectors) at full size
             src = buf_n[0][0]
-            got = commits_finish(commits_start(2))
+            got5 = commits_finish(commits_start(5), all_parts=True)
             sc = O.from_mont(cid, src.download((n, 4)))
             want = (checks.msm_expected_distinct(cid, 0x5EED, sc) if args.bases == "distinct"
                     else checks.msm_expected_tiled(cid, 0x5EED, min(n, 1 << 11), sc))
-            g_, gi = w.g1_to_affine(got)
             e_, ei = O.jac_to_affine(cid, want)
-            verification["commit_vs_oracle_exact"] = bool(gi == ei and np.array_equal(g_, e_))
+            ok = True
+            for got in got5:
+                g_, gi = w.g1_to_affine(got)
+                ok &= bool(gi == ei and np.array_equal(g_, e_))
+            verification["commit_vs_oracle_exact"] = ok
             del sc
             # (2) one 8n coset FFT as timed: sampled outputs against Horner evaluations by an unrelated kernel (plonk_poly_eval_dev,
             #     itself oracle-checked in tests/), then the coset iFFT must return the zero-padded coefficients everywhere

@@ -129,3 +129,30 @@ def test_commit_many_argument_errors(gpu_workers):
         assert w.g1_to_affine(zero[i])[1]
     d.free()
     d_b.free()
+
+
+@pytest.mark.parametrize("curve,cid,log_n", [("bn254", 0, 24), ("bls12_381", 1, 22)])
+def test_commit_many_full_size_exact(gpu_workers, oracle, curve, cid, log_n):
+    """BASELINE's sizes, three scalar vectors of ragged length in one launch set (45 / 48 windows: the n * W * K < 2^32 bound of the sort's
+    entry indices is within a factor of six), pairwise-distinct bases: every point against the EXACT expected point
+    (oracle/checks.py: two 4096-point oracle MSMs of aggregated scalars; the tail beyond a shorter vector's length counts as zero)."""
+    from oracle import checks
+    w = gpu_workers(curve)
+    n, q = 1 << log_n, w.q64
+    d_b = _setup(w, n, seed=0x5EED)
+    lens = [n, n - 12345, n // 2 + 1]
+    polys = []
+    for i, ln in enumerate(lens):
+        d = w.alloc(n * 32)
+        w.synth_fr(0xD15 + i, d.ptr, n)
+        polys.append(d)
+    got = w.commit_many_dev([(d.ptr, ln) for d, ln in zip(polys, lens)])
+    for i, (d, ln) in enumerate(zip(polys, lens)):
+        sc = oracle.from_mont(cid, d.download((n, 4)))
+        sc[ln:] = 0
+        e, ei = oracle.jac_to_affine(cid, checks.msm_expected_distinct(cid, 0x5EED, sc))
+        g, gi = w.g1_to_affine(got[i])
+        assert gi == ei and np.array_equal(g, e), f"polynomial {i}"
+    for d in polys:
+        d.free()
+    d_b.free()
