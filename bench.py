@@ -120,6 +120,46 @@ def plan(args, S):
             "problems": problems, "ok": not problems}
 
 
+class ResultLine:
+    """The one JSON line of a run and the watchdog that protects it.  The line exists (`out`) as soon as the headline is measured;
+    the optional legs that follow only add fields.  With the watchdog started, a leg that exceeds the budget it was armed with — a
+    collective that never completes on an N > 1 run — costs that leg, not the line: rank 0 prints what it has, with
+    `aborted_optional_leg` naming the leg, and every rank leaves with exit code 0 (os._exit: the hung thread cannot be joined)."""
+
+    def __init__(self, fd, rank, out):
+        import threading
+        self.fd, self.rank, self.out = fd, rank, out
+        self._emitted = threading.Event()
+        self._lock = threading.Lock()
+        self._leg = (None, None)                 # (name, deadline on time.monotonic())
+
+    def emit(self):
+        with self._lock:
+            if self.rank == 0 and not self._emitted.is_set():
+                os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+            self._emitted.set()
+
+    def arm(self, name, seconds):
+        """Start (or, with name None, stop) the watchdog clock of one optional leg."""
+        self._leg = (name, time.monotonic() + seconds) if name else (None, None)
+
+    def start_watchdog(self, poll_s=1.0):
+        import threading
+
+        def run():
+            while True:                              # daemon thread: ends with the process
+                time.sleep(poll_s)
+                name, deadline = self._leg
+                if deadline is not None and time.monotonic() > deadline:
+                    if self.rank == 0:
+                        self.out["aborted_optional_leg"] = {"leg": name, "note": "the leg exceeded its watchdog budget (a collective that never "
+                                                            "completed?); the headline above was measured before it started and is unaffected"}
+                    self.emit()
+                    os._exit(0)
+
+        threading.Thread(target=run, daemon=True).start()
+
+
 def main():
     args = parse()
     if args.dry_run:
@@ -514,34 +554,11 @@ def main():
                         for k, v in sorted(kernels.items())},
             "cpu_baseline": None, "other_scheme": None, "verified": None, "verification": None, "next_rows": None,
         }
-    emitted = threading.Event()
-    emit_lock = threading.Lock()
-
-    def emit():
-        with emit_lock:
-            if rank == 0 and not emitted.is_set():
-                os.write(json_fd, (json.dumps(out) + "\n").encode())
-            emitted.set()
-
-    leg = {"name": None, "deadline": None}
-
-    def arm(name, seconds):
-        """Start (or, with name None, stop) the watchdog clock of one optional leg."""
-        leg["name"], leg["deadline"] = name, (time.monotonic() + seconds if name else None)
-
-    def watchdog():
-        while True:                                  # daemon thread: ends with the process
-            time.sleep(1.0)
-            dl = leg["deadline"]
-            if dl is not None and time.monotonic() > dl:
-                if rank == 0:
-                    out["aborted_optional_leg"] = {"leg": leg["name"], "note": "the leg exceeded its watchdog budget (a collective that never completed?); "
-                                                   "the headline above was measured before it started and is unaffected"}
-                emit()
-                os._exit(0)
+    guard = ResultLine(json_fd, rank, out)
+    emit, arm = guard.emit, guard.arm
 
     if world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
-        threading.Thread(target=watchdog, daemon=True).start()
+        guard.start_watchdog()
     LEG_BUDGET_S = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
 
     # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)

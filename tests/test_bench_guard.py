@@ -1,0 +1,61 @@
+"""bench.py's result line must survive an optional leg that never returns (an N > 1 collective that hangs): the watchdog prints
+the line that exists by then and ends the process with exit code 0.  CPU only: the guard is exercised in a subprocess."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+HUNG_LEG = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+import bench
+g = bench.ResultLine(1, {rank}, {{"value": 42.0}} if {rank} == 0 else None)
+g.start_watchdog(poll_s=0.05)
+g.arm("class_prover", 0.3)
+time.sleep(120)                 # the leg that never comes back
+print("NOT REACHED")
+"""
+
+FINISHED_LEG = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+import bench
+out = {{"value": 42.0}}
+g = bench.ResultLine(1, 0, out)
+g.start_watchdog(poll_s=0.05)
+g.arm("other_scheme", 5.0)
+out["other_scheme"] = {{"ms_per_step": 1.0}}
+g.arm(None, 0)
+time.sleep(0.3)                 # a disarmed watchdog stays quiet
+g.emit()
+g.emit()                        # only one line, ever
+"""
+
+
+def _run(src, **kw):
+    return subprocess.run([sys.executable, "-c", src.format(root=ROOT, **kw)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=60)
+
+
+def test_hung_leg_costs_the_leg_not_the_line():
+    r = _run(HUNG_LEG, rank=0)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["value"] == 42.0 and d["aborted_optional_leg"]["leg"] == "class_prover"
+
+
+def test_other_ranks_leave_quietly():
+    r = _run(HUNG_LEG, rank=3)
+    assert r.returncode == 0 and r.stdout.decode().strip() == ""
+
+
+def test_finished_leg_prints_one_complete_line():
+    r = _run(FINISHED_LEG)
+    assert r.returncode == 0, r.stderr.decode()
+    lines = r.stdout.decode().strip().splitlines()
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert "aborted_optional_leg" not in d and d["other_scheme"]["ms_per_step"] == 1.0
