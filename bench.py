@@ -318,8 +318,10 @@ def main():
         def run(lane):
             try:
                 if commit_batch:
-                    for at, r in commit_groups(count):
-                        mine = list(range(at + lane, at + r, use_lanes))
+                    for gi, (at, r) in enumerate(commit_groups(count)):
+                        # the odd polynomial of a round goes to another context every round (5 -> 3 + 2, then 1 -> 0 + 1, 5 -> 2 + 3, ...):
+                        # 7 + 6 commitments per step instead of 8 + 5, so neither context runs a long tail alone
+                        mine = list(range(at + (lane + gi) % use_lanes, at + r, use_lanes))
                         if mine:
                             pts = cworkers[lane].commit_many_dev([(src, n_loc)] * len(mine))
                             for j, i in enumerate(mine):
