@@ -126,6 +126,48 @@ class Dispatcher {
         return inf != 0;
     }
 
+    // The commitments of ONE prover round — independent polynomials against the same key (dispatcher2.rs:313-321 five wires, :519-531
+    // five quotient parts, :690-697 two openings) — where the reference loops commit_polynomial: every worker takes its key range
+    // [lo, hi) (dispatcher2.rs:875-878) of ALL polynomials through plonk_commit_many_dev (one Pippenger problem per worker), the
+    // partial points are added per polynomial (:887-890).  polys[k]: lens[k] Montgomery coefficients on the host.
+    // Returns the infinity flags; xys[k] = affine x||y.
+    std::vector<bool> commit_round(const std::vector<const uint64_t*>& polys, const std::vector<size_t>& lens, std::vector<std::vector<uint64_t>>* xys) {
+        const size_t K = polys.size(), S = workers_.size(), J = 3 * fq_limbs64(curve_);
+        std::vector<std::vector<uint64_t>> acc(K);
+        const std::vector<plonk_msm_workload> wl = make_msm_workloads(n_bases_, S);
+        for (size_t s = 0; s < S; s++) {
+            plonk_ctx* ctx = workers_[s]->ctx();
+            const size_t lo = wl[s].start, hi = wl[s].end;
+            std::vector<void*> d(K, nullptr);
+            std::vector<const void*> ptrs(K);
+            std::vector<size_t> cnt(K);
+            for (size_t k = 0; k < K; k++) {
+                const size_t len = lens[k] < n_bases_ ? lens[k] : n_bases_;
+                cnt[k] = len > lo ? (len < hi ? len : hi) - lo : 0;
+                check(plonk_dev_alloc(ctx, (cnt[k] ? cnt[k] : 1) * 32, &d[k]));
+                if (cnt[k]) check(plonk_memcpy_h2d(ctx, d[k], polys[k] + 4 * lo, cnt[k] * 32));
+                ptrs[k] = d[k];
+            }
+            std::vector<uint64_t> part(K * J);
+            const int rc = plonk_commit_many_dev(ctx, K, ptrs.data(), cnt.data(), lo, part.data());
+            for (void* q : d) plonk_dev_free(ctx, q);
+            check(rc);
+            for (size_t k = 0; k < K; k++) {
+                std::vector<uint64_t> pk(part.begin() + k * J, part.begin() + (k + 1) * J);
+                if (acc[k].empty()) acc[k] = pk;
+                else { std::vector<uint64_t> sum(J); check(plonk_g1_add(curve_, acc[k].data(), pk.data(), sum.data())); acc[k] = sum; }
+            }
+        }
+        std::vector<bool> infs(K);
+        xys->assign(K, std::vector<uint64_t>(2 * fq_limbs64(curve_), 0));
+        for (size_t k = 0; k < K; k++) {
+            int inf = 0;
+            check(plonk_g1_to_affine(curve_, acc[k].data(), (*xys)[k].data(), &inf));
+            infs[k] = inf != 0;
+        }
+        return infs;
+    }
+
     // Prover::fft, dispatcher2.rs:732-787.  coeffs: len Fr (zero-padded to the domain); result: N Fr, natural order
     std::vector<uint64_t> fft(const uint64_t* coeffs, size_t len, bool is_quot, bool is_inv, bool is_coset) {
         const size_t N = is_quot ? quot_domain_size_ : domain_size_, S = workers_.size();

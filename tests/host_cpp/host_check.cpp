@@ -79,6 +79,24 @@ int main(int argc, char** argv) {
             const bool cinf = d.commit_polynomial(sc_mont.data(), nb, &cxy);
             if ((int)cinf != winf || cxy != want_xy) { fprintf(stderr, "commit_polynomial mismatch: S=%zu\n", S); return 1; }
             checks += 2;
+            // ---- a prover round: three polynomials of ragged length (one longer than the key: clamped like commit_polynomial, one
+            // empty) through plonk_commit_many_dev on every worker's key range, against one commit_polynomial each
+            {
+                std::vector<uint64_t> p1(4 * (nb + 9)), p2(4 * 1000);
+                o_rand(curve, 79, nb + 9, p1.data());
+                o_rand(curve, 80, 1000, p2.data());
+                const std::vector<const uint64_t*> polys = {sc_mont.data(), p1.data(), p2.data(), p2.data()};
+                const std::vector<size_t> lens = {nb, nb + 9, 1000, 0};
+                std::vector<std::vector<uint64_t>> xys;
+                const std::vector<bool> infs = d.commit_round(polys, lens, &xys);
+                for (size_t k = 0; k < polys.size(); k++) {
+                    std::vector<uint64_t> one;
+                    const bool oinf = d.commit_polynomial(polys[k], lens[k], &one);
+                    if (oinf != infs[k] || (!oinf && one != xys[k])) { fprintf(stderr, "commit_round mismatch: S=%zu poly %zu\n", S, k); return 1; }
+                    checks++;
+                }
+                if (infs[0] != (bool)winf || xys[0] != want_xy) { fprintf(stderr, "commit_round != oracle: S=%zu\n", S); return 1; }
+            }
         }
     } catch (const plonk::Error& e) {
         fprintf(stderr, "plonk error %d: %s\n", e.code, e.what());

@@ -1,6 +1,7 @@
 """The host side in compiled code: host/plonk_host.hpp is a C++ mirror of the reference worker / dispatcher orchestration on the bare
 C ABI (the reference's host is Rust; no Rust toolchain here — ffi/plonk_hip.rs is that binding as source).  tests/host_cpp/host_check.cpp
-drives it — distributed FFT in all four modes on S = 1, 2, 4 in-process workers, sharded MSM, commit_polynomial — and compares with
+drives it — distributed FFT in all four modes on S = 1, 2, 4 in-process workers, sharded MSM, commit_polynomial, a prover round through
+plonk_commit_many_dev on every worker's key range — and compares with
 the oracle, with no Python between the host program and libplonk_hip.so."""
 import os
 import subprocess
