@@ -503,8 +503,8 @@ def main():
     def valu_entry(name, avg_ms):
         """The roofline that actually binds these kernels: VALU issue.  insts = SQ_INSTS_VALU per launch; issue_ms = insts * 4.5 clk /
         (1024 SIMDs * 2.4 GHz), 4.5 clk being the measured issue interval of v_mad_u64_u32 and the VOP3 carry ops
-        (profiles/r01_valu_microbench.txt) and 2.4 GHz the peak clock (a lower sustained clock raises the fraction; plain VOP2
-        issues faster, which lowers it)."""
+        (profiles/r01_valu_microbench.txt) and 2.4 GHz the peak clock (a lower sustained clock raises the fraction — rocm-smi beside the
+        running step shows 2.06-2.27 GHz at 1.25-1.36 kW, profiles/r02_clock_samples.txt; plain VOP2 issues faster, which lowers it)."""
         ent = pmc.get(name)
         if not ent or "SQ_INSTS_VALU" not in ent:
             return None
