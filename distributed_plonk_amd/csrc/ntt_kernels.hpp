@@ -231,8 +231,13 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
     constexpr int KMAX = (EPT == 8) ? 3 : (EPT == 4) ? 2 : (EPT == 2 ? 1 : 1);
     constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-    const uint32_t T = 1u << P.log_t;
-    const uint32_t pitch = P.tile_pitch;
+    // The swizzled instantiation is only dispatched for 8-column tiles with pitch 8 (ntt_engine.hip: launch_one): with the tile shape a
+    // compile-time constant the column t = e & 7 of a lane is the same for its EPT elements (the lane count is a multiple of 8), and
+    // everything that depends on t alone — array / class / plane / row-table / output base addresses, 64-bit products — is computed
+    // once per lane instead of once per element.
+    const uint32_t LOG_T = SWZ ? 3u : P.log_t;
+    const uint32_t T = 1u << LOG_T;
+    const uint32_t pitch = SWZ ? 8u : P.tile_pitch;
     const uint32_t plane = R * pitch;
     const uint32_t nthreads = (R * T) / EPT;
     const uint32_t u = threadIdx.x;
@@ -259,7 +264,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         const uint32_t e = u + i * nthreads;
         uint32_t a, t;
         if (P.load_a_fast) { a = e & (R - 1); t = e >> LOG_R; }
-        else               { t = e & (T - 1); a = e >> P.log_t; }
+        else               { t = e & (T - 1); a = e >> LOG_T; }
         F29 v;
         const uint64_t arr = q0 + (uint64_t)t * P.tq;                       // array index; its class selects the first-pass tables
         const uint64_t cls = arr & (((uint64_t)1 << P.cls_log) - 1);
@@ -298,7 +303,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
     // ---- in-LDS DIT transform, stages grouped KMAX at a time from stage 0 (the first group enjoys the
     //      trivial twiddles), the LOG_R % KMAX remainder last
     {
-        const uint32_t t = u & (T - 1), w = u >> P.log_t;
+        const uint32_t t = u & (T - 1), w = u >> LOG_T;
         constexpr int KREM = LOG_R % KMAX;
         constexpr int SFULL = LOG_R - KREM;          // stages covered by full groups
         if constexpr (R <= EPT) {
@@ -339,7 +344,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
 #pragma unroll
     for (int i = 0; i < EPT; i++) {
         const uint32_t e = u + i * nthreads;
-        const uint32_t t = e & (T - 1), idx = e >> P.log_t;
+        const uint32_t t = e & (T - 1), idx = e >> LOG_T;
         F29 v = tile.get((idx ^ sw_fold<SWZ>(idx)) * pitch + t);
         if (!P.is_last) {
             const uint64_t b = b0 + (uint64_t)t * P.tb;
