@@ -215,6 +215,9 @@ def main():
     workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_commit_lanes)]
     w = workers[0]
     q64 = w.q64
+    if os.environ.get("PLONK_BENCH_MSM_WINDOW"):                 # experiment knob: force the Pippenger window (0 / unset: the library's cost model)
+        for x in workers:
+            x.set_option("msm_window", int(os.environ["PLONK_BENCH_MSM_WINDOW"]))
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
     transport = args.transport if (world > 1 or args.multi_path) else "torch"
     rccl_info = None
