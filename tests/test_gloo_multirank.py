@@ -1,4 +1,4 @@
-"""The N>1 path on CPU: two processes, `gloo` backend, world_size 2.
+"""The N>1 path on CPU: separate processes over the `gloo` backend, world sizes 2, 4 and 8 (8 = the size of the driver's SCALE run).
 
 What runs here is the product's rank-level plumbing (distributed_plonk_amd.dispatcher: the workload
 partition, ONE all-to-all for the NTT exchange, the all-gather + add for MSM partials); the field / curve
@@ -74,19 +74,19 @@ def _rank_main(rank, world, port, log_n, cid, result_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("log_n,cid", [(7, 0), (8, 1)])
-def test_two_rank_exchange_and_msm_reduce(log_n, cid):
+@pytest.mark.parametrize("world,log_n,cid", [(2, 7, 0), (2, 8, 1), (8, 8, 0)])          # 8 ranks: the SCALE run's world size (r = c = 16: 2 rows per rank)
+def test_two_rank_exchange_and_msm_reduce(world, log_n, cid):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank_main, args=(rk, 2, port, log_n, cid, q)) for rk in range(2)]
+    procs = [ctx.Process(target=_rank_main, args=(rk, world, port, log_n, cid, q)) for rk in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(rk, True) for rk in range(world)]
 
 
 # --------------------------------------------------------------------------------------------- coset-class decomposition (class_prover.py)
@@ -161,21 +161,21 @@ def _class_rank_main(rank, world, port, log_m, cid, result_q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("log_m,cid", [(8, 0), (9, 1)])
-def test_two_rank_coset_class_exchange(log_m, cid):
+@pytest.mark.parametrize("world,log_m,cid", [(2, 8, 0), (2, 9, 1), (8, 9, 0)])
+def test_two_rank_coset_class_exchange(world, log_m, cid):
     """class_prover.TorchComm over gloo, world size 2: per-class interpolation contributions -> all-to-all -> sum -> all-gather
     reproduces the whole-domain coset iFFT; sharded commitments add up."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_class_rank_main, args=(rk, 2, port, log_m, cid, q)) for rk in range(2)]
+    procs = [ctx.Process(target=_class_rank_main, args=(rk, world, port, log_m, cid, q)) for rk in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in procs]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    assert sorted(results) == [(0, True), (1, True)]
+    assert sorted(results) == [(rk, True) for rk in range(world)]
 
 
 # --------------------------------------------------------------------------------------------- the whole class prover, SPMD over gloo
@@ -220,7 +220,7 @@ def _prover_rank_main(rank, world, port, log_n, cid, result_q, shard_key=False):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,log_n,cid,shard_key", [(2, 4, 0, False), (4, 5, 1, True), (2, 5, 0, True)])
+@pytest.mark.parametrize("world,log_n,cid,shard_key", [(2, 4, 0, False), (4, 5, 1, True), (2, 5, 0, True), (8, 5, 0, True)])     # 8: the SCALE run's world size
 def test_class_prover_spmd_over_gloo(world, log_n, cid, shard_key):
     """distributed_plonk_amd.class_prover.ClassProver end to end as `world` processes over gloo: the product's SPMD orchestration
     and torch.distributed calls run for real (host-staged tensors); each rank's device work is done by the oracle through the
