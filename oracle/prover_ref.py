@@ -118,9 +118,41 @@ def make_ck(curve: int, n: int, seed: int, unique: int = 64):
     return bases, inf
 
 
-def prove_rounds(curve: int, log_n: int, ck, ck_inf, circ: dict, blinders: dict, ch: dict, threads: int = 1):
+def make_ck_trapdoor(curve: int, n: int, tau: int):
+    """universal_setup with a KNOWN trapdoor (dispatcher2.rs:1278 draws tau from rng and forgets it): P_i = tau^i * G for the
+    n + 3 powers the prover needs, padded with the point at infinity to a multiple of 32 (dispatcher2.rs:206-208).  With it the
+    final pairing check of the verifier becomes an equation in G1 (oracle/verifier_ref.py).  -> (bases x||y, inf flags)."""
+    f = CURVE_OBJ[curve].fr
+    cnt = n + 3
+    N = ((cnt + 31) >> 5) << 5
+    Q = O.FQ_LIMBS[curve]
+    bases = np.zeros((N, 2 * Q), dtype=np.uint64)
+    g = O.generator(curve)
+    s = 1
+    for i in range(cnt):
+        k = np.array(B.to_limbs(s, 4), dtype=np.uint64)             # canonical scalar
+        bases[i], is_inf = O.jac_to_affine(curve, O.scalar_mul(curve, g, k))
+        assert not is_inf
+        s = s * tau % f.p
+    inf = np.zeros(N, dtype=np.uint8)
+    inf[cnt:] = 1
+    return bases, inf
+
+
+def prove_rounds(curve: int, log_n: int, ck, ck_inf, circ: dict, blinders: dict, ch, threads: int = 1):
     """dispatcher2.rs:296-712.  blinders: {"wires": (5,2,4), "perm": (3,4)}; ch: {"beta","gamma","alpha","zeta","v"}
-    as Montgomery limbs (4,).  Returns commitments as affine (xy, is_inf) plus evaluations and intermediate polys."""
+    as Montgomery limbs (4,), or a callable (label, proof_so_far) -> limbs that is asked where `prove` draws each challenge
+    (a Fiat-Shamir transcript).  Returns commitments as affine (xy, is_inf) plus evaluations and intermediate polys."""
+    if callable(ch):
+        draw, ch, so_far = ch, {}, {}
+
+        def need(label):
+            ch[label] = draw(label, so_far)
+    else:
+        so_far = {}
+
+        def need(label):
+            pass
     f = CURVE_OBJ[curve].fr
     p = f.p
     n = 1 << log_n
@@ -139,12 +171,14 @@ def prove_rounds(curve: int, log_n: int, ck, ck_inf, circ: dict, blinders: dict,
 
     # Round 1
     wire_polys = [O.blind(curve, O.ntt(curve, circ["wires"][i], True, False, threads=threads), n, blinders["wires"][i]) for i in range(5)]
-    wires_poly_comms = [commit(q) for q in wire_polys]
+    wires_poly_comms = so_far["wires_poly_comms"] = [commit(q) for q in wire_polys]
     # Round 2
+    need("beta"); need("gamma")
     prod = O.perm_product(curve, circ["wires"], circ["id_perm"], circ["perm_idx"], ch["beta"], ch["gamma"])
     perm_poly = O.blind(curve, O.ntt(curve, prod, True, False, threads=threads), n, blinders["perm"])
-    prod_perm_poly_comm = commit(perm_poly)
+    prod_perm_poly_comm = so_far["prod_perm_poly_comm"] = commit(perm_poly)
     # Round 3
+    need("alpha")
     pi_poly = O.ntt(curve, circ["pub_input"], True, False, threads=threads)
     evals = O.quotient_evals(curve, log_n, np.stack([cfft(q) for q in circ["selectors"]]), np.stack([cfft(q) for q in circ["sigmas"]]),
                              np.stack([cfft(q) for q in wire_polys]), cfft(perm_poly), cfft(pi_poly), ch["alpha"], ch["beta"], ch["gamma"],
@@ -157,13 +191,16 @@ def prove_rounds(curve: int, log_n: int, ck, ck_inf, circ: dict, blinders: dict,
     if deg != expected:
         raise ValueError(f"WrongQuotientPolyDegree({deg}, {expected})")
     split = [quot[i:min(i + n + 2, deg + 1)] for i in range(0, deg + 1, n + 2)]
-    split_quot_poly_comms = [commit(q) for q in split]
+    split_quot_poly_comms = so_far["split_quot_poly_comms"] = [commit(q) for q in split]
     # Round 4
+    need("zeta")
     zeta = ch["zeta"]
     zeta_w = L(I(zeta) * dom.group_gen)
     wires_evals = [O.poly_eval(curve, q, zeta) for q in wire_polys]
     wire_sigma_evals = [O.poly_eval(curve, circ["sigmas"][i], zeta) for i in range(4)]
     perm_next_eval = O.poly_eval(curve, perm_poly, zeta_w)
+    so_far.update(wires_evals=wires_evals, wire_sigma_evals=wire_sigma_evals, perm_next_eval=perm_next_eval)
+    need("v")
     # Round 5 (scalar coefficients in Python ints)
     z, al, be, ga, v = I(zeta), I(ch["alpha"]), I(ch["beta"]), I(ch["gamma"]), I(ch["v"])
     a, b, c, d, e = (I(x) for x in wires_evals)
