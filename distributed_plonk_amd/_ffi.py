@@ -90,6 +90,9 @@ SIGNATURES = {
     "plonk_memcpy_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plonk_synth_fr": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     "plonk_synth_bases": (C.c_int, [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p]),
+    "plonk_synth_srs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "plonk_synth_circuit": (C.c_int, [C.c_void_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                      C.c_void_p]),
     "plonk_init_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]),
     "plonk_debug_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plonk_quotient_evals_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientInputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),

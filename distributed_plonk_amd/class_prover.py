@@ -198,7 +198,10 @@ class ClassProver(Prover):
             else:                                                # sharded key: coefficient i pairs with LOCAL base i - key_lo
                 klo, khi = self.key_range
                 lo, hi = min(klo, ln), min(khi, ln)
-                shards.append((ptr + lo * 32, lo - klo, hi - lo))
+                if hi <= lo:                                     # the polynomial ends before this rank's key slice: an empty shard
+                    shards.append((ptr, 0, 0))                   # (lo - klo would be negative, i.e. ~2^64 through c_size_t)
+                else:
+                    shards.append((ptr + lo * 32, lo - klo, hi - lo))
         parts = [None] * len(shards)
         lanes = [self.w] + ([self.commit_helper] if self.commit_helper is not None and len(shards) > 1 else [])
 

@@ -131,6 +131,36 @@ int comm_rccl_version() {
     return api->GetVersion(&v) == ncclSuccess ? v : 0;
 }
 
+// ---- one total order of collectives per GPU.  A process may hold several communicators on one device (one per context: the two
+// lanes of the distributed transform, the two commitment contexts), each issuing on its own stream.  RCCL / NCCL do not guarantee
+// progress when collectives of DIFFERENT communicators are in flight on a device at the same time: the ranks' GPUs may schedule the
+// two kernels in different orders and each waits for the peer's other kernel.  So every collective of this library first waits (on
+// its stream) for the previous collective issued on the same device, whatever communicator or stream that one used, and the issue
+// itself happens under a mutex.  Collectives therefore run one after the other in HOST ISSUE ORDER — which callers must keep
+// identical on every rank (bench.py and the provers issue them from one thread) — while still overlapping the other streams' compute.
+namespace {
+struct CollectiveOrder {
+    std::mutex mu;
+    hipEvent_t last[64] = {};
+};
+CollectiveOrder g_order;
+
+struct CollectiveScope {        // RAII: wait for the device's previous collective, issue, record
+    std::unique_lock<std::mutex> lock;
+    int device;
+    hipStream_t stream;
+    bool ok = true;
+    CollectiveScope(int dev, hipStream_t s) : lock(g_order.mu), device(dev & 63), stream(s) {
+        hipEvent_t& e = g_order.last[device];
+        if (!e) ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
+        else ok = hipStreamWaitEvent(stream, e, 0) == hipSuccess;
+    }
+    ~CollectiveScope() {
+        if (g_order.last[device]) (void)hipEventRecord(g_order.last[device], stream);
+    }
+};
+}  // namespace
+
 // block p of `send` -> rank p ; block p of `recv` <- rank p.  One group = one fused RCCL launch; per pair bytes_per_peer bytes,
 // each pair over its own xGMI link (the fabric is point-to-point: 7 links per GPU, no switch).
 int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_peer, hipStream_t stream) {
@@ -139,6 +169,9 @@ int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_p
     if (rc) return rc;
     const char* s = (const char*)send;
     char* r = (char*)recv;
+    CollectiveScope order(c->device, stream);
+    if (!order.ok) return plonk_fail(PLONK_ERR_HIP, "collective ordering event");
+    ProfScope prof("rccl_alltoall", stream);          // HIP events on the stream: the exchange as the GPU saw it (incl. waiting for peers)
     NCCL_TRY(api, api->GroupStart());
     for (int p = 0; p < c->world; p++) {
         ncclResult_t a = api->Send(s + (size_t)p * bytes_per_peer, bytes_per_peer, ncclInt8, p, c->comm, stream);
@@ -153,6 +186,9 @@ int comm_allgather(PlonkComm* c, const void* send, void* recv, size_t bytes, hip
     const RcclApi* api;
     int rc = rccl_api(&api);
     if (rc) return rc;
+    CollectiveScope order(c->device, stream);
+    if (!order.ok) return plonk_fail(PLONK_ERR_HIP, "collective ordering event");
+    ProfScope prof("rccl_allgather", stream);
     NCCL_TRY(api, api->AllGather(send, recv, bytes, ncclInt8, c->comm, stream));
     return PLONK_OK;
 }

@@ -834,12 +834,6 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
-static int g_msm_slice_log = 26;
-void msm_set_slice_log(int v) { g_msm_slice_log = v < 8 ? 8 : (v > 26 ? 26 : v); }
-static int g_msm_batch_max = 32;    // option "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
-void msm_set_batch_max(int v) { g_msm_batch_max = v < 1 ? 1 : (v > 64 ? 64 : v); }
-static int g_msm_fused_y3 = 1;      // option "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
-void msm_set_fused_y3(int v) { g_msm_fused_y3 = v ? 1 : 0; }
 
 // K >= 1 scalar vectors against the SAME bases in one set of launches (the independent commitments of a prover round): vector k
 // supplies the windows k*W1 .. (k+1)*W1 - 1 of one big (window, bucket) problem, so the sort, the bucket accumulation and the
@@ -966,7 +960,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
     hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, bin_cursor, order); }
     { ProfScope ps("msm_accumulate_kernel", stream);
-    if (g_msm_fused_y3)
+    if (ws.fused_y3)
         hipLaunchKernelGGL((msm_accumulate_kernel<NQ, true>), dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
                            nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve));
     else
@@ -1043,7 +1037,7 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* const* d_sc
                      MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     std::vector<XyzzPt<NQ>> total((size_t)K, xyzz_inf<NQ>());
-    const size_t SLICE = (size_t)1 << g_msm_slice_log;      // default 2^26 points per slice (workspace sizing); "msm_slice_log" option for tests
+    const size_t SLICE = (size_t)1 << std::min(std::max(ws.slice_log, 8), 26);      // default 2^26 points per slice (workspace sizing); "msm_slice_log" option for tests
     for (size_t s = 0; s < n; s += SLICE) {
         const size_t m = std::min(SLICE, n - s);
         // windows per vector for this slice size -> how many vectors fit one launch set
@@ -1053,7 +1047,7 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* const* d_sc
         const uint64_t per = (uint64_t)m * W1;
         int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)K, (0xfffffff0ull / per)));
         if ((uint64_t)group * W1 > 65535) group = 65535 / W1;                    // grid.y of the per-window launches
-        group = std::min(group, g_msm_batch_max);
+        group = std::min(group, std::min(std::max(ws.batch_max, 1), 64));
         for (int k0 = 0; k0 < K; k0 += group) {
             const int kn = std::min(group, K - k0);
             std::vector<const uint32_t*> ptrs(kn);

@@ -9,9 +9,7 @@
 #include "plonk_internal.hpp"
 
 static int ilog2(uint64_t x) { int l = 0; while (((uint64_t)1 << (l + 1)) <= x) l++; return l; }
-static int g_ntt_max_log_r = NTT_LOG_RMAX;
-void ntt_set_ept(int v);
-void ntt_set_max_log_r(int v) { g_ntt_max_log_r = std::max(3, std::min(v, NTT_LOG_RMAX)); }
+static_assert(NTT_LOG_RMAX == 9, "NttTables::max_log_r defaults to NTT_LOG_RMAX");
 
 const FrParams& fr_params(int curve) { return curve == PLONK_BN254 ? BN254_FR_PARAMS : BLS12_381_FR_PARAMS; }
 
@@ -281,9 +279,9 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
 }
 
 // ---------------------------------------------------------------------------------------------- plan
-std::vector<int> ntt_plan_widths(int log_m) {
+std::vector<int> ntt_plan_widths(int log_m, int max_log_r) {
     std::vector<int> w;
-    const int mx = g_ntt_max_log_r;
+    const int mx = std::max(3, std::min(max_log_r, NTT_LOG_RMAX));
     if (log_m <= mx) { w.push_back(log_m); return w; }
     int P = (log_m + mx - 1) / mx;
     int base = log_m / P, rem = log_m % P;
@@ -293,9 +291,6 @@ std::vector<int> ntt_plan_widths(int log_m) {
 
 
 static int pref_log_t(int log_r) {
-    static const char* ept_env = getenv("PLONK_NTT_EPT");
-    static bool ept_done = false;
-    if (!ept_done) { ept_done = true; if (ept_env) ntt_set_ept(atoi(ept_env)); }
     static const char* ov9 = getenv("PLONK_NTT_LOGT9");     // tuning overrides (experiments)
     static const char* ov8 = getenv("PLONK_NTT_LOGT8");
     if (log_r >= 9 && ov9) return atoi(ov9);
@@ -305,8 +300,8 @@ static int pref_log_t(int log_r) {
     return 11 - log_r;         // 2048-element tiles (72 KiB: two workgroups per CU)
 }
 
-bool ntt_single_pass_inplace_ok(const NttCall& c) {
-    return ntt_plan_widths(c.log_m).size() == 1 && c.layout == NTT_CONTIGUOUS && c.out_layout == NTT_CONTIGUOUS && c.split_log < 0;
+bool ntt_single_pass_inplace_ok(const NttTables& T, const NttCall& c) {
+    return ntt_plan_widths(c.log_m, T.max_log_r).size() == 1 && c.layout == NTT_CONTIGUOUS && c.out_layout == NTT_CONTIGUOUS && c.split_log < 0;
 }
 
 static TwoLevelScale make_scale(const NttTables& T, const ScaleSpec& s, uint64_t q_offset) {
@@ -330,8 +325,16 @@ static TwoLevelScale make_scale(const NttTables& T, const ScaleSpec& s, uint64_t
     return o;
 }
 
-static int g_ntt_ept = 4;      // elements per lane: 8 (radix-8 steps) or 4 (radix-4 steps, twice the waves per tile)
-void ntt_set_ept(int v) { g_ntt_ept = (v == 4 || v == 2) ? v : 8; }
+// elements per lane: 4 (radix-4 steps; the measured choice) — PLONK_NTT_EPT = 8 / 2 selects the other instantiations for experiments.
+// Read once per process (a thread-safe function-local static), never changed afterwards.
+static int ntt_ept() {
+    static const int ept = [] {
+        const char* e = getenv("PLONK_NTT_EPT");
+        const int v = e ? atoi(e) : 4;
+        return (v == 4 || v == 2) ? v : (e ? 8 : 4);
+    }();
+    return ept;
+}
 
 template <int LOG_R, int EPT, bool SWZ = false>
 static hipError_t launch_one_e(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
@@ -353,10 +356,10 @@ template <int LOG_R>
 static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     // the bank swizzle (ntt_kernels.hpp: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
     if constexpr (LOG_R >= 7) {
-        if (g_ntt_ept == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
+        if (ntt_ept() == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
     }
-    if (g_ntt_ept == 4) return launch_one_e<LOG_R, 4>(P, grid, threads, lds, stream);
-    if (g_ntt_ept == 2) return launch_one_e<LOG_R, 2>(P, grid, threads, lds, stream);
+    if (ntt_ept() == 4) return launch_one_e<LOG_R, 4>(P, grid, threads, lds, stream);
+    if (ntt_ept() == 2) return launch_one_e<LOG_R, 2>(P, grid, threads, lds, stream);
     return launch_one_e<LOG_R, 8>(P, grid, threads, lds, stream);
 }
 
@@ -385,7 +388,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     if (L < 1 || L > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "ntt_run: log size %d outside [1,%d]", L, T.two_adicity);
     if (c.batch == 0 || (c.batch & (c.batch - 1))) return plonk_fail(PLONK_ERR_ARG, "ntt_run: batch must be a power of two");
     const uint64_t M = (uint64_t)1 << L, Bt = c.batch;
-    const std::vector<int> widths = ntt_plan_widths(L);
+    const std::vector<int> widths = ntt_plan_widths(L, T.max_log_r);
     const int NP = (int)widths.size();
     if (NP > NTT_MAX_PASSES) return plonk_fail(PLONK_ERR_ARG, "ntt_run: too many passes");
     const int dir = c.inverse ? 1 : 0;
@@ -406,7 +409,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     const uint64_t n_cls = c.shared_in ? Bt / c.in_rows : 1;                 // classes per row (shared-input mode)
     const int cls_log = ilog2(n_cls);
     Fr* const inplace = c.shared_in ? c.work : const_cast<Fr*>(c.in);      // where the non-last passes leave their output
-    if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(c))
+    if (NP == 1 && (const void*)c.in == (const void*)c.out && !ntt_single_pass_inplace_ok(T, c))
         return plonk_fail(PLONK_ERR_ARG, "ntt_run: in-place only for contiguous single pass");
 
     // forward coset shift of a whole contiguous vector: x[n] * g^n with n = a*r_1 + b splits into a per-row table
@@ -584,7 +587,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         }
         if (p == 0 && !coset_folded) P.pro = make_scale(T, c.pro, c.q_offset);
         const uint64_t Tt = (uint64_t)1 << P.log_t;
-        const uint32_t ept = (R >= (uint64_t)g_ntt_ept) ? (uint32_t)g_ntt_ept : (uint32_t)R;
+        const uint32_t ept = (R >= (uint64_t)ntt_ept()) ? (uint32_t)ntt_ept() : (uint32_t)R;
         const uint32_t threads = (uint32_t)(R * Tt / ept);
         if (threads > 1024) return plonk_fail(PLONK_ERR_ARG, "ntt_run: tile of %llu x %llu needs %u lanes", (unsigned long long)R, (unsigned long long)Tt, threads);
         const size_t lds = (size_t)9 * R * P.tile_pitch * 4 + std::max<size_t>(R / 2, 1) * 36;

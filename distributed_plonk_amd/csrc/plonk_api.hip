@@ -9,11 +9,6 @@
 #include "ec.hpp"
 #include "plonk_internal.hpp"
 
-void ntt_set_max_log_r(int v);
-void msm_set_slice_log(int v);
-void quotient_set_fuse(int v);
-void msm_set_fused_y3(int v);
-void msm_set_batch_max(int v);
 
 // ---------------------------------------------------------------------------------------------- errors
 static thread_local char g_err[512] = {0};
@@ -203,11 +198,12 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
-    if (!strcmp(key, "ntt_max_log_r")) { ntt_set_max_log_r((int)value); return PLONK_OK; }
-    if (!strcmp(key, "msm_batch_max")) { msm_set_batch_max((int)value); return PLONK_OK; }        // process-wide; vectors per launch set of commit_many
-    if (!strcmp(key, "msm_fused_y3")) { msm_set_fused_y3((int)value); return PLONK_OK; }          // process-wide; default 1
-    if (!strcmp(key, "quotient_fuse")) { quotient_set_fuse((int)value); return PLONK_OK; }        // process-wide; experiments, see quotient.hip
-    if (!strcmp(key, "msm_slice_log")) { msm_set_slice_log((int)value); return PLONK_OK; }          // process-wide; MSMs above 2^value points are sliced (8..26)
+    // every knob lives in the context it was set on (another context, possibly driven from another host thread, is not affected)
+    if (!strcmp(key, "ntt_max_log_r")) { ctx->tables.max_log_r = (int)value; return PLONK_OK; }
+    if (!strcmp(key, "msm_batch_max")) { ctx->msm_ws.batch_max = (int)value; return PLONK_OK; }      // vectors per launch set of commit_many
+    if (!strcmp(key, "msm_fused_y3")) { ctx->msm_ws.fused_y3 = value ? 1 : 0; return PLONK_OK; }      // default 1
+    if (!strcmp(key, "quotient_fuse")) { ctx->tables.quotient_fuse = (int)value; return PLONK_OK; }   // experiments, see quotient.hip
+    if (!strcmp(key, "msm_slice_log")) { ctx->msm_ws.slice_log = (int)value; return PLONK_OK; }       // MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);
 }
 
@@ -430,7 +426,7 @@ extern "C" int plonk_ntt_dev(plonk_ctx* ctx, void* d_in, void* d_out, size_t n, 
         if (is_coset && is_inv) { c.epi.kind = 2; c.epi.b0 = 1; }       // X[k] * g^-k
         Fr* out = (Fr*)d_out;
         bool via_scratch = false;
-        if (d_in == d_out && !ntt_single_pass_inplace_ok(c)) {
+        if (d_in == d_out && !ntt_single_pass_inplace_ok(ctx->tables, c)) {
             int rc = ensure_scratch(ctx, n * 32);
             if (rc) return rc;
             out = (Fr*)ctx->d_scratch;
@@ -533,6 +529,7 @@ extern "C" int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_
     if (i >= t->nrows) return plonk_fail(PLONK_ERR_ARG, "plonk_fft1: local row %llu >= %llu", (unsigned long long)i, (unsigned long long)t->nrows);
     if (t->prepared || t->rows_external) return plonk_fail(PLONK_ERR_STATE, "plonk_fft1: rows already consumed");
     if (!t->d_rows) { int prc = pool_get(ctx, t->nrows * t->c * 32, (void**)&t->d_rows); if (prc) return prc; }
+    t->compact_len = 0;          // dense rows
     HIP_TRY(hipMemcpyAsync(t->d_rows + i * t->c, v, t->c * 32, hipMemcpyHostToDevice, ctx->stream));
     if (!t->row_present[i]) { t->row_present[i] = 1; t->rows_filled++; }
     return PLONK_OK;
@@ -548,6 +545,7 @@ extern "C" int plonk_fft1_dev(plonk_ctx* ctx, uint64_t id, void* d_rows) {
     if (t->d_rows && !t->rows_external) pool_put(ctx, t->nrows * t->c * 32, t->d_rows);
     t->d_rows = (Fr*)d_rows;     // consumed: the row pass uses it as workspace
     t->rows_external = true;
+    t->compact_len = 0;          // dense [nrows][c] rows, also after an earlier plonk_fft1_dev_compact on this task
     t->rows_filled = t->nrows;
     return PLONK_OK;
 }
@@ -634,15 +632,17 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     if (t->rows_filled != t->nrows) return plonk_fail(PLONK_ERR_STATE, "plonk_fft2_prepare: %llu of %llu rows received", (unsigned long long)t->rows_filled,
                                                       (unsigned long long)t->nrows);
     const size_t S = t->wl.size();
-    if (!exchange && ctx->comm) {               // the in-library RCCL transport
-        if ((size_t)comm_world(ctx->comm) != S)
-            return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu workloads but the communicator has %d ranks", S, comm_world(ctx->comm));
+    // transport precedence: an explicit callback; else the context's RCCL communicator when the task spans exactly its ranks; a
+    // single-workload task on a context that joined a larger communicator stays local (nothing to exchange)
+    if (!exchange && ctx->comm && (size_t)comm_world(ctx->comm) == S) {
         exchange = plonk_exchange_rccl;
         user = ctx;
     }
+    if (!exchange && ctx->comm && S > 1)
+        return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu workloads but the communicator has %d ranks", S, comm_world(ctx->comm));
     if (S > 1 && !exchange) return plonk_fail(PLONK_ERR_ARG, "plonk_fft2_prepare: %zu ranks need plonk_comm_init or an exchange callback", S);
     const size_t tile_bytes = t->nrows * t->c * 32;     // == r * ncols * 32
-    if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_send))) return rc;
+    if (!t->d_send && (rc = pool_get(ctx, tile_bytes, (void**)&t->d_send))) return rc;      // kept across a failed attempt, not re-taken
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     // row pass (fft1_helper, worker.rs:66-94) for all local rows, written straight into the
     // per-peer blocks of the send buffer (the pack of worker.rs:327-330)
@@ -665,7 +665,7 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
         const uint64_t len = t->compact_len;
         int k = 0;
         while (k < 4 && c.log_m - k > 1 && 2 * len < 3 * (t->c >> (k + 1))) k++;       // same rule as coset_eval_run
-        if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_work))) return rc;
+        if (!t->d_work && (rc = pool_get(ctx, tile_bytes, (void**)&t->d_work))) return rc;
         c.pro = ScaleSpec();
         c.shared_in = true;
         c.in_rows = t->nrows;
@@ -685,7 +685,7 @@ extern "C" int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn
     }
     if ((rc = ntt_run(ctx->tables, c, ctx->stream))) return rc;
     if (exchange) {          // also honoured for a single rank (all-to-all with oneself), so the transport is testable on one GPU
-        if ((rc = pool_get(ctx, tile_bytes, (void**)&t->d_recv))) return rc;
+        if ((!t->d_recv || t->d_recv == t->d_send) && (rc = pool_get(ctx, tile_bytes, (void**)&t->d_recv))) return rc;
         const int xr = exchange(user, t->d_send, t->d_recv, t->nrows * t->ncols * 32, (int)S, (void*)ctx->stream);
         if (xr) return plonk_fail(PLONK_ERR_EXCHANGE, "exchange callback returned %d", xr);
     } else {
@@ -946,6 +946,26 @@ extern "C" int plonk_synth_bases(plonk_ctx* ctx, uint64_t seed, size_t unique, s
     if (!d_out && n) return plonk_fail(PLONK_ERR_ARG, "plonk_synth_bases: null");
     if (unique == 0) return synth_bases_distinct_dev(ctx->curve, seed, n, d_out, ctx->stream);
     return synth_bases_dev(ctx->curve, seed, unique, n, d_out, ctx->stream);
+}
+extern "C" int plonk_synth_srs(plonk_ctx* ctx, const uint64_t* tau, size_t n, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!tau || (!d_out && n)) return plonk_fail(PLONK_ERR_ARG, "plonk_synth_srs: null");
+    return synth_srs_dev(ctx->curve, tau, n, d_out, ctx->stream);
+}
+extern "C" int plonk_synth_circuit(plonk_ctx* ctx, uint64_t seed, size_t n, size_t num_inputs, const uint64_t* k, void* d_wires, void* d_selector_evals,
+                                   void* d_sigma_evals, void* d_id_perm, void* d_perm_idx, void* d_pub_input) {
+    CHECK_CTX(ctx);
+    if (!k || !d_wires || !d_selector_evals || !d_sigma_evals || !d_id_perm || !d_perm_idx || !d_pub_input)
+        return plonk_fail(PLONK_ERR_ARG, "plonk_synth_circuit: null");
+    if (n < 2 || (n & (n - 1))) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_synth_circuit: n = %zu is not a power of two >= 2", n);
+    int log_n = 0;
+    while (((size_t)1 << log_n) < n) log_n++;
+    if (log_n > ctx->tables.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "plonk_synth_circuit: 2^%d exceeds the two-adicity", log_n);
+    if (num_inputs > n) return plonk_fail(PLONK_ERR_ARG, "plonk_synth_circuit: %zu public inputs for %zu gates", num_inputs, n);
+    Fr w = ctx->tables.h_root[0];                       // primitive 2^two_adicity-th root, squared down to order n
+    for (int i = log_n; i < ctx->tables.two_adicity; i++) w = fp_sqr(w, ctx->tables.fp);
+    return synth_circuit_dev(ctx->curve, seed, n, num_inputs, k, w, d_wires, d_selector_evals, d_sigma_evals, d_id_perm, d_perm_idx, d_pub_input,
+                             ctx->stream);
 }
 extern "C" int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
     CHECK_CTX(ctx);

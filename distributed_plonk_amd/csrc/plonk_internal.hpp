@@ -87,6 +87,9 @@ struct NttTables {
     // poly_ops.hip: three-level power tables z^i keyed by (z, levels, scale) — LRU cache (pow_order: least recent first)
     std::unordered_map<std::string, F29*> pow_tabs;
     std::vector<std::string> pow_order;
+    // per-context tuning knobs (plonk_set_option): tests and experiments only; a context is driven by one host thread at a time
+    int max_log_r = 9;                      // "ntt_max_log_r": widest in-LDS transform of a pass (<= NTT_LOG_RMAX)
+    int quotient_fuse = 0;                  // "quotient_fuse": kernel-formulation experiments of quotient.hip (0 = the shipped kernel)
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };
@@ -134,8 +137,8 @@ struct NttCall {
 int ntt_tables_create(NttTables& T, int curve, hipStream_t stream);
 void ntt_tables_destroy(NttTables& T);
 int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream);
-bool ntt_single_pass_inplace_ok(const NttCall& c);
-std::vector<int> ntt_plan_widths(int log_m);
+bool ntt_single_pass_inplace_ok(const NttTables& T, const NttCall& c);
+std::vector<int> ntt_plan_widths(int log_m, int max_log_r);
 
 int transpose_fr(const Fr* in, Fr* out, uint64_t rows, uint64_t cols, hipStream_t stream);
 
@@ -143,6 +146,10 @@ int transpose_fr(const Fr* in, Fr* out, uint64_t rows, uint64_t cols, hipStream_
 struct MsmWorkspace {
     void* d_buf = nullptr;
     size_t bytes = 0;
+    // per-context tuning knobs (plonk_set_option): tests and experiments only
+    int slice_log = 26;       // "msm_slice_log": MSMs above 2^slice_log points run slice by slice (workspace sizing)
+    int batch_max = 32;       // "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
+    int fused_y3 = 1;         // "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
 };
 // Fixed-base window table (msm_engine.hip: msm_table_kernel): W planes of `stride` points, plane w = 2^(c*w) * bases.
 struct MsmTable {
@@ -173,6 +180,9 @@ int field_op_dev(int curve, int field, int op, const void* a, const void* b, voi
 int synth_fr_dev(int curve, uint64_t seed, Fr* out, size_t n, hipStream_t stream);
 int synth_bases_dev(int curve, uint64_t seed, size_t unique, size_t n, void* d_out, hipStream_t stream);
 int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hipStream_t stream);
+int synth_srs_dev(int curve, const uint64_t* tau_mont, size_t n, void* d_out, hipStream_t stream);
+int synth_circuit_dev(int curve, uint64_t seed, size_t n, size_t num_inputs, const uint64_t* k_mont, const Fr& omega_n, void* d_wires, void* d_sel,
+                      void* d_sigma, void* d_id_perm, void* d_perm_idx, void* d_pub, hipStream_t stream);
 
 const FrParams& fr_params(int curve);
 

@@ -303,8 +303,6 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
 }
 
 // ---------------------------------------------------------------------------------------------- host
-static int g_quotient_fuse = 0;       // 0: the unlifted kernel (default); 1, 2, 3: lifted wires with 1 / 2 / 3 products per reduction (experiments)
-void quotient_set_fuse(int v) { g_quotient_fuse = (v >= 0 && v <= 4) ? v : 0; }
 static F29 host_const(const Fr& v_mont, const FrParams& P) { return f29_const_from_mont256(v_mont, P); }
 
 int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, size_t m, const uint64_t* alpha, const uint64_t* beta,
@@ -414,7 +412,7 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        const int fuse = g_quotient_fuse;
+        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 4) ? T.quotient_fuse : 0;
         const dim3 grid((uint32_t)((m_local + 255) / 256));
         if (fuse == 1) hipLaunchKernelGGL(quotient_evals_kernel_f1, grid, dim3(256), 0, stream, q);
         else if (fuse == 2) hipLaunchKernelGGL(quotient_evals_kernel_f2, grid, dim3(256), 0, stream, q);

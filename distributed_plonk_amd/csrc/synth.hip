@@ -200,3 +200,156 @@ int synth_bases_distinct_dev(int curve, uint64_t seed, size_t n, void* d_out, hi
     if (curve == PLONK_BN254) return synth_distinct_t<8>(curve, seed, n, d_out, stream);
     return synth_distinct_t<12>(curve, seed, n, d_out, stream);
 }
+
+// ---------------------------------------------------------------------------------------------- trapdoor SRS
+// P_i = tau^i * G, i < n: a KZG commit key whose trapdoor the test knows (the reference's universal_setup draws tau from rng and
+// forgets it, dispatcher2.rs:1278).  With it commit(f) = f(tau) * G, and the verifier's pairing check becomes an equation in G1
+// (oracle/verifier_ref.py) — which is what lets bench.py verify a whole 2^24-gate proof.  Fixed-base, 8-bit windows: a table
+// T[w][b] = b * 2^(8w) * G (32 x 256 affine points) and at most 32 mixed additions + one inversion per point.
+template <int NQ>
+__global__ void __launch_bounds__(64) srs_table_kernel(AffPt<NQ>* __restrict__ table, const AffPt<NQ> G, const FpParams<NQ> P) {
+    const uint32_t e = blockIdx.x * blockDim.x + threadIdx.x;      // e = w * 256 + b
+    if (e >= 32 * 256) return;
+    const uint32_t w = e >> 8, b = e & 255;
+    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    for (int i = 7; i >= 0; i--) {
+        acc = xyzz_dbl_cold(acc, P);
+        if ((b >> i) & 1) acc = xyzz_madd_cold(acc, G, P);
+    }
+    for (uint32_t i = 0; i < 8 * w; i++) acc = xyzz_dbl_cold(acc, P);
+    st16(table + e, xyzz_to_affine(acc, P));
+}
+
+template <int NQ>
+__global__ void __launch_bounds__(128) srs_points_kernel(const AffPt<NQ>* __restrict__ table, const Fr tau, uint64_t n, AffPt<NQ>* __restrict__ out,
+                                                         const FrParams FR, const FpParams<NQ> P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Fr s = fp_from_mont(fp_pow_u64(tau, i, FR), FR);          // tau^i, canonical
+    XyzzPt<NQ> acc = xyzz_inf<NQ>();
+    for (int w = 0; w < 32; w++) {
+        const uint32_t b = (s.l[w >> 2] >> ((w & 3) * 8)) & 255;
+        if (b) acc = xyzz_madd_cold(acc, ld16(table + w * 256 + b), P);
+    }
+    st16(out + i, xyzz_to_affine(acc, P));
+}
+
+template <int NQ>
+static int synth_srs_t(int curve, const Fr& tau, size_t n, void* d_out, hipStream_t stream) {
+    const FpParams<NQ>& P = field_params<NQ>(curve, 1);
+    AffPt<NQ>* table = nullptr;
+    HIP_TRY(hipMalloc((void**)&table, 32 * 256 * sizeof(AffPt<NQ>)));
+    hipLaunchKernelGGL(srs_table_kernel<NQ>, dim3(32 * 256 / 64), dim3(64), 0, stream, table, generator_affine<NQ>(curve), P);
+    hipLaunchKernelGGL(srs_points_kernel<NQ>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, stream, table, tau, (uint64_t)n, (AffPt<NQ>*)d_out,
+                       fr_params(curve), P);
+    hipError_t e = hipGetLastError();
+    (void)hipStreamSynchronize(stream);
+    (void)hipFree(table);
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_srs launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+int synth_srs_dev(int curve, const uint64_t* tau_mont, size_t n, void* d_out, hipStream_t stream) {
+    if (n == 0) return PLONK_OK;
+    const Fr tau = fp_from_limbs<8>((const uint32_t*)tau_mont);
+    if (curve == PLONK_BN254) return synth_srs_t<8>(curve, tau, n, d_out, stream);
+    return synth_srs_t<12>(curve, tau, n, d_out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------- a random SATISFIED circuit
+// The reference's generate_circuit (dispatcher2.rs:1214-1270) builds a Merkle-membership circuit with jellyfish, which is not
+// available here; north_star asks for synthetic random circuits.  One lane per gate j:
+//   * wiring: column i of gate j reads variable P_i(j), P_i a seeded bijection of [0, n) (xor-shift, odd multiplier, offset), so
+//     every variable occurs once per column and the copy constraints are n cycles of length 5 that hop between pseudo-random
+//     gates: (i, j) -> (i+1, P_{i+1}^-1(P_i(j)));
+//   * witness: value(v) = rand_fr(seed, v); wires[i][j] = value(P_i(j)) — equal along every cycle by construction;
+//   * selectors: 12 of the 13 are uniform random, q_c is solved so the gate equation of dispatcher2.rs:465-477 holds;
+//   * public input: uniform on the first num_inputs gates, zero elsewhere (part of the solved equation);
+//   * id_perm[i*n + j] = k_i * w^j (extended_id_permutation), sigma evaluations = id_perm[perm_idx] written directly.
+struct CircuitSynthParams {
+    uint64_t seed, n, num_inputs;
+    uint32_t log_n, shift;
+    uint64_t mul[5], mul_inv[5], off[5];
+    Fr k[5];
+    Fr omega;
+};
+__device__ __forceinline__ uint64_t cs_fwd(const CircuitSynthParams& c, int i, uint64_t j) {
+    const uint64_t mask = c.n - 1;
+    j ^= j >> c.shift;
+    return (j * c.mul[i] + c.off[i]) & mask;
+}
+__device__ __forceinline__ uint64_t cs_inv(const CircuitSynthParams& c, int i, uint64_t v) {
+    const uint64_t mask = c.n - 1;
+    uint64_t j = ((v - c.off[i]) * c.mul_inv[i]) & mask;
+    return j ^ (j >> c.shift);                  // 2 * shift >= log n: the xor-shift is an involution
+}
+
+__global__ void __launch_bounds__(128) synth_circuit_kernel(const CircuitSynthParams c, Fr* __restrict__ wires, Fr* __restrict__ sel, Fr* __restrict__ sigma,
+                                                            Fr* __restrict__ id_perm, uint64_t* __restrict__ perm_idx, Fr* __restrict__ pub,
+                                                            const FrParams P) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= c.n) return;
+    Fr w[5];
+    const Fr wj = fp_pow_u64(c.omega, j, P);
+    for (int i = 0; i < 5; i++) {
+        const uint64_t v = cs_fwd(c, i, j);
+        w[i] = rand_fr_elem(c.seed, v, P);
+        st16(wires + i * c.n + j, w[i]);
+        const int i2 = i == 4 ? 0 : i + 1;
+        const uint64_t j2 = cs_inv(c, i2, v);
+        perm_idx[i * c.n + j] = (uint64_t)i2 * c.n + j2;
+        st16(id_perm + i * c.n + j, fp_mul(c.k[i], wj, P));
+        st16(sigma + i * c.n + j, fp_mul(c.k[i2], fp_pow_u64(c.omega, j2, P), P));
+    }
+    Fr q[13];
+    for (int t = 0; t < 13; t++) q[t] = rand_fr_elem(c.seed + 0x1000 + t, j, P);
+    const Fr pi = j < c.num_inputs ? rand_fr_elem(c.seed + 0x2000, j, P) : fp_zero<8>();
+    const Fr ab = fp_mul(w[0], w[1], P), cd = fp_mul(w[2], w[3], P);
+    Fr acc = pi;
+    for (int t = 0; t < 4; t++) {
+        acc = fp_add(acc, fp_mul(q[t], w[t], P), P);                                  // q_lc
+        const Fr w2 = fp_sqr(w[t], P);
+        acc = fp_add(acc, fp_mul(q[6 + t], fp_mul(fp_sqr(w2, P), w[t], P), P), P);    // q_hash * w^5
+    }
+    acc = fp_add(acc, fp_mul(q[4], ab, P), P);                                        // q_mul
+    acc = fp_add(acc, fp_mul(q[5], cd, P), P);
+    acc = fp_add(acc, fp_mul(q[12], fp_mul(fp_mul(ab, cd, P), w[4], P), P), P);       // q_ecc * abcde
+    acc = fp_sub(acc, fp_mul(q[10], w[4], P), P);                                     // - q_o * e
+    q[11] = fp_neg(acc, P);                                                           // q_c
+    for (int t = 0; t < 13; t++) st16(sel + t * c.n + j, q[t]);
+    st16(pub + j, pi);
+}
+
+static uint64_t inv_odd_u64(uint64_t a) {        // a^-1 mod 2^64 by Newton iteration
+    uint64_t x = a;
+    for (int i = 0; i < 6; i++) x *= 2 - a * x;
+    return x;
+}
+static uint64_t host_splitmix(uint64_t& s) {
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+int synth_circuit_dev(int curve, uint64_t seed, size_t n, size_t num_inputs, const uint64_t* k_mont, const Fr& omega_n, void* d_wires, void* d_sel,
+                      void* d_sigma, void* d_id_perm, void* d_perm_idx, void* d_pub, hipStream_t stream) {
+    CircuitSynthParams c;
+    c.seed = seed; c.n = n; c.num_inputs = num_inputs;
+    c.log_n = 0;
+    while (((size_t)1 << c.log_n) < n) c.log_n++;
+    c.shift = c.log_n ? (c.log_n + 1) / 2 : 1;
+    uint64_t s = seed ^ 0xC1C5EEDull;
+    for (int i = 0; i < 5; i++) {
+        c.mul[i] = host_splitmix(s) | 1;
+        c.mul_inv[i] = inv_odd_u64(c.mul[i]);
+        c.off[i] = host_splitmix(s);
+        c.k[i] = fp_from_limbs<8>((const uint32_t*)(k_mont + 4 * i));
+    }
+    c.omega = omega_n;
+    hipLaunchKernelGGL(synth_circuit_kernel, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, stream, c, (Fr*)d_wires, (Fr*)d_sel, (Fr*)d_sigma,
+                       (Fr*)d_id_perm, (uint64_t*)d_perm_idx, (Fr*)d_pub, fr_params(curve));
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_circuit launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}

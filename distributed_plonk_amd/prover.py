@@ -82,6 +82,7 @@ class Prover:
         self._bufs = []
         self._ws: Dict[str, object] = {}      # named work buffers, allocated by the first proof and reused (hipMalloc of ~100 GiB takes seconds)
         self.timings: Dict[str, float] = {}
+        self.last_polys: Dict[str, object] = {}
 
     # ------------------------------------------------------------------ device buffers
     def _alloc(self, n_fr: int):
@@ -427,6 +428,10 @@ class Prover:
         w.poly_div_linear_dev(d_pp.ptr, PP, zeta_w, d_wit.ptr + PP * 32)
         proof["opening_proof"], proof["shifted_opening_proof"] = self._commit_many([(d_wit.ptr, PP - 1), (d_wit.ptr + PP * 32, PP - 1)])
         tick("round5", t0)
+        # where the committed polynomials live until the next proof reuses the work buffers (post-hoc checks: bench.py re-derives
+        # commitments and evaluations of a finished 2^24-gate proof from them with the CPU oracle)
+        self.last_polys = dict(wire_polys=[(wp[i], WP) for i in range(5)], perm_poly=(d_pp.ptr, PP), split_quot_polys=list(split),
+                               opening_poly=(d_wit.ptr, PP - 1), shifted_opening_poly=(d_wit.ptr + PP * 32, PP - 1))
         if keep:
             proof["_debug"] = dict(perm_product=dbg_prod, perm_poly=d_pp.download((PP, 4)),
                                    quot_poly=self._download(d_quot_ptr, expected + 1), lin_poly=d_lin.download((PP, 4)),

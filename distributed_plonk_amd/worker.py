@@ -358,6 +358,16 @@ class PlonkWorker:
     def synth_bases(self, seed: int, unique: int, n: int, d_out: int):
         check(self.lib.plonk_synth_bases(self.ctx, seed, unique, n, d_out))
 
+    def synth_srs(self, tau: np.ndarray, n: int, d_out: int):
+        """d_out[i] = tau^i * G (x || y), i < n: a commit key with a known trapdoor (tau: Fr limbs, Montgomery)."""
+        check(self.lib.plonk_synth_srs(self.ctx, _ptr(_u64(tau)), n, d_out))
+
+    def synth_circuit(self, seed: int, n: int, num_inputs: int, k: np.ndarray, d_wires: int, d_sel_evals: int, d_sigma_evals: int, d_id_perm: int,
+                      d_perm_idx: int, d_pub_input: int):
+        """A random satisfied TurboPlonk instance generated in HBM (include/plonk_hip.h: plonk_synth_circuit)."""
+        check(self.lib.plonk_synth_circuit(self.ctx, seed, n, num_inputs, _ptr(_u64(k)), d_wires, d_sel_evals, d_sigma_evals, d_id_perm, d_perm_idx,
+                                           d_pub_input))
+
     def field_op(self, field: int, op: int, a: np.ndarray, b: Optional[np.ndarray] = None) -> np.ndarray:
         a = _u64(a)
         b = _u64(b) if b is not None else None

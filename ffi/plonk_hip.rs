@@ -129,6 +129,9 @@ extern "C" {
     pub fn plonk_memset_dev(ctx: *mut plonk_ctx, d_dst: *mut c_void, byte: c_int, bytes: usize) -> c_int;
     pub fn plonk_synth_fr(ctx: *mut plonk_ctx, seed: u64, d_out: *mut c_void, n: usize) -> c_int;
     pub fn plonk_synth_bases(ctx: *mut plonk_ctx, seed: u64, unique: usize, n: usize, d_out: *mut c_void) -> c_int;
+    pub fn plonk_synth_srs(ctx: *mut plonk_ctx, tau: *const u64, n: usize, d_out: *mut c_void) -> c_int;
+    pub fn plonk_synth_circuit(ctx: *mut plonk_ctx, seed: u64, n: usize, num_inputs: usize, k: *const u64, d_wires: *mut c_void, d_selector_evals: *mut c_void,
+                               d_sigma_evals: *mut c_void, d_id_perm: *mut c_void, d_perm_idx: *mut c_void, d_pub_input: *mut c_void) -> c_int;
     pub fn plonk_init_dev(ctx: *mut plonk_ctx, d_bases_xy: *const c_void, n_bases: usize, domain_size: usize, quot_domain_size: usize) -> c_int;
     pub fn plonk_debug_field_op(ctx: *mut plonk_ctx, field: c_int, op: c_int, a: *const u64, b: *const u64, out: *mut u64, n: usize) -> c_int;
     pub fn plonk_set_option(ctx: *mut plonk_ctx, key: *const c_char, value: i64) -> c_int;

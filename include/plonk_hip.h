@@ -69,7 +69,9 @@ typedef int (*plonk_exchange_fn)(void* user, const void* send, void* recv, size_
  * communicator attached, plonk_fft2_prepare(ctx, id, NULL, NULL) performs the all-to-all itself (grouped ncclSend/ncclRecv on the
  * context's stream); the callback form stays for tests and for hosts that bring their own transport.  Two contexts of one
  * process (two streams) need two communicators, created in the same order on every rank, and every rank must issue its
- * collectives in the same order. */
+ * collectives in the same order.  The library chains every collective it issues on a GPU behind the previous one (an event wait on
+ * the issuing stream), whatever communicator it belongs to: collectives of different communicators are never in flight together
+ * (RCCL gives no progress guarantee for that), they still overlap the other contexts' compute. */
 #define PLONK_COMM_ID_BYTES 128
 int plonk_comm_unique_id(void* out_id);
 int plonk_comm_init(plonk_ctx* ctx, const void* id, int rank, int world);
@@ -113,8 +115,9 @@ int plonk_fft_init(plonk_ctx* ctx, uint64_t id, const plonk_fft_workload* worklo
 int plonk_fft1(plonk_ctx* ctx, uint64_t id, uint64_t i, const uint64_t* v, size_t len);
 /* ---- PlonkSlave @4 fft2Prepare + PlonkPeer @0 fftExchange — worker.rs:280-345, 412-438 --------
  * Row pass on every local row, then the all-to-all block transpose.  Collective: every rank calls
- * it for the same id.  exchange == NULL: the context's RCCL communicator (plonk_comm_init) carries the all-to-all; with a
- * single workload and no communicator there is nothing to exchange. */
+ * it for the same id.  Transport precedence: a non-NULL `exchange` callback; else the context's RCCL communicator (plonk_comm_init)
+ * when the task has exactly as many workloads as the communicator has ranks; a single-workload task stays local (nothing to
+ * exchange) whether or not the context joined a communicator; anything else is PLONK_ERR_ARG. */
 int plonk_fft2_prepare(plonk_ctx* ctx, uint64_t id, plonk_exchange_fn exchange, void* user);
 /* ---- PlonkSlave @5 fft2 — worker.rs:347-381 (helper :96-115).  out_cols receives num_cols
  * columns of r elements each (column-major blobs, as the reply of worker.rs:366-376); the task is
@@ -251,6 +254,19 @@ int plonk_synth_fr(plonk_ctx* ctx, uint64_t seed, void* d_out, size_t n);
 /* SRS-like bases in PLONK_BASES_XY layout.  unique > 0: `unique` points k_j*G tiled to n (the
  * distribution of dispatcher.rs:190-196); unique == 0: n pairwise-distinct points A[i%4096] + B[i/4096]. */
 int plonk_synth_bases(plonk_ctx* ctx, uint64_t seed, size_t unique, size_t n, void* d_out);
+/* A KZG commit key with a KNOWN trapdoor: d_out[i] = tau^i * G, i < n (PLONK_BASES_XY).  The reference's universal_setup
+ * (dispatcher2.rs:1278) draws tau and forgets it; keeping it makes commit(f) = f(tau) * G, so a proof can be verified in G1 without
+ * a pairing (oracle/verifier_ref.py) — how bench.py checks a whole 2^24-gate proof.  tau: host Fr, Montgomery. */
+int plonk_synth_srs(plonk_ctx* ctx, const uint64_t* tau, size_t n, void* d_out);
+/* A random SATISFIED TurboPlonk instance of n = 2^k gates, generated in HBM (the reference's generate_circuit, dispatcher2.rs:1214-1270,
+ * needs jellyfish's circuit builder; north_star asks for synthetic random circuits).  Column i of gate j reads variable P_i(j) for
+ * seeded bijections P_i, so the copy constraints are n cycles of length 5 between pseudo-random gates; witness values are uniform
+ * per variable; 12 selectors are uniform and q_c is solved so that the gate equation of dispatcher2.rs:465-477 holds; the first
+ * num_inputs gates carry uniform public inputs.  Outputs (device): wires [5][n] Fr, selector EVALUATIONS [13][n] and sigma
+ * EVALUATIONS [5][n] on the n-point domain (coefficient form = plonk_ntt_dev(.., is_inv = 1)), id_perm [5n] = k_i * w^j
+ * (extended_id_permutation), perm_idx [5n] u64 (perm_i * n + perm_j), pub_input [n].  k: vk.k[0..5], host Fr. */
+int plonk_synth_circuit(plonk_ctx* ctx, uint64_t seed, size_t n, size_t num_inputs, const uint64_t* k, void* d_wires, void* d_selector_evals,
+                        void* d_sigma_evals, void* d_id_perm, void* d_perm_idx, void* d_pub_input);
 /* Use n_bases points already in HBM (PLONK_BASES_XY) as the SRS without a host round trip; they are
  * re-encoded into the library's resident limb form (72 B / 112 B per point), the caller keeps its buffer. */
 int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size,
@@ -259,8 +275,9 @@ int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_
  * field: 0 Fr, 1 Fq.  op: 0 mul, 1 add, 2 sub, 3 to_mont, 4 from_mont, 5 inverse, 6 square.  Host buffers. */
 int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, const uint64_t* b,
                          uint64_t* out, size_t n);
-/* tuning knobs: key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 9), "msm_slice_log" (8..26: MSMs above 2^value points are
- * computed slice by slice and the partial points added; default 26 — process-wide, for tests of the slicing path), "msm_batch_max"
+/* tuning knobs, each stored in the context it is set on (other contexts — also ones driven from other host threads — keep theirs):
+ * key "msm_window" (bits, 0 = auto), "ntt_max_log_r" (<= 9), "msm_slice_log" (8..26: MSMs above 2^value points are
+ * computed slice by slice and the partial points added; default 26, for tests of the slicing path), "msm_batch_max"
  * (scalar vectors per launch set of plonk_commit_many_dev, default 32; 1 = one MSM at a time), "msm_fused_y3", "quotient_fuse"
  * (kernel-formulation experiments). */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
@@ -272,7 +289,8 @@ int plonk_last_kernel_ms(plonk_ctx* ctx, double* out_ms);
  * (off by default).  Names: "ntt_pass_kernel", "ntt_pass_kernel<9>" (per in-LDS size),
  * "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_kernel", "msm_accumulate_redo_kernel", "msm_heavy",
  * "msm_reduce", "quotient_evals_kernel", "perm_terms_kernel", "perm_scan_num", "perm_scan_den_final",
- * "poly_eval_kernel", "poly_lincomb_kernel", "poly_scale_kernel", "poly_div_scan".  total_ms / launches accumulate until reset. */
+ * "poly_eval_kernel", "poly_lincomb_kernel", "poly_scale_kernel", "poly_div_scan", "rccl_alltoall", "rccl_allgather" (the collective
+ * as the stream saw it, waiting for peers included).  total_ms / launches accumulate until reset. */
 int plonk_profile_enable(plonk_ctx* ctx, int on);
 int plonk_profile_reset(plonk_ctx* ctx);
 int plonk_profile_get(plonk_ctx* ctx, const char* name, double* total_ms, uint64_t* launches);

@@ -186,6 +186,8 @@ class CpuWorker:
         v[:] = O.blind(self.curve, v.copy(), n, bl)
 
     def commit_range_dev(self, d_coeffs, start, count):
+        if start < 0 or count < 0 or start > self.bases.shape[0]:       # the C ABI takes size_t and rejects start > n_bases
+            raise ValueError(f"commit_range_dev: start {start}, count {count} against {self.bases.shape[0]} bases")
         count = min(count, self.bases.shape[0] - start)
         if count <= 0:
             return O.commit_polynomial(self.curve, self.bases[:1], np.zeros((1, 4), dtype=np.uint64), inf=np.ones(1, dtype=np.uint8))

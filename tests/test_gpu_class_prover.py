@@ -63,7 +63,7 @@ def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
-@pytest.mark.parametrize("log_n,G", [(5, 2), (8, 4), (9, 8)])
+@pytest.mark.parametrize("log_n,G", [(5, 2), (8, 4), (9, 8), (5, 4), (4, 8)])     # the last two: polynomials that END before a rank's key slice (empty shards)
 def test_class_prover_sharded_commit_key(oracle, curve, cid, log_n, G):
     """The SRS sharded G ways like the reference's (dispatcher2.rs:260-266): rank s holds only bases [s*K/G, (s+1)*K/G) and commits
     the coefficients of every polynomial whose index falls in that slice — incl. polynomials shorter than the key (n, n + 2, n + 3
