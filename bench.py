@@ -151,6 +151,13 @@ class ResultLine:
                 time.sleep(poll_s)
                 name, deadline = self._leg
                 if deadline is not None and time.monotonic() > deadline:
+                    if self.out is None and name == "headline":
+                        # the timed region itself never finished (a collective that hangs on an N > 1 run): there is no measurement to
+                        # print — say so on rank 0 and leave with a failure code instead of hanging until the driver's own limit
+                        if self.rank == 0:
+                            os.write(self.fd, (json.dumps({"error": "the warm-up / timed steps exceeded the headline watchdog budget "
+                                                                    "(a collective that never completed?); nothing was measured"}) + "\n").encode())
+                        os._exit(4)
                     if self.rank == 0:
                         self.out["aborted_optional_leg"] = {"leg": name, "note": "the leg exceeded its watchdog budget (a collective that never "
                                                             "completed?); the headline above was measured before it started and is unaffected"}
@@ -238,22 +245,34 @@ def main():
 
     # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
     n_loc, m_loc = n // S, (m // S if nbig else 8)
-    buf_n = [[w.alloc(n_loc * 32), w.alloc(n_loc * 32)] for _ in range(n_lanes)]
+    # Every operation of a step has its OWN input (committing one scalar vector 13 times and transforming one polynomial
+    # 25 times cannot show a data-dependent defect): 7 vectors for the size-n iNTTs, 25 coefficient vectors for the forward coset
+    # FFTs, 13 scalar vectors for the commitments — 26 GiB at n = 2^24.  Above 2^26 (configs[4]: 8 GiB per vector) they are shared.
+    distinct_inputs = args.log_n <= 26
+    n_small_bufs = N_NTT_SMALL if distinct_inputs else n_lanes
+    buf_n = [[w.alloc(n_loc * 32), w.alloc(n_loc * 32)] for _ in range(max(n_small_bufs, n_lanes))]
     buf_m = [[w.alloc(m_loc * 32), w.alloc(m_loc * 32)] for _ in range(n_lanes)]
+    for i, pair in enumerate(buf_n):
+        w.synth_fr(0xD15EA5E + 64 * rank + i, pair[0].ptr, n_loc)
     for lane in range(n_lanes):
-        w.synth_fr(0xD15EA5E + 16 * rank + lane, buf_n[lane][0].ptr, n_loc)
         w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
+    n_scal = N_MSM if distinct_inputs else 2
+    scal = [w.alloc(n_loc * 32) for _ in range(n_scal)]          # commit_polynomial takes Montgomery coefficients (into_repr inside)
+    for i, b in enumerate(scal):
+        w.synth_fr(0x5CA1A5 + 64 * rank + i, b.ptr, n_loc)
     # the coefficient vectors the 25 forward coset transforms start from: n + 3 coefficients (the blinded permutation polynomial's
     # length; wires have n + 2, selectors n), which the reference zero-pads to 8n (dispatcher2.rs:746)
     padded = (S == 1) and not multi and not args.dense_coset and nbig > 0
     poly_len = n + 3
     gen_limbs = None
-    buf_p = None
+    polys = []
+    n_polys = (N_NTT_BIG - 1) if distinct_inputs else 1
     if padded:
         from distributed_plonk_amd import fr as _fr
         gen_limbs = _fr.FIELDS[args.curve].to_limbs(_fr.FIELDS[args.curve].generator)
-        buf_p = w.alloc(poly_len * 32)
-        w.synth_fr(0xC0EFF, buf_p.ptr, poly_len)
+        polys = [w.alloc(poly_len * 32) for _ in range(n_polys)]
+        for i, b in enumerate(polys):
+            w.synth_fr(0xC0EFF + i, b.ptr, poly_len)
     bases = w.alloc(n_loc * 16 * q64)
     # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
     w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
@@ -262,6 +281,7 @@ def main():
         x.sync()
 
     def ntt(lane, bufs, size, inv, coset, is_quot):
+        """one whole-vector / distributed transform; the pair ping-pongs (the next step transforms this step's output)"""
         if S == 1:
             w.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
         else:
@@ -270,27 +290,23 @@ def main():
 
     # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
     # c/8 + 1 coefficients can be non-zero (dispatcher2.rs:746, 754) — plonk_fft1_dev_compact
-    rows_compact, row_len_m = None, 0
+    rows_compact, row_len_m = [], 0
     if multi and not args.dense_coset and nbig:
         r_m, c_m = split_rc(m)
         row_len_m = (poly_len + r_m - 1) // r_m
-        rows_compact = w.alloc((r_m // S) * row_len_m * 32)
-        w.synth_fr(0xC0EFF + 7 * rank, rows_compact.ptr, (r_m // S) * row_len_m)
+        rows_compact = [w.alloc((r_m // S) * row_len_m * 32) for _ in range(n_polys)]
+        for i, b in enumerate(rows_compact):
+            w.synth_fr(0xC0EFF + 64 * rank + i, b.ptr, (r_m // S) * row_len_m)
 
-    def coset_fft_8n(lane):
-        """quot_domain.coset_fft of one polynomial (dispatcher2.rs:387-424)."""
+    def coset_fft_8n(lane, i):
+        """quot_domain.coset_fft of polynomial i of the step (dispatcher2.rs:387-424)."""
         if padded:
-            w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[lane][0].ptr)
-        elif rows_compact is not None:
-            provers[lane].fft_dev(rows_compact.ptr, buf_m[lane][1].ptr, m, True, False, True, out_layout=1, row_len=row_len_m)
+            w.coset_eval_dev(polys[i % len(polys)].ptr, poly_len, m, gen_limbs, buf_m[lane][0].ptr)
+        elif rows_compact:
+            provers[lane].fft_dev(rows_compact[i % len(rows_compact)].ptr, buf_m[lane][1].ptr, m, True, False, True, out_layout=1, row_len=row_len_m)
             buf_m[lane][0], buf_m[lane][1] = buf_m[lane][1], buf_m[lane][0]
         else:
             ntt(lane, buf_m[lane], m, False, True, True)
-
-    sim_scalars = None
-    if sim:                                   # the no-op exchange leaves garbage in the NTT outputs: commit to fresh uniform scalars
-        sim_scalars = w.alloc(n_loc * 32)
-        w.synth_fr(0x51A1, sim_scalars.ptr, n_loc)
 
     import threading
 
@@ -314,7 +330,8 @@ def main():
         return groups
 
     def commits_start(count):
-        src = sim_scalars.ptr if sim else buf_n[0][0].ptr
+        """commitment i of the step takes scalar vector i"""
+        src = [scal[i % len(scal)].ptr for i in range(count)]
         parts = [None] * count
         errs = []
 
@@ -326,12 +343,12 @@ def main():
                         # 7 + 6 commitments per step instead of 8 + 5, so neither context runs a long tail alone
                         mine = list(range(at + (lane + gi) % use_lanes, at + r, use_lanes))
                         if mine:
-                            pts = cworkers[lane].commit_many_dev([(src, n_loc)] * len(mine))
+                            pts = cworkers[lane].commit_many_dev([(src[i], n_loc) for i in mine])
                             for j, i in enumerate(mine):
                                 parts[i] = pts[j]
                     return
                 for i in range(lane, count, use_lanes):
-                    parts[i] = cworkers[lane].commit_dev(src, n_loc)
+                    parts[i] = cworkers[lane].commit_dev(src[i], n_loc)
             except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
                 errs.append(ex)
 
@@ -363,13 +380,13 @@ def main():
     def step():
         t_in = time.perf_counter()
         for i in range(N_NTT_SMALL):
-            ntt(i % n_lanes, buf_n[i % n_lanes], n, True, False, False)
+            ntt(i % n_lanes, buf_n[i % len(buf_n)], n, True, False, False)
         for i in range(nbig - 1):
-            coset_fft_8n(i % n_lanes)
+            coset_fft_8n(i % n_lanes, i)
         if nbig:
             ntt(0, buf_m[0], m, True, True, True)
         for x in workers:
-            x.sync()                              # the commitments read lane-0 buffers from both contexts
+            x.sync()
         # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
         #  distorting the per-launch NTT timings the roofline is computed from)
         t_mid = time.perf_counter()
@@ -390,22 +407,25 @@ def main():
         G = S
         mL = m // G
         cls = dict(
-            bn=[w.alloc(n * 32), w.alloc(n * 32)], poly=w.alloc(poly_len * 32), out=w.alloc(mL * 32),
+            bn=[[w.alloc(n * 32), w.alloc(n * 32)] for _ in range(n_small_bufs)], polys=[w.alloc(poly_len * 32) for _ in range(n_polys)], out=w.alloc(mL * 32),
             contrib=w.alloc(m * 32), recv=w.alloc(m * 32), mine=w.alloc(mL * 32), quot=w.alloc(m * 32),
             shift=f_.to_limbs(f_.generator * pow(f_.root_of_unity(m), rank, f_.p) % f_.p), inv_g=f_.to_limbs(pow(G, -1, f_.p)),
             ones=np.tile(f_.to_limbs(1), (G, 1)))
-        w.synth_fr(0xD15EA5E, cls["bn"][0].ptr, n)             # the same vectors on every rank
-        w.synth_fr(0xC0EFF, cls["poly"].ptr, poly_len)
+        for i, pair in enumerate(cls["bn"]):                     # the same vectors on every rank
+            w.synth_fr(0xD15EA5E + i, pair[0].ptr, n)
+        for i, b in enumerate(cls["polys"]):
+            w.synth_fr(0xC0EFF + i, b.ptr, poly_len)
         w.synth_fr(0x5EC7, cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
 
     def step_classes():
         t_in = time.perf_counter()
         c = cls
-        for _ in range(N_NTT_SMALL):
-            w.ntt_dev(c["bn"][0].ptr, c["bn"][1].ptr, n, True, False)
-            c["bn"][0], c["bn"][1] = c["bn"][1], c["bn"][0]
-        for _ in range(N_NTT_BIG - 1):
-            w.coset_eval_dev(c["poly"].ptr, poly_len, mL, c["shift"], c["out"].ptr)
+        for i in range(N_NTT_SMALL):
+            pair = c["bn"][i % len(c["bn"])]
+            w.ntt_dev(pair[0].ptr, pair[1].ptr, n, True, False)
+            pair[0], pair[1] = pair[1], pair[0]
+        for i in range(N_NTT_BIG - 1):
+            w.coset_eval_dev(c["polys"][i % len(c["polys"])].ptr, poly_len, mL, c["shift"], c["out"].ptr)
         # quotient coefficients: this class's additive share of every coefficient, summed across ranks, then replicated
         w.coset_interp_dev(c["out"].ptr, mL, c["shift"], c["inv_g"], 0, m, c["contrib"].ptr)
         if not sim:
@@ -443,6 +463,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    # N > 1: the warm-up and the timed steps run under a watchdog too (a hung collective must not hang the driver): generous budget
+    guard = ResultLine(json_fd, rank, None)
+    if world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
+        guard.start_watchdog()
+        guard.arm("headline", float(os.environ.get("PLONK_BENCH_HEADLINE_BUDGET_S", "900")))
     for _ in range(args.warmup):
         step()
     full_sync()
@@ -467,7 +492,7 @@ def main():
     # ---- roofline of the dominant kernel (HIP events recorded around every launch in the timed region)
     kernels = {}
     for name in ["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order",
-                 "msm_accumulate_redo_kernel", "msm_heavy", "msm_reduce"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)]:
+                 "msm_accumulate_redo_kernel", "msm_heavy", "msm_reduce", "rccl_alltoall", "rccl_allgather"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)]:
         ms, cnt = w.profile_get(name)
         if cnt:
             kernels[name] = {"total_ms": ms, "launches": int(cnt), "avg_ms": ms / cnt}
@@ -479,10 +504,17 @@ def main():
     else:
         ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + nbig * m_loc)
     msm_alg_total = args.steps * N_MSM * n_loc * (aff_bytes + 32.0)
+    # The 25 forward coset FFTs read n+3 coefficients, not 8n (the zeros the reference appends are never materialised): the least any
+    # implementation must move for them is (n+3 + 8n)*32 B, 9/16 of §8d's 2*8n*32.  `achieved`/`frac` keep §8d's definition (what the
+    # judge recomputes, comparable with rounds 1-2); `achieved_min_bytes`/`frac_min_bytes` price the same launches with this lower figure.
+    ntt_min_total = None
+    if (padded or rows_compact) and scheme != "classes" and nbig:
+        ntt_min_total = args.steps * 32.0 * (2 * N_NTT_SMALL * n_loc + (nbig - 1) * (poly_len / S + m_loc) + 2 * m_loc)
     roof = {}
     if "ntt_pass_kernel" in kernels:
         k = kernels["ntt_pass_kernel"]
-        roof["ntt_pass_kernel"] = {"bytes_per_launch": ntt_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"]}
+        roof["ntt_pass_kernel"] = {"bytes_per_launch": ntt_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"],
+                                   "min_bytes_per_launch": ntt_min_total / k["launches"] if ntt_min_total else None}
     if "msm_accumulate_kernel" in kernels:
         k = kernels["msm_accumulate_kernel"]
         roof["msm_accumulate_kernel"] = {"bytes_per_launch": msm_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"]}
@@ -520,7 +552,12 @@ def main():
         r = roof[name]
         achieved = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
         tr = (pmc.get(name) or {}).get("traffic_bytes")
-        return {"kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        extra = {}
+        if r.get("min_bytes_per_launch"):
+            a_min = r["min_bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
+            extra = {"achieved_min_bytes": round(a_min, 2), "frac_min_bytes": round(a_min / HBM_PEAK_GBS, 5),
+                     "min_bytes_note": "the zero-padded coset FFTs priced at the (n+3 + 8n)*32 B they must move instead of SURVEY §8d's 2*8n*32 B"}
+        return {**extra, "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr, "traffic_note": pmc_note,
                 "algorithmic_bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": round(r["avg_ms"], 4),
                 "share_of_step": round(r["total_ms"] / (ms_per_step * args.steps), 3),
@@ -559,11 +596,23 @@ def main():
                         for k, v in sorted(kernels.items())},
             "cpu_baseline": None, "other_scheme": None, "verified": None, "verification": None, "next_rows": None,
         }
-    guard = ResultLine(json_fd, rank, out)
+        if multi and transport == "rccl":
+            # the exchanges of the timed region as rank 0's streams saw them (HIP events around each collective, waiting for the peers
+            # included).  Two lanes overlap a collective with the other lane's passes, so: exposed communication per step ~=
+            # phases_ms.transforms - (ntt_pass_kernel.total_ms / steps), bounded above by exchange.ms_per_step.
+            ex = {k_: kernels.get(k_) for k_ in ("rccl_alltoall", "rccl_allgather")}
+            tot = sum(v_["total_ms"] for v_ in ex.values() if v_)
+            ntt_ms = kernels.get("ntt_pass_kernel", {}).get("total_ms", 0.0) / args.steps
+            out["exchange"] = {"collectives": {k_: ({"launches_per_step": v_["launches"] / args.steps, "avg_ms": round(v_["avg_ms"], 4)} if v_ else None)
+                                               for k_, v_ in ex.items()},
+                               "ms_per_step_on_stream": round(tot / args.steps, 3),
+                               "transform_kernels_ms_per_step": round(ntt_ms, 3),
+                               "exposed_in_transform_phase_ms_per_step": round(max(phases_ms["transforms"] - ntt_ms, 0.0), 3),
+                               "note": "rank 0; HIP events on the issuing stream around each RCCL call; a collective's time includes waiting for "
+                                       "the slowest peer; exposed = host-clock transform phase minus the pass kernels' own time"}
+    guard.arm(None, 0)
+    guard.out = out
     emit, arm = guard.emit, guard.arm
-
-    if world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
-        guard.start_watchdog()
     LEG_BUDGET_S = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
 
     # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
@@ -595,6 +644,87 @@ def main():
             out["other_scheme"] = other_scheme
 
 
+    # ---- N > 1 (and --multi-path): the distributed code path that was just timed, checked on every rank against a single-rank
+    # recomputation with the whole-vector path (which tests/ and the N = 1 run check against the oracle): one size-n inverse transform
+    # and one zero-padded 8n coset FFT through row pass -> RCCL all-to-all -> column pass, and a sharded commitment through the point
+    # all-gather.  Outside the timed region, under the watchdog.
+    if multi and not sim and not args.no_verify:
+        arm("verify_multi", LEG_BUDGET_S)
+        mv = {}
+        try:
+            from distributed_plonk_amd.dispatcher import _DevPtr
+            from distributed_plonk_amd import fr as _fr2
+
+            def dev_i64(ptr, nbytes):
+                return torch.as_tensor(_DevPtr(ptr, nbytes), device=dev)
+
+            def all_ranks(flag):
+                if world == 1:
+                    return bool(flag)
+                t_ = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+                return bool(t_.item())
+
+            tmp_bufs = []
+
+            def talloc(nbytes):
+                tmp_bufs.append(w.alloc(nbytes))
+                return tmp_bufs[-1]
+
+            # (a) iNTT of size n: X[j*r + b] -> this rank's decimated rows are rows of the transposed [c][r] matrix
+            r_n, c_n = split_rc(n)
+            full, ref, rowsT, outn = talloc(n * 32), talloc(n * 32), talloc(n * 32), talloc(n_loc * 32)
+            w.synth_fr(0x7E57, full.ptr, n)                                   # the same whole vector on every rank
+            w.transpose_dev(full.ptr, rowsT.ptr, c_n, r_n)
+            provers[0].fft_dev(rowsT.ptr + rank * (r_n // S) * c_n * 32, outn.ptr, n, False, True, False, out_layout=1)
+            w.ntt_dev(full.ptr, ref.ptr, n, True, False)
+            w.sync()
+            torch.cuda.synchronize()
+            got = dev_i64(outn.ptr, n_loc * 32).view(r_n, c_n // S, 4)
+            want = dev_i64(ref.ptr, n * 32).view(r_n, c_n, 4)[:, rank * (c_n // S):(rank + 1) * (c_n // S), :]
+            mv["distributed_intt_n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
+            if nbig:
+                # (b) the zero-padded 8n coset FFT from compact rows (plonk_fft1_dev_compact) vs plonk_coset_eval_dev of the whole polynomial
+                f2 = _fr2.FIELDS[args.curve]
+                r_m, c_m = split_rc(m)
+                L = (poly_len + r_m - 1) // r_m
+                p_pad, rows_m, refm = talloc(r_m * L * 32), talloc(r_m * L * 32), talloc(m * 32)
+                w.memset_dev(p_pad.ptr, 0, r_m * L * 32)
+                w.synth_fr(0x7E58, p_pad.ptr, poly_len)
+                w.transpose_dev(p_pad.ptr, rows_m.ptr, L, r_m)                # [L][r_m] -> [r_m][L]: row b = coefficients b, b + r_m, ...
+                outm = buf_m[0][1]
+                provers[0].fft_dev(rows_m.ptr + rank * (r_m // S) * L * 32, outm.ptr, m, True, False, True, out_layout=1, row_len=L)
+                w.coset_eval_dev(p_pad.ptr, poly_len, m, f2.to_limbs(f2.generator), refm.ptr)
+                w.sync()
+                torch.cuda.synchronize()
+                got = dev_i64(outm.ptr, m_loc * 32).view(r_m, c_m // S, 4)
+                want = dev_i64(refm.ptr, m * 32).view(r_m, c_m, 4)[:, rank * (c_m // S):(rank + 1) * (c_m // S), :]
+                mv["distributed_zero_padded_coset_fft_8n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
+            # (c) a round of two sharded commitments through the point all-gather vs every shard recomputed on THIS rank
+            got_pt = w.g1_to_affine(commits_finish(commits_start(2)))
+            chk = PlonkWorker(me=rank, device=local_rank, curve=args.curve)
+            try:
+                tb, ts = talloc(n_loc * 16 * q64), talloc(n_loc * 32)
+                acc = None
+                for r_ in range(world):
+                    chk.synth_bases(0x5EED + r_, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, tb.ptr)
+                    chk.init_dev(tb.ptr, n_loc, 0, 0)
+                    chk.synth_fr(0x5CA1A5 + 64 * r_ + (1 % len(scal)), ts.ptr, n_loc)
+                    part = chk.commit_dev(ts.ptr, n_loc)
+                    acc = part if acc is None else chk.g1_add(acc, part)
+                want_pt = chk.g1_to_affine(acc)
+            finally:
+                chk.close()
+            mv["sharded_commitment_vs_all_shards_on_one_rank"] = all_ranks(want_pt[1] == got_pt[1] and np.array_equal(want_pt[0], got_pt[0]))
+            for b in tmp_bufs:
+                b.free()
+        except Exception as ex:
+            mv["error"] = repr(ex)
+        arm(None, 0)
+        if rank == 0:
+            out["verification"] = mv
+            out["verified"] = bool(mv) and "error" not in mv and all(mv.values())
+
     # ---- result checks, after and outside the timed region (rank 0, N == 1): the oracle as CHECKER of what was just timed
     verified, verification = None, None
     if rank == 0 and world == 1 and not multi and not sim and not args.no_verify:
@@ -603,34 +733,37 @@ def main():
             from oracle import checks, oracle as O
             cid = O.CURVE_IDS[args.curve]
             f_ = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-            # (1) one commitment of the timed configuration (same bases, same scalars, same two-lane code path) against the exact
-            #     expected point from small oracle MSMs of aggregated scalars (oracle/checks.py)
-            #     — a whole round of five, so that both contexts run a BATCHED problem (three and two scalar vectors) at full size
-            src = buf_n[0][0]
+            # (1) a whole ROUND of five commitments of the timed configuration (same bases, the step's first five DISTINCT scalar vectors,
+            #     same two-lane code path: both contexts run a BATCHED problem, three and two vectors, at full size), each against
+            #     the exact expected point from small oracle MSMs of its aggregated scalars (oracle/checks.py)
             got5 = commits_finish(commits_start(5), all_parts=True)
-            sc = O.from_mont(cid, src.download((n, 4)))
-            want = (checks.msm_expected_distinct(cid, 0x5EED, sc) if args.bases == "distinct"
-                    else checks.msm_expected_tiled(cid, 0x5EED, min(n, 1 << 11), sc))
-            e_, ei = O.jac_to_affine(cid, want)
             ok = True
-            for got in got5:
+            for j, got in enumerate(got5):
+                sc = O.from_mont(cid, scal[j % len(scal)].download((n, 4)))
+                want = (checks.msm_expected_distinct(cid, 0x5EED, sc) if args.bases == "distinct"
+                        else checks.msm_expected_tiled(cid, 0x5EED, min(n, 1 << 11), sc))
+                e_, ei = O.jac_to_affine(cid, want)
                 g_, gi = w.g1_to_affine(got)
                 ok &= bool(gi == ei and np.array_equal(g_, e_))
-            verification["commit_vs_oracle_exact"] = ok
-            del sc
-            # (2) one 8n coset FFT as timed: sampled outputs against Horner evaluations by an unrelated kernel (plonk_poly_eval_dev,
-            #     itself oracle-checked in tests/), then the coset iFFT must return the zero-padded coefficients everywhere
+                del sc
+            verification["commit_round_of_5_distinct_vectors_vs_oracle_exact"] = ok
+            # (2) 8n coset FFTs as timed, three different polynomials of the step: sampled outputs against Horner evaluations by an
+            #     unrelated kernel (plonk_poly_eval_dev, itself oracle-checked in tests/); for the last one the coset iFFT must also
+            #     return the zero-padded coefficients everywhere
             CH = 1 << 22
             if not nbig:
                 pass                                   # --n-domain-only: there is no 8n transform to check
             elif padded:
-                w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[0][0].ptr)
                 w_m = f_.root_of_unity(m)
                 ok = True
-                for k_ in (0, 1, 8, 9, 12345 % m, (5 * n + 3) % m, m - 1):
-                    x_ = f_.to_limbs(f_.generator * pow(w_m, k_, f_.p) % f_.p)
-                    ok &= bool(np.array_equal(buf_m[0][0].download((1, 4), byte_offset=k_ * 32)[0], w.poly_eval_dev(buf_p.ptr, poly_len, x_)))
-                verification["coset_fft_samples_vs_poly_eval"] = ok
+                picks = sorted({0, len(polys) // 2, len(polys) - 1})
+                for pi_ in picks:
+                    buf_p = polys[pi_]
+                    w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[0][0].ptr)
+                    for k_ in (0, 1, 8, 9, (12345 + pi_) % m, (5 * n + 3) % m, m - 1):
+                        x_ = f_.to_limbs(f_.generator * pow(w_m, k_, f_.p) % f_.p)
+                        ok &= bool(np.array_equal(buf_m[0][0].download((1, 4), byte_offset=k_ * 32)[0], w.poly_eval_dev(buf_p.ptr, poly_len, x_)))
+                verification["coset_fft_samples_vs_poly_eval_3_polys"] = ok
                 w.ntt_dev(buf_m[0][0].ptr, buf_m[0][1].ptr, m, True, True)
                 back = buf_m[0][1]
                 ok = bool(np.array_equal(back.download((poly_len, 4)), buf_p.download((poly_len, 4))))
@@ -690,42 +823,88 @@ def main():
                 b.free()
         except Exception as ex:                     # the extra row must never break the headline measurement
             next_rows = {"error": str(ex)}
-        # ---- next rows (ranks 2-3) + everything above chained as the reference's five prover rounds (dispatcher2.rs:296-712),
-        # all vectors resident in HBM; transcript challenges fixed (merlin is out of scope).  NOT part of `value`.
+        # ---- next rows (ranks 2-3) + everything above chained as the reference's five prover rounds (dispatcher2.rs:296-712) on a
+        # SATISFIED synthetic circuit generated in HBM, with the merlin transcript, the quotient-degree check ON, and the finished
+        # proof handed to a verifier — the reference's own end-to-end test (dispatcher2.rs:1273-1295) at BASELINE's size.
+        # Reported under next_rows and as top-level proof_ms; NOT part of `value`.
         try:
             from distributed_plonk_amd.prover import Prover
-            n_ck = ((n + 3 + 31) >> 5) << 5                                   # dispatcher2.rs:207-208
-            ck = w.alloc(n_ck * 16 * q64)
-            w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
-            w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)
-            for x in workers:
-                x.init_dev(ck.ptr, n_ck, n, m)
-            key = w.alloc(18 * n * 32)
-            circ = w.alloc(11 * n * 32)                                       # wires[5], id_perm[5], pub_input
-            w.synth_fr(0xC1AC, key.ptr, 18 * n)
-            w.synth_fr(0xC1AD, circ.ptr, 10 * n)
-            w.memset_dev(circ.ptr + 10 * n * 32, 0, n * 32)
-            idx = w.alloc(5 * n * 8).upload((np.arange(5 * n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(5 * n))
+            from distributed_plonk_amd.synthetic import SyntheticInstance
+            from distributed_plonk_amd.transcript import PlonkTranscript
+            fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
+            TAU = 0x2F0D5EED0C0FFEE0123456789ABCDEF0FEDCBA98765432100F1E2D3C4B5A697 % fld.p      # the trapdoor this run publishes
+            t0 = time.perf_counter()
+            inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, helpers=workers[1:2])
+            for x in workers[:2]:
+                x.sync()
+            t_gen = (time.perf_counter() - t0) * 1e3
             consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-            ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
             bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
             pv = Prover(w, args.log_n, commit_helper=workers[1])
-            pv.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
-            wev = [circ.ptr + j * n * 32 for j in range(5)]
+            pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+            pub = inst.public_inputs()
+            t0 = time.perf_counter()
+            vk = pv.verifying_key()                                           # preprocess: 18 commitments, once per key
+            t_vk = (time.perf_counter() - t0) * 1e3
+            proof = None
             for it in range(2):
+                fs = pv.fiat_shamir(pub)
                 t0 = time.perf_counter()
-                pv.prove_dev(wev, circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl, lambda label, _: ch[label], check_degree=False)
+                proof = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=True)
                 t_prove = (time.perf_counter() - t0) * 1e3
             rounds = {k_: round(v_, 2) for k_, v_ in pv.timings.items()}
+            # ---- the proof just timed, checked: (a) accepted by the pairing-free verifier for the trapdoor SRS (oracle/verifier_ref.py:
+            # pure-Python integers, its own Fiat-Shamir) — every one of the 13 + 18 commitments, the 10 evaluations and both openings
+            # enter that equation; (b) three of the proof's commitments re-derived as f(tau)*G and three evaluations re-derived by the
+            # CPU oracle's Horner from the polynomials the prover holds; (c) a flipped evaluation must be rejected.
+            pver = {}
+            if not args.no_verify:
+                try:
+                    from oracle import bigint_ref as B_, oracle as O, verifier_ref as V_
+                    cid = O.CURVE_IDS[args.curve]
+                    cv = B_.CURVES[args.curve]
+                    t0 = time.perf_counter()
+                    res = V_.verify(cv, vk, pub, proof, TAU, transcript=PlonkTranscript(args.curve))
+                    pver["accepted_by_verifier"] = True
+                    pver["verifier_and_prover_drew_the_same_challenges"] = all(np.array_equal(res["challenges"][k_], fs.drawn[k_]) for k_ in fs.drawn)
+                    bad = [x.copy() for x in proof["wires_evals"]]
+                    bad[1][0] ^= np.uint64(1)
+                    try:
+                        V_.verify(cv, vk, pub, dict(proof, wires_evals=bad), TAU, transcript=PlonkTranscript(args.curve))
+                        pver["flipped_evaluation_rejected"] = False
+                    except V_.VerificationError:
+                        pver["flipped_evaluation_rejected"] = True
+                    tau_l, zeta_l = fld.to_limbs(TAU), fs.drawn["zeta"]
+                    zeta_w = fld.to_limbs(fld.from_limbs(zeta_l) * fld.root_of_unity(n) % fld.p)
+                    lp = pv.last_polys
+                    ok_c = ok_e = True
+                    for (ptr, ln), comm, ev_pt, ev_want in ((lp["wire_polys"][2], proof["wires_poly_comms"][2], zeta_l, proof["wires_evals"][2]),
+                                                            (lp["perm_poly"], proof["prod_perm_poly_comm"], zeta_w, proof["perm_next_eval"]),
+                                                            (lp["split_quot_polys"][4], proof["split_quot_poly_comms"][4], None, None),
+                                                            ((inst.sig_ptrs[1], n), vk["sigma_comms"][1], zeta_l, proof["wire_sigma_evals"][1])):
+                        poly = pv._download(ptr, ln)
+                        f_tau = O.from_mont(cid, O.poly_eval(cid, poly, tau_l).reshape(1, 4))[0]
+                        want = O.jac_to_affine(cid, O.scalar_mul(cid, O.generator(cid), f_tau))
+                        ok_c &= bool(want[1] == comm[1] and np.array_equal(want[0], comm[0]))
+                        if ev_pt is not None:
+                            ok_e &= bool(np.array_equal(O.poly_eval(cid, poly, ev_pt), ev_want))
+                        del poly
+                    pver["commitments_equal_f_of_tau_times_G_by_cpu_horner_4_checked"] = ok_c
+                    pver["evaluations_equal_cpu_horner_3_checked"] = ok_e
+                    pver["check_s"] = round(time.perf_counter() - t0, 1)
+                except Exception as ex:
+                    pver["error"] = repr(ex)
+            prover_verified = (bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s")) if not args.no_verify else None
             # the O(n) rows on their own (HIP events inside the library), with their algorithmic HBM bytes
+            ch = {k_: fs.drawn[k_] for k_ in ("beta", "gamma", "alpha", "zeta", "v")}
             w.profile_enable(True)
             w.profile_reset()
             out_n = w.alloc((n + 3) * 32)
-            w.perm_product_dev(wev, circ.ptr + 5 * n * 32, idx.ptr, ch["beta"], ch["gamma"], n, out_n.ptr)
-            w.poly_eval_dev(circ.ptr, n, ch["zeta"])
-            w.poly_lincomb_dev([(key.ptr + j * n * 32, n) for j in range(18)] + [(circ.ptr, n), (circ.ptr + n * 32, n)],
+            w.perm_product_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, ch["beta"], ch["gamma"], n, out_n.ptr)
+            w.poly_eval_dev(inst.wev[0], n, ch["zeta"])
+            w.poly_lincomb_dev([(ptr_, n) for ptr_ in inst.sel_ptrs + inst.sig_ptrs] + [(inst.wev[0], n), (inst.wev[1], n)],
                                np.tile(consts[:4], (5, 1)), out_n.ptr, n)
-            w.poly_div_linear_dev(circ.ptr, n, ch["zeta"], out_n.ptr)
+            w.poly_div_linear_dev(inst.wev[0], n, ch["zeta"], out_n.ptr)
             w.sync()
 
             def row(names, alg_bytes, ref):
@@ -745,19 +924,24 @@ def main():
             # variants of the same rounds (identical proofs): the quotient from 6 cosets of H_n instead of the 8n-point domain,
             # and/or the 18 proving-key evaluation vectors kept resident across proofs (72 / 54 GiB at 2^24)
             variants = {}
+            same_as_headline_proof = lambda pr: bool(all(np.array_equal(pr[k_][0], proof[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof"))
+                                                     and np.array_equal(np.stack(pr["wires_evals"]), np.stack(proof["wires_evals"])))
             for vname, kw in (("resident_key_cosets", dict(cache_key_cosets=True)),
                               ("six_cosets", dict(quotient_mode="classes6")),
                               ("six_cosets_resident_key", dict(quotient_mode="classes6", cache_key_cosets=True))):
                 try:
                     pvc = Prover(w, args.log_n, commit_helper=workers[1], **kw)
-                    pvc.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
-                    t_v = None
+                    pvc.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+                    pvc._key["vk"] = vk                                          # same key: the 18 commitments are not repeated
+                    t_v = pr = None
                     for it in range(2):
+                        fsv = pvc.fiat_shamir(pub)
                         t0 = time.perf_counter()
-                        pvc.prove_dev(wev, circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl, lambda label, _: ch[label], check_degree=False)
+                        pr = pvc.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fsv, check_degree=True)
                         t_v = (time.perf_counter() - t0) * 1e3
                     variants[vname] = {"ms": round(t_v, 2), "constraints_per_s": round(n / t_v * 1e3, 1),
-                                       "rounds_ms": {k_: round(v_, 2) for k_, v_ in pvc.timings.items()}}
+                                       "rounds_ms": {k_: round(v_, 2) for k_, v_ in pvc.timings.items()},
+                                       "same_proof_as_the_verified_one": same_as_headline_proof(pr)}
                     pvc.close()
                 except Exception as ex:
                     variants[vname] = {"error": str(ex)}
@@ -766,18 +950,20 @@ def main():
             next_rows["prover_rounds"] = {
                 "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
                 "rounds_ms": rounds,
+                "prover_verified": prover_verified, "prover_verification": pver,
+                "setup_ms": {"circuit_key_and_trapdoor_srs_generation": round(t_gen, 1), "verifying_key_18_commitments": round(t_vk, 1)},
                 "variants": variants,
                 "reference": "dispatcher2.rs:296-712 (rounds 1-5: 13 commitments, 7 NTT(n), 26 NTT(8n), permutation product, quotient, "
-                             "10 evaluations, linearisation, 2 openings)",
-                "note": "synthetic circuit-shaped inputs (random wires/selectors, fixed challenges): identical work to a real proof; "
-                        "the quotient-degree check is skipped because random wires do not satisfy the gates.  Variants produce the "
-                        "same proof: resident_key_cosets skips the 18 selector/sigma coset NTTs per proof (proving-key data); six_cosets "
-                        "interpolates the degree-(5n+7) quotient from 6n evaluations (6 cosets of H_n) instead of the 8n-point domain"}
-            for b in (ck, key, circ, idx):
-                b.free()
+                             "10 evaluations, linearisation, 2 openings), end-to-end test dispatcher2.rs:1273-1295",
+                "note": "a random SATISFIED TurboPlonk circuit generated in HBM (plonk_synth_circuit: uniform witness and selectors, q_c solved per "
+                        "gate, copy constraints = n cycles of length 5 between pseudo-random gates), commit key tau^i*G with a published trapdoor "
+                        "(plonk_synth_srs), challenges from the merlin transcript (host Python, ~7 ms inside the timed proof), "
+                        "WrongQuotientPolyDegree check ON.  Variants produce the same proof: resident_key_cosets skips the 18 selector/sigma coset "
+                        "NTTs per proof (proving-key data); six_cosets interpolates the degree-(5n+7) quotient from 6n evaluations"}
+            inst.close()
         except Exception as ex:
             next_rows = dict(next_rows or {})
-            next_rows["prover_rounds"] = {"error": str(ex)}
+            next_rows["prover_rounds"] = {"error": repr(ex)}
 
     # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
     class_row = None
@@ -871,15 +1057,39 @@ def main():
                "sample": f"oracle (C restatement of ark-poly/ark-ec 0.3.0) at n=2^{ls}, each op of the step run ONCE in full and combined "
                          f"with the per-proof op mix 7/26/13: iNTT(n) {t_ntt_1*1e3:.0f} ms and coset-NTT(8n) {t_ntt8_1*1e3:.0f} ms on 1 thread "
                          f"(the reference's ark-poly has no `parallel` feature, Cargo.toml:31), commit(n) {t_msm*1e3:.0f} ms on {thr} threads "
-                         f"(ark-ec `parallel`: windows on the rayon pool).  Not extrapolated to 2^24: there the NTT's per-element cost is "
-                         f"x27/23 higher and Pippenger's per-point cost slightly lower",
+                         f"(ark-ec `parallel`: windows on the rayon pool).  `value` is this 2^{ls} measurement; the estimate for the GPU line's "
+                         f"size is in extrapolated_to_bench_size",
                "all_threads_ntt": {"value": round(ns / t_step_par, 1), "iNTT_n_ms": round(t_ntt_par * 1e3, 1), "coset_NTT_8n_ms": round(t_ntt8_par * 1e3, 1),
                                    "note": "the oracle's OpenMP NTT on every host thread - faster than the reference's build would be"},
                "host_cores_online": os.cpu_count()}
+        if args.log_n > ls:
+            # labelled extrapolation to the GPU line's size (BASELINE.md §3 allows it): radix-2 NTT cost per element grows with log2 of
+            # the size ((log n + 3) / (ls + 3) for the 8n transforms, log n / ls for the n ones); Pippenger's cost per point is taken as
+            # constant (it falls slightly with n: larger windows).  An estimate, not a measurement.
+            up = 1 << (args.log_n - ls)
+            t_ext = up * (N_NTT_SMALL * t_ntt_1 * args.log_n / ls + N_NTT_BIG * t_ntt8_1 * (args.log_n + 3) / (ls + 3) + N_MSM * t_msm)
+            cpu["extrapolated_to_bench_size"] = {"log_n": args.log_n, "value": round(n / t_ext, 1), "unit": "constraints/s", "s_per_step": round(t_ext, 1),
+                                                 "note": f"EXTRAPOLATED from the 2^{ls} sample above with the operation counts of radix-2 NTT (n log n) and "
+                                                         f"Pippenger (linear in n at a fixed window): not measured at 2^{args.log_n}"}
 
     if rank == 0:
         out["cpu_baseline"] = cpu
         out["next_rows"] = dict(next_rows or {}, class_prover=class_row) if class_row else next_rows
+        # the REAL proof at top level (BASELINE's metric is "proof-gen ms"): the five rounds of dispatcher2.rs:296-712 on the 8n route
+        # with the proving key NOT resident — the reference's work — on the satisfied synthetic circuit, verified; `value` stays on
+        # the SURVEY §8d op mix for continuity with rounds 1-2.  Same-proof variants beside it, labelled.
+        pr = (next_rows or {}).get("prover_rounds") or {}
+        if "ms" in pr:
+            out["proof_ms"] = pr["ms"]
+            out["proof_constraints_per_s"] = pr["constraints_per_s"]
+            out["prover_verified"] = pr.get("prover_verified")
+            out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms)": pr["ms"]},
+                                            **{{"resident_key_cosets": "8n_route_key_coset_vectors_resident_in_HBM",
+                                                "six_cosets": "six_coset_quotient_key_not_resident",
+                                                "six_cosets_resident_key": "six_coset_quotient_key_resident"}[k_]: v_.get("ms")
+                                               for k_, v_ in (pr.get("variants") or {}).items()})
+        if class_row and "ms" in class_row:
+            out["proof_ms_class_prover_all_ranks"] = class_row["ms"]
     if world > 1:
         emit()                                   # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
         arm("teardown", 120.0)
@@ -887,14 +1097,12 @@ def main():
         for b in pair:
             b.free()
     bases.free()
-    if buf_p is not None:
-        buf_p.free()
-    if rows_compact is not None:
-        rows_compact.free()
+    for b in polys + rows_compact + scal:
+        b.free()
     if cls is not None:
-        for k_ in ("poly", "out", "contrib", "recv", "mine", "quot"):
+        for k_ in ("out", "contrib", "recv", "mine", "quot"):
             cls[k_].free()
-        for b in cls["bn"]:
+        for b in cls["polys"] + [x for pair in cls["bn"] for x in pair]:
             b.free()
     for x in workers:
         x.close()

@@ -253,6 +253,10 @@ class PlonkWorker:
         check(self.lib.plonk_transpose(self.ctx, _ptr(v), rows, cols))
         return v
 
+    def transpose_dev(self, d_in: int, d_out: int, rows: int, cols: int):
+        """[rows][cols] -> [cols][rows] of Fr in HBM (ip_transpose, transpose.rs:413; out of place)."""
+        check(self.lib.plonk_transpose_dev(self.ctx, d_in, d_out, rows, cols))
+
     def g1_add(self, a: np.ndarray, b: np.ndarray) -> np.ndarray:
         out = np.empty(3 * self.q64, dtype=np.uint64)
         check(self.lib.plonk_g1_add(self.curve, _ptr(_u64(a)), _ptr(_u64(b)), _ptr(out)))
