@@ -173,10 +173,16 @@ int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_p
     if (!order.ok) return plonk_fail(PLONK_ERR_HIP, "collective ordering event");
     ProfScope prof("rccl_alltoall", stream);          // HIP events on the stream: the exchange as the GPU saw it (incl. waiting for peers)
     NCCL_TRY(api, api->GroupStart());
+    // at most 1 GiB per ncclSend / ncclRecv call: a single-rank world exchanges the WHOLE 4 GiB buffer of a 2^27-point transform with
+    // itself, and byte counts at or above 2^32 are not safe to hand to one call
+    const size_t CHUNK = (size_t)1 << 30;
     for (int p = 0; p < c->world; p++) {
-        ncclResult_t a = api->Send(s + (size_t)p * bytes_per_peer, bytes_per_peer, ncclInt8, p, c->comm, stream);
-        ncclResult_t b = a == ncclSuccess ? api->Recv(r + (size_t)p * bytes_per_peer, bytes_per_peer, ncclInt8, p, c->comm, stream) : a;
-        if (b != ncclSuccess) { (void)api->GroupEnd(); return plonk_fail(PLONK_ERR_EXCHANGE, "ncclSend/Recv (peer %d): %s", p, api->GetErrorString(b)); }
+        for (size_t off = 0; off < bytes_per_peer; off += CHUNK) {
+            const size_t len = bytes_per_peer - off < CHUNK ? bytes_per_peer - off : CHUNK;
+            ncclResult_t a = api->Send(s + (size_t)p * bytes_per_peer + off, len, ncclInt8, p, c->comm, stream);
+            ncclResult_t b = a == ncclSuccess ? api->Recv(r + (size_t)p * bytes_per_peer + off, len, ncclInt8, p, c->comm, stream) : a;
+            if (b != ncclSuccess) { (void)api->GroupEnd(); return plonk_fail(PLONK_ERR_EXCHANGE, "ncclSend/Recv (peer %d): %s", p, api->GetErrorString(b)); }
+        }
     }
     NCCL_TRY(api, api->GroupEnd());
     return PLONK_OK;
