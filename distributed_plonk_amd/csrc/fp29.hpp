@@ -31,6 +31,15 @@ struct F29Params {
     uint32_t one[9];    // 2^261 mod p  (the constant that multiplies by 1)
     uint32_t inv;       // -p^{-1} mod 2^29
     float inv_top;      // (1 - 2^-20) / (p[8] + 1): quotient estimate for f29_canon_lazy
+    uint32_t pbar[9];   // 2^261 - p, normalised: the low half of -q*p for the precomputed-quotient multiplier (f29_mul_shoup)
+};
+
+// A constant prepared for the precomputed-quotient ("Shoup") multiplier: c < p as a PLAIN residue (the data operand keeps whatever
+// Montgomery factor it carries) and cq = floor(c * 2^261 / p).  80 bytes = five 128-bit loads.
+struct alignas(16) F29S {
+    uint32_t c[9];
+    uint32_t cq[9];
+    uint32_t pad[2];
 };
 
 #define F29_MASK 0x1fffffffu
@@ -130,6 +139,39 @@ FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
         F29_CHAIN(acc);
     }
     r.l[8] = (uint32_t)acc;
+    return r;
+}
+
+// x * c mod p for a PREPARED constant (F29S): every NTT butterfly product is data x twiddle, so the quotient is precomputed too.
+//     q = floor(x * cq / 2^261)  ->  floor(x*c/p) - 2 <= q <= floor(x*c/p)      (x < 2^261; the dropped low columns cost < 2^-20 of a unit)
+//     r = x*c - q*p  in [0, 3p)  and only its low 261 bits are needed:  r = (x*c + q*pbar) mod 2^261,  pbar = 2^261 - p
+// Cost: columns 7..16 of x*cq (53 limb products) + columns 0..8 of x*c and of q*pbar (45 + 45) = 143 limb products and no v_mul_lo,
+// against 171 for the Montgomery product above (profiles/r02_multiplier_variants_static.txt: 213 -> 188 VALU instructions).
+// x: limbs < 2^31, value < 2^259.4 (f29_mul's contract); result normalised, value < 3p — butterflies subtract it from 4p (c4p).
+FP_HD F29 f29_mul_shoup(const F29& x, const uint32_t* c, const uint32_t* cq, const F29Params& P) {
+    uint64_t acc = 0;
+    uint32_t q[9];
+#pragma unroll
+    for (int k = 7; k < 17; k++) {
+#pragma unroll
+        for (int i = (k > 8 ? k - 8 : 0); i <= (k < 8 ? k : 8); i++) { acc += (uint64_t)x.l[i] * cq[k - i]; F29_CHAIN(acc); }
+        if (k >= 9) q[k - 9] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
+    q[8] = (uint32_t)acc;
+    F29 r;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)x.l[i] * c[k - i]; F29_CHAIN(acc); }
+#pragma unroll
+        for (int i = 0; i <= k; i++) { acc += (uint64_t)q[i] * P.pbar[k - i]; F29_CHAIN(acc); }
+        r.l[k] = (uint32_t)acc & F29_MASK;
+        acc >>= 29;
+        F29_CHAIN(acc);
+    }
     return r;
 }
 
@@ -243,9 +285,10 @@ FP_HD F29 f29_canon(const F29& a, const F29Params& P) {
     return r;
 }
 
-// normalised a < 24p  ->  a mod p (canonical), without a product: q = floor(a / p) is estimated from the top limb
+// normalised a < 48p  ->  a mod p (canonical), without a product: q = floor(a / p) is estimated from the top limb
 // (a_8 / (p_8 + 1), scaled down by 2^-20 so that float rounding can only under-estimate: q_est is q or q - 1, the error terms
-// being < 24 * 2^-20 + 24 / p_8 << 1), a - q_est * p lands in [0, 2p), one conditional subtraction finishes.
+// being < 48 * 2^-20 + 48 / p_8 << 1), a - q_est * p lands in [0, 2p), one conditional subtraction finishes.  (Montgomery
+// butterflies deliver < 21.4p after nine stages, the precomputed-quotient ones < 36p; a must stay below 2^261.)
 // Replaces the "multiply by one" the NTT's last pass used to bring its lazy values (< 21.4 p after nine stages) below 1.36p:
 // 9 mads + 9 carries + a canon instead of a 171-mad product + a canon.
 FP_HD F29 f29_canon_lazy(const F29& a, const F29Params& P) {
@@ -304,7 +347,49 @@ inline F29Params f29_make_params(const FpParams<8>& P) {
     for (int i = 0; i < 5; i++) o = fp_add(o, o, P);
     F29 o29 = f29_from_sat(o);
     for (int i = 0; i < 9; i++) q.one[i] = o29.l[i];
+    // pbar = 2^261 - p on 29-bit limbs: (2^29 - p_0, 2^29 - 1 - p_1, ..., 2^29 - 1 - p_8)
+    q.pbar[0] = (1u << 29) - q.p[0];
+    for (int i = 1; i < 9; i++) q.pbar[i] = F29_MASK - q.p[i];
+    uint32_t cy = 0;
+    for (int i = 0; i < 9; i++) { const uint32_t v = q.pbar[i] + cy; q.pbar[i] = v & F29_MASK; cy = v >> 29; }
     return q;
+}
+
+// c given in the reference's Montgomery form (c*2^256) -> the prepared constant (plain residue and floor(c * 2^261 / p)); host only
+inline F29S f29_shoup_from_mont256(const Fp<8>& c_mont, const FpParams<8>& P) {
+    const Fp<8> c = fp_from_mont(c_mont, P);
+    F29S s;
+    const F29 c29 = f29_from_sat(c);
+    for (int i = 0; i < 9; i++) s.c[i] = c29.l[i];
+    // binary long division of c * 2^261 by p on 9 x 32-bit words
+    uint32_t rem[9] = {0}, quo[9] = {0};
+    for (int i = 0; i < 8; i++) rem[i] = c.l[i];
+    for (int b = 260; b >= 0; b--) {
+        uint32_t cy = 0;
+        for (int i = 0; i < 9; i++) { const uint32_t v = rem[i]; rem[i] = (v << 1) | cy; cy = v >> 31; }
+        bool ge = rem[8] != 0;
+        if (!ge) {
+            ge = true;
+            for (int i = 7; i >= 0; i--) if (rem[i] != P.p[i]) { ge = rem[i] > P.p[i]; break; }
+        }
+        if (ge) {
+            uint64_t br = 0;
+            for (int i = 0; i < 9; i++) {
+                const uint64_t t = (uint64_t)rem[i] - (i < 8 ? P.p[i] : 0) - br;
+                rem[i] = (uint32_t)t;
+                br = (t >> 32) & 1;
+            }
+            quo[b >> 5] |= 1u << (b & 31);
+        }
+    }
+    for (int k = 0; k < 9; k++) {
+        const int bit = 29 * k, w = bit >> 5, off = bit & 31;
+        uint64_t v = quo[w] >> off;
+        if (off + 29 > 32 && w + 1 < 9) v |= (uint64_t)quo[w + 1] << (32 - off);
+        s.cq[k] = (uint32_t)v & F29_MASK;
+    }
+    s.pad[0] = s.pad[1] = 0;
+    return s;
 }
 
 // value v given in the reference's Montgomery form (v*2^256) -> constant form v*2^261 mod p, 29-bit limbs

@@ -63,9 +63,20 @@ int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
         if ((rc = upload_powers(&T.tw_hi[d], host_pow2k(w[d], T.lt, P), nt, one, P, stream))) return rc;
         if ((rc = upload_powers(&T.tw_small[d], host_pow2k(w[d], T.two_adicity - NTT_LOG_RMAX, P),
                                 (size_t)1 << (NTT_LOG_RMAX - 1), one, P, stream))) return rc;
+        {   // the in-LDS twiddles once more, prepared for f29_mul_shoup
+            const size_t cnt = (size_t)1 << (NTT_LOG_RMAX - 1);
+            std::vector<F29S> h(cnt);
+            const Fr base = host_pow2k(w[d], T.two_adicity - NTT_LOG_RMAX, P);
+            Fr acc = one;
+            for (size_t i = 0; i < cnt; i++) { h[i] = f29_shoup_from_mont256(acc, P); acc = fp_mul(acc, base, P); }
+            HIP_TRY(hipMalloc((void**)&T.tw_shoup[d], cnt * sizeof(F29S)));
+            HIP_TRY(hipMemcpyAsync(T.tw_shoup[d], h.data(), cnt * sizeof(F29S), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+        }
         if ((rc = upload_powers(&T.g_lo[d], g[d], nt, one, P, stream))) return rc;
         if ((rc = upload_powers(&T.g_hi[d], host_pow2k(g[d], T.lt, P), nt, one, P, stream))) return rc;
     }
+    T.use_shoup = curve == PLONK_BN254 && getenv("PLONK_NTT_NO_SHOUP") == nullptr;
     // 2^-k
     Fr two = fp_add(one, one, P), half = fp_inv(two, P);
     T.h_pow2_inv.resize(T.two_adicity + 1);
@@ -76,6 +87,7 @@ int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
 
 void ntt_tables_destroy(NttTables& T) {
     for (int d = 0; d < 2; d++) {
+        (void)hipFree(T.tw_shoup[d]); T.tw_shoup[d] = nullptr;
         (void)hipFree(T.tw_small[d]); (void)hipFree(T.tw_lo[d]); (void)hipFree(T.tw_hi[d]); (void)hipFree(T.g_lo[d]); (void)hipFree(T.g_hi[d]);
         T.tw_small[d] = T.tw_lo[d] = T.tw_hi[d] = T.g_lo[d] = T.g_hi[d] = nullptr;
     }
@@ -336,16 +348,16 @@ static int ntt_ept() {
     return ept;
 }
 
-template <int LOG_R, int EPT, bool SWZ = false>
+template <int LOG_R, int EPT, bool SWZ = false, bool SHOUP = false>
 static hipError_t launch_one_e(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT, SWZ>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT, SWZ, SHOUP>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT, SWZ>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
+    hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT, SWZ, SHOUP>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
     return hipGetLastError();
 }
 static bool swizzle_on() {
@@ -356,7 +368,10 @@ template <int LOG_R>
 static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     // the bank swizzle (ntt_kernels.hpp: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
     if constexpr (LOG_R >= 7) {
-        if (ntt_ept() == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
+        if (ntt_ept() == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) {
+            if (P.tw_shoup != nullptr) return launch_one_e<LOG_R, 4, true, true>(P, grid, threads, lds, stream);
+            return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
+        }
     }
     if (ntt_ept() == 4) return launch_one_e<LOG_R, 4>(P, grid, threads, lds, stream);
     if (ntt_ept() == 2) return launch_one_e<LOG_R, 2>(P, grid, threads, lds, stream);
@@ -447,6 +462,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         memset(&P, 0, sizeof P);
         P.fp = T.fp29;
         P.tw_small = T.tw_small[dir];
+        P.tw_shoup = T.use_shoup ? T.tw_shoup[dir] : nullptr;
         P.tw_lo = T.tw_lo[dir];
         P.tw_hi = T.tw_hi[dir];
         P.tw_lt = T.lt;

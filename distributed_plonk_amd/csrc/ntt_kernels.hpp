@@ -47,6 +47,7 @@ struct NttPassParams {
     Fr* out;
     F29Params fp;
     const F29* tw_small;      // w_Rmax^e, e < Rmax/2 (direction already chosen)
+    const F29S* tw_shoup;     // the same twiddles prepared for f29_mul_shoup (plain residue + precomputed quotient), read through L1
     const F29* tw_lo;         // w_Nmax^e, e < 2^tw_lt      (inter-pass twiddles; may carry 1/N)
     const F29* tw_hi;         // w_Nmax^(e << tw_lt)
     uint32_t tw_lt;
@@ -168,8 +169,23 @@ template <bool SWZ> __device__ __forceinline__ uint32_t sw_fold(uint32_t row) {
 
 // K radix-2 decimation-in-time stages (s0 .. s0+K-1 of a size-2^LOG_R transform whose input sits in
 // bit-reversed order) on the EPT elements a lane holds.  Tile contents are normalised on entry and exit.
-template <int LOG_R, int K, int EPT, bool FIRST, bool SWZ>
-__device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw_lds, int s0, uint32_t w, uint32_t t,
+// prepared twiddle e of the size-2^LOG_R transform (table entry e << (9 - LOG_R)): five 128-bit loads
+template <int LOG_R>
+__device__ __forceinline__ void shoup_tw_load(const F29S* __restrict__ tab, uint32_t e, uint32_t* cw) {
+    const uint4* src = reinterpret_cast<const uint4*>(tab + ((size_t)e << (NTT_LOG_RMAX - LOG_R)));
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint4 d = src[j];
+        cw[4 * j] = d.x; cw[4 * j + 1] = d.y; cw[4 * j + 2] = d.z; cw[4 * j + 3] = d.w;
+    }
+}
+// SHOUP: the butterfly products use the precomputed-quotient multiplier with twiddles fetched from the 80-byte global table (five
+// 128-bit loads per product on the otherwise idle vector-memory pipe; the table is L1-resident) instead of Montgomery products
+// with twiddles from LDS: 143 limb products instead of 171 + 9.  Its result is < 3p, so butterflies subtract from 4p and bounds
+// grow by 4p per stage: < 1.4p + 4p * 9 < 40p after the nine stages of the widest pass — inside f29_mul's 2^259.4 for BN254
+// (p < 2^253.6: 55p) but not for BLS12-381 (23p), which keeps the Montgomery path.
+template <int LOG_R, int K, int EPT, bool FIRST, bool SWZ, bool SHOUP>
+__device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw_lds, const F29S* __restrict__ tw_shoup, int s0, uint32_t w, uint32_t t,
                                          uint32_t pitch, const F29Params& fp) {
     constexpr int R = 1 << LOG_R;
     constexpr int RADIX = 1 << K;
@@ -205,12 +221,20 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
                     v[k + span] = (ds == 0) ? f29_sub2p(x, tt, fp) : f29_sub4p(x, tt, fp);
                 } else {
                     const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
-                    F29 tw;
+                    if constexpr (SHOUP) {
+                        uint32_t cw[20];
+                        shoup_tw_load<LOG_R>(tw_shoup, e, cw);
+                        tt = f29_mul_shoup(v[k + span], cw, cw + 9, fp);
+                        v[k] = f29_add(x, tt);
+                        v[k + span] = f29_sub4p(x, tt, fp);
+                    } else {
+                        F29 tw;
 #pragma unroll
-                    for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
-                    tt = f29_mul(v[k + span], tw, fp);
-                    v[k] = f29_add(x, tt);
-                    v[k + span] = f29_sub2p(x, tt, fp);
+                        for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
+                        tt = f29_mul(v[k + span], tw, fp);
+                        v[k] = f29_add(x, tt);
+                        v[k + span] = f29_sub2p(x, tt, fp);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one butterfly's temporaries live at a time (interleaving two spills at 128 VGPRs: measured 1.6x slower)
             }
@@ -224,7 +248,7 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
     }
 }
 
-template <int LOG_R, int EPT_REQ, bool SWZ = false>
+template <int LOG_R, int EPT_REQ, bool SWZ = false, bool SHOUP = false>
 __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(const NttPassParams P) {
     constexpr int R = 1 << LOG_R;
     constexpr int EPT = (R >= EPT_REQ) ? EPT_REQ : R;
@@ -251,11 +275,13 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
     const uint64_t b0 = x0 * P.bs0 + x1 * P.bs1;
     const uint64_t q0 = x0 * P.qs0 + x1 * P.qs1 + x2 * P.qs2;
 
-    // ---- small twiddle table -> LDS : w_R^e , e < R/2
-    for (uint32_t e = u; e < TWN; e += nthreads) {
-        const F29 tw = load_f29(P.tw_small + ((uint64_t)e << (NTT_LOG_RMAX - LOG_R)));
+    // ---- small twiddle table -> LDS : w_R^e , e < R/2   (the SHOUP instantiation reads its prepared twiddles through L1 instead)
+    if constexpr (!SHOUP) {
+        for (uint32_t e = u; e < TWN; e += nthreads) {
+            const F29 tw = load_f29(P.tw_small + ((uint64_t)e << (NTT_LOG_RMAX - LOG_R)));
 #pragma unroll
-        for (int l = 0; l < 9; l++) tw_lds[l * TWN + e] = tw.l[l];
+            for (int l = 0; l < 9; l++) tw_lds[l * TWN + e] = tw.l[l];
+        }
     }
 
     // ---- load tile (element a of the column goes to LDS row brev(a): DIT input order)
@@ -307,20 +333,20 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
         constexpr int KREM = LOG_R % KMAX;
         constexpr int SFULL = LOG_R - KREM;          // stages covered by full groups
         if constexpr (R <= EPT) {
-            ntt_step<LOG_R, LOG_R, EPT, true, SWZ>(tile, tw_lds, 0, w, t, pitch, P.fp);
+            ntt_step<LOG_R, LOG_R, EPT, true, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, 0, w, t, pitch, P.fp);
             __syncthreads();
         } else {
             if constexpr (SFULL > 0) {
-                ntt_step<LOG_R, KMAX, EPT, true, SWZ>(tile, tw_lds, 0, w, t, pitch, P.fp);
+                ntt_step<LOG_R, KMAX, EPT, true, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, 0, w, t, pitch, P.fp);
                 __syncthreads();
 #pragma unroll 1
                 for (int s = KMAX; s < SFULL; s += KMAX) {
-                    ntt_step<LOG_R, KMAX, EPT, false, SWZ>(tile, tw_lds, s, w, t, pitch, P.fp);
+                    ntt_step<LOG_R, KMAX, EPT, false, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, s, w, t, pitch, P.fp);
                     __syncthreads();
                 }
             }
             if constexpr (KREM != 0) {
-                ntt_step<LOG_R, KREM, EPT, SFULL == 0, SWZ>(tile, tw_lds, SFULL, w, t, pitch, P.fp);
+                ntt_step<LOG_R, KREM, EPT, SFULL == 0, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, SFULL, w, t, pitch, P.fp);
                 __syncthreads();
             }
         }
@@ -375,7 +401,7 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             } else if (P.scale_const_enabled) {
                 v = f29_mul(v, P.scale_const, P.fp);
             } else {
-                lazy = true;                                     // < 7.4p + 2p per stage beyond the second: < 21.4p after nine
+                lazy = true;                                     // < 7.4p + 2p per stage beyond the second: < 21.4p after nine (SHOUP: 4p per stage, < 36p)
             }
             v = lazy ? f29_canon_lazy(v, P.fp) : f29_canon(v, P.fp);
             uint64_t addr;

@@ -64,6 +64,8 @@ struct NttTables {
     int lt = 0;                       // two-level table split: 2^lt entries per level, 2*lt >= two_adicity
     // all device tables hold constants c*2^261 mod p as 9 x 29-bit limbs (fp29.hpp)
     F29* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
+    F29S* tw_shoup[2] = {nullptr, nullptr};  // [dir] w_Rmax^e prepared for the precomputed-quotient multiplier (plain residue + quotient constant)
+    bool use_shoup = false;                  // BN254 only (bounds, ntt_kernels.hpp: ntt_step); PLONK_NTT_NO_SHOUP=1 keeps the Montgomery butterflies
     F29* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
     F29* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
     F29* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e
