@@ -53,13 +53,33 @@ def _newest_header():
     return max([os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS] + [os.path.getmtime(os.path.abspath(__file__))])
 
 
-def _compile(unit, force):
+def _compile(unit, force, objdir=OBJDIR, unit_flags=None):
     src = os.path.join(CSRC, unit)
-    obj = os.path.join(OBJDIR, unit.replace(".hip", ".o"))
+    obj = os.path.join(objdir, unit.replace(".hip", ".o"))
     if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(os.path.getmtime(src), _newest_header()):
         return obj, False
-    subprocess.check_call([HIPCC, *FLAGS, *UNIT_FLAGS.get(unit, []), "-c", src, "-o", obj])
+    subprocess.check_call([HIPCC, *FLAGS, *(UNIT_FLAGS if unit_flags is None else unit_flags).get(unit, []), "-c", src, "-o", obj])
     return obj, True
+
+
+def build_variant(name, unit_flags, force=False):
+    """An A/B build: the same sources with other per-unit flags (e.g. {"quotient.hip": UNROLL, **UNIT_FLAGS}) as
+    lib/variants/<name>/libplonk_hip.so — selected at run time with PLONK_HIP_LIB=<that path> (distributed_plonk_amd/_ffi.py).
+    Units whose flags equal the product build's reuse its objects."""
+    objdir = os.path.join(OBJDIR, "variants", name)
+    outdir = os.path.join(LIBDIR, "variants", name)
+    os.makedirs(objdir, exist_ok=True)
+    os.makedirs(outdir, exist_ok=True)
+    build(verbose=False)
+    objs = []
+    for u in UNITS:
+        if unit_flags.get(u, []) == UNIT_FLAGS.get(u, []):
+            objs.append(os.path.join(OBJDIR, u.replace(".hip", ".o")))
+        else:
+            objs.append(_compile(u, force, objdir, unit_flags)[0])
+    out = os.path.join(outdir, "libplonk_hip.so")
+    subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", out])
+    return out
 
 
 def build(force=False, verbose=True):

@@ -69,9 +69,28 @@ struct LazySum {           // sum of normalised values; limbs re-normalised ever
 
 __device__ __forceinline__ F29 ldq(const Fr* p, uint64_t i) { return f29_from_sat(load_fr(p + i)); }
 
+// one evaluation point (local index i)
+__device__ __forceinline__ void quotient_point_unlifted(const QuotParams& P, const uint64_t i);
+
 __device__ __forceinline__ void quotient_evals_unlifted(const QuotParams& P) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // local index k
     if (i >= P.m_local) return;
+    quotient_point_unlifted(P, i);
+}
+// The point's arithmetic is ~12 000 straight-line instructions (68 KiB of code: more than the 64 KiB instruction cache two CUs
+// share), executed exactly once per wave in the kernels above, so every wave streams the whole kernel through the instruction
+// cache.  Here a wave walks PTS points in a rolled loop: the code is fetched once per PTS points (profiles/r03_quotient_slow_mode.txt).
+template <int PTS>
+__device__ __forceinline__ void quotient_evals_unlifted_loop(const QuotParams& P) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+#pragma unroll 1
+    for (int it = 0; it < PTS; it++, i += stride) {
+        if (i < P.m_local) quotient_point_unlifted(P, i);
+    }
+}
+
+__device__ __forceinline__ void quotient_point_unlifted(const QuotParams& P, const uint64_t i) {
     const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
     const F29Params& fp = P.fp;
     F29 w5[5];
@@ -262,6 +281,8 @@ __device__ __forceinline__ void quotient_evals_body(const QuotParams& P) {
 // Variants: how many products share a reduction.  PLONK_QUOT_FUSE selects; the default is the measured best.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel(const QuotParams P) { quotient_evals_unlifted(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_u3(const QuotParams P) { quotient_evals_unlifted(P); }      // uncapped registers: 3 waves
+#define QUOT_LOOP_PTS 8
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel_loop(const QuotParams P) { quotient_evals_unlifted_loop<QUOT_LOOP_PTS>(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_f1(const QuotParams P) { quotient_evals_body<1>(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_f2(const QuotParams P) { quotient_evals_body<2>(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_f3(const QuotParams P) { quotient_evals_body<3>(P); }
@@ -412,12 +433,13 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 4) ? T.quotient_fuse : 0;
+        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 5) ? T.quotient_fuse : 0;
         const dim3 grid((uint32_t)((m_local + 255) / 256));
         if (fuse == 1) hipLaunchKernelGGL(quotient_evals_kernel_f1, grid, dim3(256), 0, stream, q);
         else if (fuse == 2) hipLaunchKernelGGL(quotient_evals_kernel_f2, grid, dim3(256), 0, stream, q);
         else if (fuse == 3) hipLaunchKernelGGL(quotient_evals_kernel_f3, grid, dim3(256), 0, stream, q);
         else if (fuse == 4) hipLaunchKernelGGL(quotient_evals_kernel_u3, grid, dim3(256), 0, stream, q);
+        else if (fuse == 5) hipLaunchKernelGGL(quotient_evals_kernel_loop, dim3((uint32_t)((m_local + 256 * QUOT_LOOP_PTS - 1) / (256 * QUOT_LOOP_PTS))), dim3(256), 0, stream, q);
         else hipLaunchKernelGGL(quotient_evals_kernel, grid, dim3(256), 0, stream, q);
     }
     hipError_t e = hipGetLastError();
