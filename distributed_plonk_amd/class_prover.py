@@ -14,8 +14,10 @@ j = s (mod G), and class s is itself a coset  {(g * w_m^s) * w_(m/G)^k}.  Rank s
   * every commitment is an index-sharded MSM (dispatcher2.rs:870-890): rank s covers coefficients [s*L/G, (s+1)*L/G); the
     partial points of a round (96/144 bytes each) travel in ONE all-gather and are added on the host.
 
-The O(n) rounds (wire / permutation iNTTs, grand product, evaluations at zeta, linearisation, openings) are computed redundantly
-on every rank: ~45 ms at n = 2^24 against ~100 ms of class work per rank at G = 8; sharding them is the next step.
+Of the O(n) rounds, the evaluations at zeta, the linearisation / batch polynomial, the two synthetic divisions and the quotient's
+degree check are sharded by coefficient index (round 3: `_evaluate_many`, `_openings`, `_degree` — 32-byte partials travel); the
+seven size-n iNTTs and the grand product still run on every rank (2.6 ms each: the class evaluations need the whole coefficient
+vectors on every rank anyway, and gathering 512 MiB costs what computing it does).
 Results are bit-identical to the single-GPU `Prover` (and the oracle): tests/test_gpu_class_prover.py runs G = 2, 4, 8 ranks as
 threads sharing one GPU; tests/test_gloo_multirank.py covers the torch.distributed transport on CPU tensors.
 """
@@ -243,7 +245,93 @@ class ClassProver(Prover):
                 acc[i] = p if acc[i] is None else self.w.g1_add(acc[i], p)
         return [self.w.g1_to_affine(a) for a in acc]
 
-    # ---- the quotient's degree: every rank holds the whole polynomial after the all-gather
+    # ---- the O(n) rounds, sharded by coefficient index (round 2 of this file computed them redundantly on every rank: ~20 ms at
+    # n = 2^24 that did not shrink with G).  Only 32-byte partials travel: one small all-gather per step.
+    def _sum_gathered(self, rows: np.ndarray) -> List[np.ndarray]:
+        """rows (k, 4): this rank's k partial values -> the k sums over all ranks (Fr limbs), identical on every rank."""
+        f = self.f
+        acc = [0] * rows.shape[0]
+        for part in self.comm.all_gather_host(np.ascontiguousarray(rows, dtype=np.uint64)):
+            for j in range(rows.shape[0]):
+                acc[j] = (acc[j] + f.from_limbs(part[j])) % f.p
+        return [f.to_limbs(x) for x in acc]
+
+    def _evaluate_many(self, polys, points):
+        """Round 4 (:545-555): rank s evaluates coefficients [s*L/G, (s+1)*L/G) of every polynomial — sum_i c_i z^i over the slice is
+        z^lo times the evaluation of the slice — and the 10 partial values are added across ranks."""
+        f, w = self.f, self.w
+        rows = np.zeros((len(polys), 4), dtype=np.uint64)
+        for j, ((ptr, ln), pt) in enumerate(zip(polys, points)):
+            lo, hi = shard_range(ln, self.s, self.G)
+            if hi > lo:
+                part = f.from_limbs(w.poly_eval_dev(ptr + lo * 32, hi - lo, pt))
+                rows[j] = f.to_limbs(part * pow(f.from_limbs(pt), lo, f.p) % f.p)
+        return self._sum_gathered(rows)
+
+    def _degree(self, d_poly: int, length: int) -> int:
+        """The quotient is replicated after the all-gather; each rank scans its slice, the highest non-zero index wins."""
+        lo, hi = shard_range(length, self.s, self.G)
+        d = self.w.poly_degree_dev(d_poly + lo * 32, hi - lo) if hi > lo else -1
+        mine = np.array([lo + d + 1 if d >= 0 else 0], dtype=np.uint64)         # 0 = all zero in my slice
+        return int(max(int(x[0]) for x in self.comm.all_gather_host(mine))) - 1
+
+    def _commit_range(self, length: int):
+        """The coefficient indices [lo, hi) of a length-`length` polynomial this rank commits (what _commit_many picks)."""
+        if self.key_range is None:
+            return shard_range(length, self.s, self.G)
+        lo, hi = min(self.key_range[0], length), min(self.key_range[1], length)
+        return (lo, hi) if hi > lo else (0, 0)
+
+    def _openings(self, alloc, lin_terms, lin_coeffs, batch_terms, batch_coeffs, perm_poly, zeta, zeta_w, PP: int, keep: bool) -> dict:
+        """Round 5 (:566-697) with every vector restricted to the slice this rank commits.  The witness polynomial of an opening is
+        q_t = sum_{k > t} c_k z^(k-t-1) (the synthetic division of :651-666).  For t in [lo, hi) that is the division of the local
+        piece (c_(lo+1) .. c_hi) with ONE extra top coefficient T = q_hi = sum over the higher ranks' pieces, and
+        T = sum_{r' above} z^(lo_r' - hi) * E_r' with E_r' the evaluation of rank r''s own piece at z: 32 bytes per rank and
+        polynomial travel, the batch polynomial is only ever formed on the slice (1/G of the scalar * polynomial work)."""
+        w, f, p = self.w, self.f, self.f.p
+        Lq = PP - 1
+        lo, hi = self._commit_range(Lq)
+        cnt = hi - lo
+        terms = list(lin_terms) + list(batch_terms)
+        coeffs = list(lin_coeffs) + list(batch_coeffs)
+        d_b = alloc(2 * (cnt + 2))                                   # two pieces: [x, c_(lo+1) .. c_hi, T]
+        piece = [d_b.ptr, d_b.ptr + (cnt + 2) * 32]
+        rows = np.zeros((2, 6), dtype=np.uint64)                     # (lo, hi, E limbs) per opening
+        pts = (zeta, zeta_w)
+        if cnt > 0:
+            w.memset_dev(d_b.ptr, 0, 2 * (cnt + 2) * 32)
+            sl = [(ptr + (lo + 1) * 32, min(ln, hi + 1) - (lo + 1)) for ptr, ln in terms]
+            live = [(t, c) for t, c in zip(sl, coeffs) if t[1] > 0]
+            w.poly_lincomb_dev([t for t, _ in live], f.vec_to_limbs([c for _, c in live]), piece[0] + 32, cnt)       # batch_poly on (lo, hi]
+            have = min(perm_poly[1], hi + 1) - (lo + 1)
+            if have > 0:
+                w.memcpy_d2d(piece[1] + 32, perm_poly[0] + (lo + 1) * 32, have * 32)
+            for j in range(2):
+                rows[j, 0], rows[j, 1] = lo, hi
+                rows[j, 2:6] = w.poly_eval_dev(piece[j] + 32, cnt, pts[j])
+        gathered = self.comm.all_gather_host(rows)
+        d_q = alloc(2 * (cnt + 2))
+        virt = []
+        for j in range(2):
+            if cnt > 0:
+                z = f.from_limbs(pts[j])
+                T = 0
+                for part in gathered:
+                    plo, phi = int(part[j, 0]), int(part[j, 1])
+                    if phi > plo and plo >= hi:
+                        T = (T + f.from_limbs(part[j, 2:6]) * pow(z, plo - hi, p)) % p
+                w.write_bytes(piece[j] + (cnt + 1) * 32, f.to_limbs(T).view(np.int64))
+                w.poly_div_linear_dev(piece[j], cnt + 2, pts[j], d_q.ptr + j * (cnt + 2) * 32)      # out[t - lo] = q_t, t in [lo, hi)
+            virt.append(d_q.ptr + j * (cnt + 2) * 32 - lo * 32)      # a pointer _commit_many offsets by lo * 32 again
+        out = dict(comms=self._commit_many([(virt[0], Lq), (virt[1], Lq)]))
+        if keep:                                                     # debug copies of the whole polynomials (tests): the proof above never used them
+            d_lin, d_batch = alloc(PP), alloc(PP)
+            w.poly_lincomb_dev(list(lin_terms), f.vec_to_limbs(list(lin_coeffs)), d_lin.ptr, PP)
+            w.poly_lincomb_dev([(d_lin.ptr, PP)] + list(batch_terms), f.vec_to_limbs([1] + list(batch_coeffs)), d_batch.ptr, PP)
+            out["lin_poly"], out["batch_poly"] = d_lin.download((PP, 4)), d_batch.download((PP, 4))
+        return out
+
+    # ---- the quotient's coset evaluations, class by class
     def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
         w, n, m, key, G, s = self.w, self.n, self.m, self._key, self.G, self.s
         mL = m // G

@@ -208,6 +208,28 @@ class Prover:
         check(self.w.lib.plonk_memcpy_d2h(self.w.ctx, out.ctypes.data_as(C.c_void_p), d_ptr, out.nbytes))
         return out
 
+    def _evaluate_many(self, polys, points):
+        """DensePolynomial::evaluate of round 4 (:545-555): polys [(device pointer, length)], points [Fr limbs] -> [Fr limbs]."""
+        return [self.w.poly_eval_dev(ptr, ln, pt) for (ptr, ln), pt in zip(polys, points)]
+
+    def _openings(self, alloc, lin_terms, lin_coeffs, batch_terms, batch_coeffs, perm_poly, zeta, zeta_w, PP: int, keep: bool) -> dict:
+        """Round 5 after the challenges (:566-697): lin_poly = sum lin_coeffs * lin_terms, batch_poly = lin_poly + sum batch_coeffs *
+        batch_terms, the two divisions by (X - zeta) / (X - zeta w) and their commitments.  -> {"comms": [opening, shifted_opening],
+        "opening_poly" / "shifted_opening_poly": (ptr, len), and with keep: "lin_poly" / "batch_poly" as host arrays}."""
+        w, f = self.w, self.f
+        d_lin = alloc(PP)
+        w.poly_lincomb_dev(lin_terms, f.vec_to_limbs(lin_coeffs), d_lin.ptr, PP)
+        d_batch = alloc(PP)
+        w.poly_lincomb_dev([(d_lin.ptr, PP)] + list(batch_terms), f.vec_to_limbs([1] + list(batch_coeffs)), d_batch.ptr, PP)
+        d_wit = alloc(2 * PP)
+        w.poly_div_linear_dev(d_batch.ptr, PP, zeta, d_wit.ptr)
+        w.poly_div_linear_dev(perm_poly[0], perm_poly[1], zeta_w, d_wit.ptr + PP * 32)
+        out = dict(comms=self._commit_many([(d_wit.ptr, PP - 1), (d_wit.ptr + PP * 32, PP - 1)]),
+                   opening_poly=(d_wit.ptr, PP - 1), shifted_opening_poly=(d_wit.ptr + PP * 32, PP - 1))
+        if keep:
+            out["lin_poly"], out["batch_poly"] = d_lin.download((PP, 4)), d_batch.download((PP, 4))
+        return out
+
     # ---- the quotient from 6n evaluations instead of 8n
     def _class_setup(self):
         """The quotient has degree 5n+7 < 6n, so its values on SIX of the eight cosets  h_s * H_n  (h_s = g * w_m^s) of the
@@ -386,9 +408,9 @@ class Prover:
         zeta = challenge("zeta", proof)
         z = I(zeta)
         zeta_w = L(z * f.root_of_unity(n))
-        proof["wires_evals"] = [w.poly_eval_dev(wp[i], WP, zeta) for i in range(5)]
-        proof["wire_sigma_evals"] = [w.poly_eval_dev(key["sig"][i], n, zeta) for i in range(4)]
-        proof["perm_next_eval"] = w.poly_eval_dev(d_pp.ptr, PP, zeta_w)
+        polys4 = [(wp[i], WP) for i in range(5)] + [(key["sig"][i], n) for i in range(4)] + [(d_pp.ptr, PP)]
+        ev = self._evaluate_many(polys4, [zeta] * 9 + [zeta_w])
+        proof["wires_evals"], proof["wire_sigma_evals"], proof["perm_next_eval"] = ev[0:5], ev[5:9], ev[9]
         tick("round4", t0)
         # ---- Round 5 (:558-690): linearisation polynomial, batched opening, shifted opening
         t0 = time.perf_counter()
@@ -417,23 +439,20 @@ class Prover:
             polys.append((ptr, ln))
             coeffs.append((-vanish) * cq % p)
             cq = cq * z_n2 % p
-        d_lin = alloc(PP)
-        w.poly_lincomb_dev(polys, f.vec_to_limbs(coeffs), d_lin.ptr, PP)
         v = I(challenge("v", proof))
-        bp = [(d_lin.ptr, PP)] + [(wp[i], WP) for i in range(5)] + [(key["sig"][i], n) for i in range(4)]
-        d_batch = alloc(PP)
-        w.poly_lincomb_dev(bp, f.vec_to_limbs([pow(v, i, p) for i in range(len(bp))]), d_batch.ptr, PP)
-        d_wit = alloc(2 * PP)
-        w.poly_div_linear_dev(d_batch.ptr, PP, zeta, d_wit.ptr)
-        w.poly_div_linear_dev(d_pp.ptr, PP, zeta_w, d_wit.ptr + PP * 32)
-        proof["opening_proof"], proof["shifted_opening_proof"] = self._commit_many([(d_wit.ptr, PP - 1), (d_wit.ptr + PP * 32, PP - 1)])
+        # batch_poly = lin_poly + v w_0 + ... + v^5 w_4 + v^6 sigma_0 + ... + v^9 sigma_3 (:646-649), as ONE list of scalar * polynomial
+        # terms: lin_poly's own terms first (coefficient v^0 = 1)
+        bterms = [(wp[i], WP) for i in range(5)] + [(key["sig"][i], n) for i in range(4)]
+        bcoef = [pow(v, i + 1, p) for i in range(len(bterms))]
+        opening = self._openings(alloc, polys, coeffs, bterms, bcoef, (d_pp.ptr, PP), zeta, zeta_w, PP, keep)
+        proof["opening_proof"], proof["shifted_opening_proof"] = opening["comms"]
         tick("round5", t0)
         # where the committed polynomials live until the next proof reuses the work buffers (post-hoc checks: bench.py re-derives
         # commitments and evaluations of a finished 2^24-gate proof from them with the CPU oracle)
         self.last_polys = dict(wire_polys=[(wp[i], WP) for i in range(5)], perm_poly=(d_pp.ptr, PP), split_quot_polys=list(split),
-                               opening_poly=(d_wit.ptr, PP - 1), shifted_opening_poly=(d_wit.ptr + PP * 32, PP - 1))
+                               opening_poly=opening.get("opening_poly"), shifted_opening_poly=opening.get("shifted_opening_poly"))
         if keep:
             proof["_debug"] = dict(perm_product=dbg_prod, perm_poly=d_pp.download((PP, 4)),
-                                   quot_poly=self._download(d_quot_ptr, expected + 1), lin_poly=d_lin.download((PP, 4)),
-                                   batch_poly=d_batch.download((PP, 4)))
+                                   quot_poly=self._download(d_quot_ptr, expected + 1), lin_poly=opening["lin_poly"],
+                                   batch_poly=opening["batch_poly"])
         return proof
