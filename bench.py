@@ -965,33 +965,66 @@ def main():
             next_rows = dict(next_rows or {})
             next_rows["prover_rounds"] = {"error": repr(ex)}
 
-    # ---- opt-in: the five prover rounds on ALL ranks with the coset-class decomposition (two collectives per proof)
+    # ---- the five prover rounds on ALL ranks with the coset-class decomposition (class_prover.py): the same satisfied synthetic
+    # instance on every rank (generated in HBM from the seed), the commit key sharded over the ranks (dispatcher2.rs:260-266), real
+    # transcript on every rank, degree check on; rank 0 hands the proof to the trapdoor verifier.  Default for N > 1.
+    # --simulate-ranks S: rank 0's share of an S-rank proof on ONE GPU with no-op collectives (garbage proof, compute time only).
+    def release_step_buffers():
+        """the op-mix step's vectors (tens of GiB at 2^24) are not needed after the legs above; the class prover wants the room"""
+        for pair in buf_n + buf_m:
+            for b in pair:
+                b.free()
+        for b in polys + rows_compact + scal:
+            b.free()
+        if cls is not None:
+            for k_ in ("out", "contrib", "recv", "mine", "quot"):
+                if cls[k_] is not None:
+                    cls[k_].free()
+            for b in cls["polys"] + [x for pair in cls["bn"] for x in pair]:
+                b.free()
+            cls["polys"], cls["bn"] = [], []
+            for k_ in ("out", "contrib", "recv", "mine", "quot"):
+                cls[k_] = None
+        del buf_n[:], buf_m[:], polys[:], rows_compact[:], scal[:]
+
     class_row = None
-    if (args.class_prover or multi) and not args.no_class_prover and not sim:
+    if (args.class_prover or multi or sim) and not args.no_class_prover and nbig:
         arm("class_prover", 2 * LEG_BUDGET_S)
         try:
+            release_step_buffers()
             from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
-            if world == 1 and not dist.is_initialized():
+            from distributed_plonk_amd.synthetic import SyntheticInstance
+            from distributed_plonk_amd.transcript import PlonkTranscript
+            if world == 1 and not dist.is_initialized() and not sim:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29653")
                 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-            n_ck = ((n + 3 + 31) >> 5) << 5
-            ck = w.alloc(n_ck * 16 * q64)
-            w.memset_dev(ck.ptr, 0, n_ck * 16 * q64)
-            w.synth_bases(0x5EED, 0 if args.bases == "distinct" else 1 << 11, n + 3, ck.ptr)     # the same key generated on every rank ...
-            klo, khi = key_shard_range(n_ck, rank, world)                                         # ... of which a rank KEEPS only its slice
-            for x in workers:                                                                     # (the SRS sharding of dispatcher2.rs:260-266)
-                x.init_dev(ck.ptr + klo * 16 * q64, khi - klo, n, m)
-            key = w.alloc(18 * n * 32)
-            circ = w.alloc(11 * n * 32)
-            w.synth_fr(0xC1AC, key.ptr, 18 * n)
-            w.synth_fr(0xC1AD, circ.ptr, 10 * n)
-            w.memset_dev(circ.ptr + 10 * n * 32, 0, n * 32)
-            idx = w.alloc(5 * n * 8).upload((np.arange(5 * n, dtype=np.uint64) * np.uint64(2654435761)) % np.uint64(5 * n))
+            fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
+            TAU = 0x2F0D5EED0C0FFEE0123456789ABCDEF0FEDCBA98765432100F1E2D3C4B5A697 % fld.p
+            G_, r_ = (sim, 0) if sim else (world, rank)
+            inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, init_worker=False)
+            klo, khi = key_shard_range(inst.key_size, r_, G_)                                     # a rank KEEPS only its slice of the key
+            for x in workers[:2]:
+                x.init_dev(inst.d_ck.ptr + klo * 16 * q64, khi - klo, n, m)
             consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-            ch = {k_: consts[i] for i, k_ in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
             bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-            if transport == "rccl" and multi:
+
+            class SimComm:
+                """rank 0 of `size` ranks with nobody else there: collectives return at once (diagnostic timing only)"""
+                rank, size = 0, G_
+
+                def all_gather_host(self, obj):
+                    return [obj] * self.size
+
+                def all_to_all_dev(self, d_send, d_recv, nbytes):
+                    pass
+
+                def all_gather_dev(self, d_send, d_recv, nbytes):
+                    pass
+
+            if sim:
+                comm = SimComm()
+            elif transport == "rccl" and multi:
                 def _boot(obj):
                     out_ = [None] * world
                     dist.all_gather_object(out_, obj)
@@ -1000,26 +1033,38 @@ def main():
             else:
                 comm = TorchComm(w, dev)
             cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
-            cp.load_key_dev([key.ptr + j * n * 32 for j in range(13)], [key.ptr + (13 + j) * n * 32 for j in range(5)], consts[5:10])
-            t_cls = None
+            cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+            pub = inst.public_inputs()
+            vk = cp.verifying_key()                                                               # 18 sharded commitments, once per key
+            t_cls, proof_c = None, None
             for it in range(2):
+                fs = cp.fiat_shamir(pub)
                 full_sync()
                 t0 = time.perf_counter()
-                cp.prove_dev([circ.ptr + j * n * 32 for j in range(5)], circ.ptr + 5 * n * 32, idx.ptr, circ.ptr + 10 * n * 32, bl,
-                             lambda label, _: ch[label], check_degree=False)
+                proof_c = cp.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=not sim)
                 full_sync()
                 t_cls = (time.perf_counter() - t0) * 1e3
             if world > 1:
                 tt = torch.tensor([t_cls], dtype=torch.float64, device=dev)
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 t_cls = float(tt.item())
-            class_row = {"n": n, "ranks": world, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
+            cverified = None
+            if rank == 0 and not sim and not args.no_verify:
+                try:
+                    from oracle import bigint_ref as B_, verifier_ref as V_
+                    V_.verify(B_.CURVES[args.curve], vk, pub, proof_c, TAU, transcript=PlonkTranscript(args.curve))
+                    cverified = True
+                except Exception as ex:
+                    cverified = f"REJECTED: {ex!r}"
+            class_row = {"n": n, "ranks": G_, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
                          "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
-                         "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round)",
+                         "accepted_by_verifier": cverified,
+                         "simulated": bool(sim),
+                         "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round), "
+                                                  "4 all-gathers of 32-byte partials (evaluations, degree, two openings)",
                          "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
             cp.close()
-            for b in (ck, key, circ, idx):
-                b.free()
+            inst.close()
         except Exception as ex:        # every rank raises or none does (same sizes everywhere); the headline must survive either way
             class_row = {"error": repr(ex)}
         arm(None, 0)
@@ -1093,17 +1138,9 @@ def main():
     if world > 1:
         emit()                                   # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
         arm("teardown", 120.0)
-    for pair in buf_n + buf_m:
-        for b in pair:
-            b.free()
+    if buf_n or buf_m:
+        release_step_buffers()
     bases.free()
-    for b in polys + rows_compact + scal:
-        b.free()
-    if cls is not None:
-        for k_ in ("out", "contrib", "recv", "mine", "quot"):
-            cls[k_].free()
-        for b in cls["polys"] + [x for pair in cls["bn"] for x in pair]:
-            b.free()
     for x in workers:
         x.close()
     if dist.is_initialized():

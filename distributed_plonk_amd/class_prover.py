@@ -23,6 +23,7 @@ threads sharing one GPU; tests/test_gloo_multirank.py covers the torch.distribut
 """
 from __future__ import annotations
 
+import os
 import threading
 import time
 from typing import List, Optional
@@ -184,6 +185,8 @@ class ClassProver(Prover):
         w_m = f.root_of_unity(self.m)
         self.shift = f.to_limbs(f.generator * pow(w_m, self.s, f.p))     # g * w_m^s : this rank's class is shift * <w_(m/G)>
         self.inv_G = f.to_limbs(f.inv(G))
+        # A/B knob (bench.py --simulate-ranks): 1 = rounds 4 / 5 and the degree check computed redundantly on every rank as in round 2
+        self.replicated_rounds = os.environ.get("PLONK_CLASS_REPLICATED_ROUNDS") == "1"
 
     # ---- commitments: index-sharded MSMs, ONE all-gather of the round's partial points (dispatcher2.rs:870-892)
     def _commit(self, d_poly: int, length: int):
@@ -259,6 +262,8 @@ class ClassProver(Prover):
     def _evaluate_many(self, polys, points):
         """Round 4 (:545-555): rank s evaluates coefficients [s*L/G, (s+1)*L/G) of every polynomial — sum_i c_i z^i over the slice is
         z^lo times the evaluation of the slice — and the 10 partial values are added across ranks."""
+        if self.replicated_rounds:
+            return super()._evaluate_many(polys, points)
         f, w = self.f, self.w
         rows = np.zeros((len(polys), 4), dtype=np.uint64)
         for j, ((ptr, ln), pt) in enumerate(zip(polys, points)):
@@ -270,6 +275,8 @@ class ClassProver(Prover):
 
     def _degree(self, d_poly: int, length: int) -> int:
         """The quotient is replicated after the all-gather; each rank scans its slice, the highest non-zero index wins."""
+        if self.replicated_rounds:
+            return super()._degree(d_poly, length)
         lo, hi = shard_range(length, self.s, self.G)
         d = self.w.poly_degree_dev(d_poly + lo * 32, hi - lo) if hi > lo else -1
         mine = np.array([lo + d + 1 if d >= 0 else 0], dtype=np.uint64)         # 0 = all zero in my slice
@@ -288,6 +295,8 @@ class ClassProver(Prover):
         piece (c_(lo+1) .. c_hi) with ONE extra top coefficient T = q_hi = sum over the higher ranks' pieces, and
         T = sum_{r' above} z^(lo_r' - hi) * E_r' with E_r' the evaluation of rank r''s own piece at z: 32 bytes per rank and
         polynomial travel, the batch polynomial is only ever formed on the slice (1/G of the scalar * polynomial work)."""
+        if self.replicated_rounds:
+            return super()._openings(alloc, lin_terms, lin_coeffs, batch_terms, batch_coeffs, perm_poly, zeta, zeta_w, PP, keep)
         w, f, p = self.w, self.f, self.f.p
         Lq = PP - 1
         lo, hi = self._commit_range(Lq)
