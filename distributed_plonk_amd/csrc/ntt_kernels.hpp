@@ -179,6 +179,57 @@ __device__ __forceinline__ void shoup_tw_load(const F29S* __restrict__ tab, uint
         cw[4 * j] = d.x; cw[4 * j + 1] = d.y; cw[4 * j + 2] = d.z; cw[4 * j + 3] = d.w;
     }
 }
+// The K radix-2 stages s0 .. s0+K-1 on the 2^K elements of one group (v[k] = row a0 + k * 2^s0, lo = the group's low row bits).
+template <int LOG_R, int K, bool FIRST, bool SHOUP>
+__device__ __forceinline__ void ntt_butterflies(F29 (&v)[1 << K], int s0, uint32_t lo, const uint32_t* tw_lds, const F29S* __restrict__ tw_shoup,
+                                                const F29Params& fp) {
+    constexpr int R = 1 << LOG_R;
+    constexpr int RADIX = 1 << K;
+    constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
+    const uint32_t h = 1u << s0;
+#pragma unroll
+    for (int ds = 0; ds < K; ds++) {
+        const int span = 1 << ds;
+#pragma unroll
+        for (int k = 0; k < RADIX; k++) {
+            if (k & span) continue;
+            const int kk = k & (span - 1);
+            F29 tt;
+            const F29 x = v[k];
+            if (FIRST && kk == 0 && ds <= 1) {
+                // first step (s0 = 0, lo = 0): exponent kk << ... is 0, the twiddle is 1 — no product.
+                // ds == 0: the partner is a fresh input (< 1.4p, normalised): x + 2p - y.
+                // ds == 1: the partner is the lazy sum of two inputs (< 2.8p, limbs <= 2^30 - 2), so the
+                //          offset must be 4p or the VALUE can go negative (caught by tests/test_gpu_fullsize.py).
+                tt = v[k + span];
+                v[k] = f29_add(x, tt);
+                v[k + span] = (ds == 0) ? f29_sub2p(x, tt, fp) : f29_sub4p(x, tt, fp);
+            } else {
+                const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
+                if constexpr (SHOUP) {
+                    uint32_t cw[20];
+                    shoup_tw_load<LOG_R>(tw_shoup, e, cw);
+                    tt = f29_mul_shoup(v[k + span], cw, cw + 9, fp);
+                    v[k] = f29_add(x, tt);
+                    v[k + span] = f29_sub4p(x, tt, fp);
+                } else {
+                    F29 tw;
+#pragma unroll
+                    for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
+                    tt = f29_mul(v[k + span], tw, fp);
+                    v[k] = f29_add(x, tt);
+                    v[k + span] = f29_sub2p(x, tt, fp);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);   // one butterfly's temporaries live at a time (interleaving two spills at 128 VGPRs: measured 1.6x slower)
+        }
+        if (ds == 1 || ds == K - 1) {
+#pragma unroll
+            for (int k = 0; k < RADIX; k++) f29_norm(v[k]);
+        }
+    }
+}
+
 // SHOUP: the butterfly products use the precomputed-quotient multiplier with twiddles fetched from the 80-byte global table (five
 // 128-bit loads per product on the otherwise idle vector-memory pipe; the table is L1-resident) instead of Montgomery products
 // with twiddles from LDS: 143 limb products instead of 171 + 9.  Its result is < 3p, so butterflies subtract from 4p and bounds
@@ -191,7 +242,6 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
     constexpr int RADIX = 1 << K;
     constexpr int NG = EPT / RADIX;
     constexpr int GROUPS_PER_STRIDE = R / EPT;     // lanes along `w`
-    constexpr int TWN = (R / 2 > 0) ? R / 2 : 1;
     const uint32_t h = 1u << s0;
 #pragma unroll
     for (int g = 0; g < NG; g++) {
@@ -202,51 +252,50 @@ __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw
         const uint32_t fa = sw_fold<SWZ>(a0);
 #pragma unroll
         for (int k = 0; k < RADIX; k++) v[k] = tile.get(((a0 + k * h) ^ fa ^ sw_fold<SWZ>(k * h)) * pitch + t);
-#pragma unroll
-        for (int ds = 0; ds < K; ds++) {
-            const int span = 1 << ds;
-#pragma unroll
-            for (int k = 0; k < RADIX; k++) {
-                if (k & span) continue;
-                const int kk = k & (span - 1);
-                F29 tt;
-                const F29 x = v[k];
-                if (FIRST && kk == 0 && ds <= 1) {
-                    // first step (s0 = 0, lo = 0): exponent kk << ... is 0, the twiddle is 1 — no product.
-                    // ds == 0: the partner is a fresh input (< 1.4p, normalised): x + 2p - y.
-                    // ds == 1: the partner is the lazy sum of two inputs (< 2.8p, limbs <= 2^30 - 2), so the
-                    //          offset must be 4p or the VALUE can go negative (caught by tests/test_gpu_fullsize.py).
-                    tt = v[k + span];
-                    v[k] = f29_add(x, tt);
-                    v[k + span] = (ds == 0) ? f29_sub2p(x, tt, fp) : f29_sub4p(x, tt, fp);
-                } else {
-                    const uint32_t e = (lo + kk * h) << (LOG_R - s0 - ds - 1);
-                    if constexpr (SHOUP) {
-                        uint32_t cw[20];
-                        shoup_tw_load<LOG_R>(tw_shoup, e, cw);
-                        tt = f29_mul_shoup(v[k + span], cw, cw + 9, fp);
-                        v[k] = f29_add(x, tt);
-                        v[k + span] = f29_sub4p(x, tt, fp);
-                    } else {
-                        F29 tw;
-#pragma unroll
-                        for (int l = 0; l < 9; l++) tw.l[l] = tw_lds[l * TWN + e];
-                        tt = f29_mul(v[k + span], tw, fp);
-                        v[k] = f29_add(x, tt);
-                        v[k + span] = f29_sub2p(x, tt, fp);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);   // one butterfly's temporaries live at a time (interleaving two spills at 128 VGPRs: measured 1.6x slower)
-            }
-            if (ds == 1 || ds == K - 1) {
-#pragma unroll
-                for (int k = 0; k < RADIX; k++) f29_norm(v[k]);
-            }
-        }
+        ntt_butterflies<LOG_R, K, FIRST, SHOUP>(v, s0, lo, tw_lds, tw_shoup, fp);
 #pragma unroll
         for (int k = 0; k < RADIX; k++) tile.put(((a0 + k * h) ^ fa ^ sw_fold<SWZ>(k * h)) * pitch + t, v[k]);
     }
 }
+
+#ifdef NTT_XLANE
+// EXPERIMENT (north_star: "wavefront-shuffle reductions"; built only with -DNTT_XLANE, profiles/r03_ntt_xlane_experiment.txt): stages
+// 0..3 of the in-LDS transform WITHOUT the LDS round trip between the first two steps.  After stages 0-1 lane w holds rows 4w + k;
+// stages 2-3 want rows (w >> 2) * 16 + (w & 3) + 4k: a 4 x 4 transpose between the register index k and the two low bits of w.
+// With those two bits placed on lane bits 4 and 5 (the lane <-> w assignment is free as long as it is used consistently) the
+// transpose is two rounds of gfx950's v_permlane16_swap / v_permlane32_swap — one VALU instruction per limb and register pair, no
+// select, no LDS traffic, no barrier: 36 instructions per lane instead of 36 ds_write + 36 ds_read + s_barrier.
+template <int LOG_R, bool SWZ, bool SHOUP>
+__device__ __forceinline__ void ntt_steps0123_xlane(const LdsTile& tile, const uint32_t* tw_lds, const F29S* __restrict__ tw_shoup, uint32_t w, uint32_t t,
+                                                    uint32_t pitch, const F29Params& fp) {
+    // w = u >> 3: its bits 0, 1, 2 are lane bits 3, 4, 5.  w_eff: bit 0 <- lane bit 4, bit 1 <- lane bit 5, bit 2 <- lane bit 3.
+    const uint32_t we = (w & ~7u) | ((w >> 1) & 3u) | ((w & 1u) << 2);
+    F29 v[4];
+    {
+        const uint32_t a0 = we << 2, fa = sw_fold<SWZ>(a0);
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = tile.get(((a0 + k) ^ fa ^ sw_fold<SWZ>(k)) * pitch + t);
+    }
+    ntt_butterflies<LOG_R, 2, true, SHOUP>(v, 0, 0, tw_lds, tw_shoup, fp);
+#pragma unroll
+    for (int l = 0; l < 9; l++) {                                       // register bit 0 <-> lane bit 4
+        auto r01 = __builtin_amdgcn_permlane16_swap(v[0].l[l], v[1].l[l], false, false);
+        auto r23 = __builtin_amdgcn_permlane16_swap(v[2].l[l], v[3].l[l], false, false);
+        v[0].l[l] = r01[0]; v[1].l[l] = r01[1]; v[2].l[l] = r23[0]; v[3].l[l] = r23[1];
+    }
+#pragma unroll
+    for (int l = 0; l < 9; l++) {                                       // register bit 1 <-> lane bit 5
+        auto r02 = __builtin_amdgcn_permlane32_swap(v[0].l[l], v[2].l[l], false, false);
+        auto r13 = __builtin_amdgcn_permlane32_swap(v[1].l[l], v[3].l[l], false, false);
+        v[0].l[l] = r02[0]; v[2].l[l] = r02[1]; v[1].l[l] = r13[0]; v[3].l[l] = r13[1];
+    }
+    const uint32_t lo = we & 3u, hi = we >> 2;
+    ntt_butterflies<LOG_R, 2, false, SHOUP>(v, 2, lo, tw_lds, tw_shoup, fp);
+    const uint32_t a0 = (hi << 4) | lo, fa = sw_fold<SWZ>(a0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) tile.put(((a0 + k * 4) ^ fa ^ sw_fold<SWZ>(k * 4)) * pitch + t, v[k]);
+}
+#endif
 
 template <int LOG_R, int EPT_REQ, bool SWZ = false, bool SHOUP = false>
 __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(const NttPassParams P) {
@@ -337,10 +386,21 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
             __syncthreads();
         } else {
             if constexpr (SFULL > 0) {
-                ntt_step<LOG_R, KMAX, EPT, true, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, 0, w, t, pitch, P.fp);
+#ifdef NTT_XLANE
+                constexpr bool XL = SWZ && EPT == 4 && LOG_R >= 7;       // one group per lane, 8-column tiles: w = u >> 3
+#else
+                constexpr bool XL = false;
+#endif
+                if constexpr (XL) {
+#ifdef NTT_XLANE
+                    ntt_steps0123_xlane<LOG_R, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, w, t, pitch, P.fp);
+#endif
+                } else {
+                    ntt_step<LOG_R, KMAX, EPT, true, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, 0, w, t, pitch, P.fp);
+                }
                 __syncthreads();
 #pragma unroll 1
-                for (int s = KMAX; s < SFULL; s += KMAX) {
+                for (int s = XL ? 2 * KMAX : KMAX; s < SFULL; s += KMAX) {
                     ntt_step<LOG_R, KMAX, EPT, false, SWZ, SHOUP>(tile, tw_lds, P.tw_shoup, s, w, t, pitch, P.fp);
                     __syncthreads();
                 }
