@@ -2,8 +2,8 @@
 # Round profile collection on the GPU box (gpurun): kernel-trace stats of the default bench command, then the PMC passes — FETCH_SIZE,
 # WRITE_SIZE and the SQ counters each in its OWN rocprofv3 run (MI355X_MICROARCH.md; never combined with other trace domains) —
 # merged by tools/pmc_collect.py into one small JSON stamped with the kernel-source hash.  Everything lands in gpurun_out/; copy
-# the summaries into profiles/ afterwards (tools/collect_profiles.sh prints the cp lines).   usage: bash tools/collect_profiles.sh r02
-TAG=${1:-r02}
+# the summaries into profiles/ afterwards (tools/collect_profiles.sh prints the cp lines).   usage: bash tools/collect_profiles.sh r03
+TAG=${1:-r03}
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
@@ -22,8 +22,12 @@ if [ -x $R/tools/fetch_calib_bin ]; then
   python tools/fetch_calib_report.py $O/pmc_calib > $O/${TAG}_fetch_calibration.txt; cat $O/fetch_calib.out >> $O/${TAG}_fetch_calibration.txt
   cat $O/${TAG}_fetch_calibration.txt
 fi
+# one 2^24 MSM ALONE (single context, nothing interleaved): the sort / reduce / accumulate costs without the second stream's contention
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_msm_alone -o m -- python $R/tools/msm_only.py 24 > $O/${TAG}_msm_alone.log 2>&1
+find $O/prof_msm_alone -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_msm_alone_2p24.csv \;
+find $O/prof_msm_alone -name "*.csv" -delete 2>/dev/null
 # keep the merged-back payload small: drop the per-dispatch traces and raw counter dumps
 find $O/prof_stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_calib -name "*.csv" -delete 2>/dev/null
 ls -la $O/pmc_current.json $O/${TAG}_kernel_stats_2p24.csv
 head -5 $O/${TAG}_kernel_stats_2p24.csv | cut -c1-160
-echo "cp gpurun_out/pmc_current.json profiles/pmc_current.json; cp gpurun_out/pmc_current.json profiles/${TAG}_pmc_2p24.json; cp gpurun_out/${TAG}_kernel_stats_2p24.csv profiles/; cp gpurun_out/${TAG}_fetch_calibration.txt profiles/"
+echo "cp gpurun_out/pmc_current.json profiles/pmc_current.json; cp gpurun_out/pmc_current.json profiles/${TAG}_pmc_2p24.json; cp gpurun_out/${TAG}_kernel_stats_2p24.csv profiles/; cp gpurun_out/${TAG}_fetch_calibration.txt profiles/; cp gpurun_out/${TAG}_kernel_stats_msm_alone_2p24.csv profiles/"
