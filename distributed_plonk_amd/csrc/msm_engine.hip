@@ -277,6 +277,71 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
     }
 }
 
+// Level 2 for WIDE windows (2^low_bits >= 256 buckets per partition, i.e. c >= 19 at 2^24 points): the direct scatter above keeps
+// 512 one-cache-line runs open per workgroup for the workgroup's whole life, and with ~2000 workgroups in flight those partial lines
+// fall out of L2 before they are full (6.2 ms at c = 20 against 1.5 ms at c = 17 for the same bytes).  Here the partition (<= STAGE_CAP
+// entries; larger ones — skewed scalars — take the direct path) is ordered in LDS and leaves in consecutive addresses: counts ->
+// exclusive scan -> ranks into the LDS buffer -> coalesced copy-out.  1024 lanes on ~78 KiB of LDS: two workgroups = eight waves per
+// SIMD, like the level-1 scatter.  tmp is read twice; its 64 KiB per partition are L2 / Infinity-Cache resident.
+#define STAGE_CAP 18432u
+#define STAGE_THREADS 1024
+__global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
+                                                                              uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t nlow = 1u << g.low_bits;
+    uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors (relative to the partition start)
+    uint32_t* run0 = lds + nlow;               // [nblk] start of every slice's run inside this partition (idx_bits == 0 only)
+    uint32_t* buf = run0 + (g.idx_bits ? 0 : g.nblk);      // [STAGE_CAP] final entries in bucket order
+    uint32_t* strip = buf;                     // [STAGE_THREADS] scratch of the scan, dead before buf is filled
+    const uint64_t pid = blockIdx.x;
+    const uint32_t* po = blk_off + pid * g.nblk;
+    const uint32_t pbeg = po[0], pend = po[g.nblk], len = pend - pbeg;
+    const int sh = g.idx_bits ? (int)g.idx_bits + 1 : SORT_SLICE_LOG + 1;
+    const bool staged = len <= STAGE_CAP;
+    for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) cnt[k] = 0;
+    if (!g.idx_bits)
+        for (uint32_t k = threadIdx.x; k < g.nblk; k += blockDim.x) run0[k] = po[k];
+    __syncthreads();
+    for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) atomicAdd(&cnt[tmp[j] >> sh], 1u);
+    __syncthreads();
+    // exclusive scan of the nlow (<= 2048) counts: two entries per lane at most, then a strip-sum scan
+    const uint32_t per = (nlow + blockDim.x - 1) / blockDim.x;
+    const uint32_t s0 = threadIdx.x * per < nlow ? threadIdx.x * per : nlow, s1 = s0 + per < nlow ? s0 + per : nlow;
+    uint32_t acc = 0;
+    for (uint32_t k = s0; k < s1; k++) acc += cnt[k];
+    strip[threadIdx.x] = acc;
+    __syncthreads();
+    for (int dd = 1; dd < STAGE_THREADS; dd <<= 1) {
+        const uint32_t t = (int)threadIdx.x >= dd ? strip[threadIdx.x - dd] : 0;
+        __syncthreads();
+        strip[threadIdx.x] += t;
+        __syncthreads();
+    }
+    uint32_t run = strip[threadIdx.x] - acc;
+    __syncthreads();                           // every lane has read its strip value: the scratch may be overwritten from here on
+    for (uint32_t k = s0; k < s1; k++) { const uint32_t v = cnt[k]; cnt[k] = run; offsets[(pid << g.low_bits) + k] = pbeg + run; run += v; }
+    if (pid == g.nreal - 1 && threadIdx.x == 0) offsets[(uint64_t)g.nreal << g.low_bits] = pend;      // end sentinel
+    __syncthreads();
+    const uint32_t in_mask = SORT_SLICE - 1;
+    const uint32_t imask = g.idx_bits ? (1u << g.idx_bits) - 1 : 0;
+    for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
+        const uint32_t e = tmp[j];
+        uint32_t val;
+        if (g.idx_bits) {
+            val = (e & imask) | (((e >> g.idx_bits) & 1u) << 31);
+        } else {
+            uint32_t lo = 0, hi = g.nblk;      // slice = largest b with run0[b] <= j
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run0[mid] <= j) lo = mid; else hi = mid; }
+            val = ((lo << SORT_SLICE_LOG) + (e & in_mask)) | (((e >> SORT_SLICE_LOG) & 1u) << 31);
+        }
+        const uint32_t pos = atomicAdd(&cnt[e >> sh], 1u);
+        if (staged) buf[pos] = val; else sorted[pbeg + pos] = val;
+    }
+    if (!staged) return;
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < len; j += blockDim.x) sorted[pbeg + j] = buf[j];
+}
+
 // ---------------------------------------------------------------------------------------------- 3b: schedule buckets by size
 // One lane owns one bucket, so a wave runs as long as its fullest bucket.  A counting sort of the bucket
 // ids by (clamped) size, largest first, puts equally loaded buckets in the same wave.
@@ -574,11 +639,13 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
 #define REDUCE_K (1u << REDUCE_LOGK)
 // ---------------------------------------------------------------------------------------------- 5: window reduction
 // V_w = sum_j (j+1) * B_j over the 2^cb buckets of a window, as a short pyramid of running-sum passes:
-//   level l holds n_l = 2^cb / K^l entries (K = REDUCE_K = 4: the serial depth 2K*log_K(2^cb) is what bounds
-//   this phase, not its work); one lane takes a chunk of min(K, n_l) entries and emits
-//   acc = sum_t t * E_t  and  S = sum_t E_t  (2K point additions, no scalar multiplications);
-//   the S values are the next level's entries.  With A_l = sum of level l's acc values and Sigma = the single
-//   entry left at the top:  V_w = Sigma + sum_l K^l * A_l   (host: a handful of doublings per window).
+//   level l holds n_l = 2^cb / K^l entries E_j with weights (j+1) (K = REDUCE_K = 4: the serial depth 2K*log_K(2^cb) is what
+//   bounds this phase, not its work); one lane takes the STRIDED chunk {ch + t * nch_l : t < K_l} (nch_l = n_l / K_l chunks; K_l =
+//   min(K, n_l)) and emits  acc = sum_t t * E_(ch + t nch)  and  S_ch = sum_t E_(ch + t nch)  (2K point additions, no scalar
+//   multiplications).  Since (j+1) = (ch+1) + t * nch_l:  sum_j (j+1) E_j = sum_ch (ch+1) S_ch + nch_l * sum_ch acc_ch — the S values
+//   are the next level's entries with the same kind of weights.  With A_l = sum of level l's acc values and Sigma = the single entry
+//   left at the top:  V_w = Sigma + sum_l nch_l * A_l  (host: Horner, log2 K_l doublings per level).  Strided rather than contiguous
+//   chunks (round 3): consecutive lanes read consecutive 144-byte entries, a wave's working set per step is 9 KiB instead of 36 KiB.
 // All in lazy limb arithmetic (ec_lazy.hpp); only the W*(L+1) results are converted to the standard form.
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ in, uint64_t n_in,
@@ -591,12 +658,12 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XyzzL<LimbG
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
     const uint64_t w = id / nch, ch = id % nch;
-    const XyzzL<NL, B>* E = in + w * n_in + ch * K;
+    const XyzzL<NL, B>* E = in + w * n_in + ch;           // STRIDED chunk: entries ch, ch + nch, ..., ch + (K-1)*nch
     XyzzL<NL, B> running = xyzzl_inf<NL, B>(), acc = xyzzl_inf<NL, B>();
     bool ok = true;
     for (uint32_t d = K; d-- > 0;) {
         if (!xyzzl_add_fast(acc, running, P)) { ok = false; break; }
-        if (!xyzzl_add_fast(running, load8(E + d), P)) { ok = false; break; }
+        if (!xyzzl_add_fast(running, load8(E + (uint64_t)d * nch), P)) { ok = false; break; }
     }
     if (ok) {
         store8(out_acc + id, acc);
@@ -618,11 +685,11 @@ __global__ void __launch_bounds__(64) msm_reduce_level_redo_kernel(const XyzzL<L
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint64_t id = redo_list[i];
         const uint64_t w = id / nch, ch = id % nch;
-        const XyzzL<NL, B>* E = in + w * n_in + ch * K;
+        const XyzzL<NL, B>* E = in + w * n_in + ch;
         XyzzL<NL, B> running = xyzzl_inf<NL, B>(), acc = xyzzl_inf<NL, B>();
         for (uint32_t d = K; d-- > 0;) {
             acc = xyzzl_add(acc, running, P);
-            running = xyzzl_add(running, load8(E + d), P);
+            running = xyzzl_add(running, load8(E + (uint64_t)d * nch), P);
         }
         store8(out_acc + id, acc);
         store8(out_s + id, running);
@@ -633,17 +700,22 @@ __global__ void __launch_bounds__(64) msm_reduce_level_redo_kernel(const XyzzL<L
 struct SumJobs {
     const void* src[16];
     uint64_t count[16];
+    uint64_t wstride[16];      // points between the inputs of consecutive windows (0: = count, the dense layout of the pyramid arrays)
 };
 #define SUM_SPLIT_MAX 16  // workgroups per (level, window) sum in merged (table) mode: 2^17 level-0 values and only one window; 1 otherwise
-template <int NQ>
+// RAW: the block's sum stays in the limb form (input of a second, combining launch) instead of being converted to the standard form.
+// Large pyramids (c = 20: 2^17 level-0 values per window) are summed by `nsplit` workgroups per (level, window) and a second launch
+// folds the nsplit partials — one workgroup per (level, window) used to walk 512 points per lane: 6.6 of the 9 ms a c = 20 reduction took.
+template <int NQ, bool RAW = false>
 __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels, uint32_t nsplit,
-                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
+                                                             XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_raw = nullptr) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
     const uint32_t l = blockIdx.x, w = blockIdx.y, z = blockIdx.z;
     const uint64_t cnt = jobs.count[l];
-    const XyzzL<NL, B>* src = reinterpret_cast<const XyzzL<NL, B>*>(jobs.src[l]) + (uint64_t)w * cnt;
+    const XyzzL<NL, B>* src = reinterpret_cast<const XyzzL<NL, B>*>(jobs.src[l]) + (uint64_t)w * (jobs.wstride[l] ? jobs.wstride[l] : cnt);
     XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
     for (uint64_t i = (uint64_t)z * blockDim.x + threadIdx.x; i < cnt; i += (uint64_t)nsplit * blockDim.x) acc = xyzzl_add(acc, load8(src + i), P);
     sh[threadIdx.x] = acc;
@@ -655,7 +727,10 @@ __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzP
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) store_std<NQ>(out + ((uint64_t)w * nlevels + l) * nsplit + z, sh[0], P);
+    if (threadIdx.x == 0) {
+        if (RAW) store8(out_raw + ((uint64_t)w * nlevels + l) * nsplit + z, sh[0]);
+        else store_std<NQ>(out + ((uint64_t)w * nlevels + l) * nsplit + z, sh[0], P);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
@@ -752,7 +827,8 @@ static bool sort_geometry(int cb, size_t n, int* lp_out) {
     return true;
 }
 
-static double g_reduce_cost = 2.7 * 3300.0 * 2.0;     // VALU instructions per bucket in the reduction pyramid (x2: it runs at lower occupancy)
+static double g_reduce_cost = 2.7 * 3300.0;           // VALU instructions per bucket in the reduction pyramid (round 3: the x2 for its low occupancy went
+                                                      // with the split per-level sums and the LDS-staged level-2 sort: c = 20 now wins at 2^24 points)
 // measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
 // addition; the reduction pyramid does ~2.7 full additions per bucket
 static bool window_usable(size_t n, int bits, int c) {
@@ -908,7 +984,10 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const uint32_t nsplit = merged ? SUM_SPLIT_MAX : 1;
+    // plain mode: the per-(level, window) sums of large pyramids are split over `gsplit` workgroups and folded by a second launch
+    const uint32_t gsplit = merged ? 1 : (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (nlev ? lev_nch[0] : 1) / 8192));
     const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * nsplit * sizeof(XyzzPt<NQ>), 256);
+    const size_t o_wpart = off; off = align_up(off + (gsplit > 1 ? (size_t)Wr * (nlev + 1) * gsplit * sizeof(BucketL) : 0), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
@@ -930,6 +1009,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     BucketL* s_arr = (BucketL*)(base + o_sarr);
     XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
     BucketL* hpart = (BucketL*)(base + o_hpart);
+    BucketL* wpart = (BucketL*)(base + o_wpart);
 
     const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
     { ProfScope ps("msm_digits_kernel", stream);
@@ -950,7 +1030,17 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     }
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(SCATTER_THREADS), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
                        blk_off, tmp);
-    hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets); }
+    const size_t lds_staged = (((size_t)1 << g.low_bits) + (g.idx_bits ? 0 : g.nblk) + STAGE_CAP) * 4;
+    if (g.low_bits >= 8 && lds_staged <= 78 * 1024 && !getenv("PLONK_MSM_NO_STAGED_SORT")) {
+        static bool attr2 = false;
+        if (!attr2) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_partition_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+            attr2 = true;
+        }
+        hipLaunchKernelGGL(sort_partition_staged_kernel, dim3(g.nreal), dim3(STAGE_THREADS), lds_staged, stream, tmp, g, blk_off, sorted, offsets);
+    } else {
+        hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets);
+    } }
     { ProfScope ps("msm_bucket_order", stream);
     HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
@@ -993,8 +1083,22 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
         }
         jobs.src[nlev] = in;            // the single entry left per window: Sigma (nb == 1: the bucket itself)
         jobs.count[nlev] = 1;
-        hipLaunchKernelGGL(msm_points_sum_kernel<NQ>, dim3(nlev + 1, Wr, nsplit), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1), nsplit,
-                           fl_params<NQ>(curve));
+        if (gsplit > 1) {
+            hipLaunchKernelGGL((msm_points_sum_kernel<NQ, true>), dim3(nlev + 1, Wr, gsplit), dim3(256), 256 * sizeof(BucketL), stream, jobs, (XyzzPt<NQ>*)nullptr,
+                               (uint32_t)(nlev + 1), gsplit, fl_params<NQ>(curve), wpart);
+            SumJobs fold;
+            memset(&fold, 0, sizeof fold);
+            for (int l = 0; l <= nlev; l++) {
+                fold.src[l] = wpart + (size_t)l * gsplit;
+                fold.count[l] = gsplit;
+                fold.wstride[l] = (uint64_t)(nlev + 1) * gsplit;
+            }
+            hipLaunchKernelGGL((msm_points_sum_kernel<NQ, false>), dim3(nlev + 1, Wr, 1), dim3(256), 256 * sizeof(BucketL), stream, fold, wsum, (uint32_t)(nlev + 1), 1u,
+                               fl_params<NQ>(curve), (BucketL*)nullptr);
+        } else {
+            hipLaunchKernelGGL((msm_points_sum_kernel<NQ, false>), dim3(nlev + 1, Wr, nsplit), dim3(256), 256 * sizeof(BucketL), stream, jobs, wsum, (uint32_t)(nlev + 1), nsplit,
+                               fl_params<NQ>(curve), (BucketL*)nullptr);
+        }
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
@@ -1013,10 +1117,11 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
             for (uint32_t z = 1; z < nsplit; z++) t = xyzz_add(t, hw[(size_t)l * nsplit + z], P);
             return t;
         };
+        // V_w = Sigma + sum_l nch_l A_l,  nch_l = nch_(l+1) * K_(l+1),  nch_(nlev-1) = 1:  Horner from level 0
         XyzzPt<NQ> v = xyzz_inf<NQ>();
-        for (int l = nlev - 1; l >= 0; l--) {
+        for (int l = 0; l < nlev; l++) {
             if (!xyzz_is_inf(v))
-                for (int k = 0; k < REDUCE_LOGK; k++) v = xyzz_dbl(v, P);
+                for (uint64_t k = lev_k[l]; k > 1; k >>= 1) v = xyzz_dbl(v, P);
             v = xyzz_add(v, part(l), P);
         }
         v = xyzz_add(v, part(nlev), P);
