@@ -635,7 +635,9 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
     }
 }
 
+#ifndef REDUCE_LOGK
 #define REDUCE_LOGK 2
+#endif
 #define REDUCE_K (1u << REDUCE_LOGK)
 // ---------------------------------------------------------------------------------------------- 5: window reduction
 // V_w = sum_j (j+1) * B_j over the 2^cb buckets of a window, as a short pyramid of running-sum passes:
