@@ -225,6 +225,9 @@ def main():
     if os.environ.get("PLONK_BENCH_MSM_WINDOW"):                 # experiment knob: force the Pippenger window (0 / unset: the library's cost model)
         for x in workers:
             x.set_option("msm_window", int(os.environ["PLONK_BENCH_MSM_WINDOW"]))
+    if os.environ.get("PLONK_BENCH_ACC_PERSIST") is not None:    # experiment knob: workgroups per CU of the persistent accumulation (0 = plain grid)
+        for x in workers:
+            x.set_option("msm_acc_persist", int(os.environ["PLONK_BENCH_ACC_PERSIST"]))
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
     transport = args.transport if (world > 1 or args.multi_path) else "torch"
     rccl_info = None

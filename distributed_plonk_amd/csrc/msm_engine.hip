@@ -526,31 +526,48 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
                                                              const uint32_t* __restrict__ order, uint64_t nbuckets, uint64_t nb, uint32_t Wm, uint64_t tab_stride,
                                                              uint32_t heavy_thresh, XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
                                                              uint32_t* __restrict__ redo_list, uint32_t* __restrict__ heavy_count,
-                                                             uint32_t* __restrict__ heavy_list,
+                                                             uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ work,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nbuckets) return;
-    const uint32_t b = order[i];
-    if (bucket_entries(offsets, b, nb, Wm) > heavy_thresh) {   // skewed scalars / a nearly empty top window: one lane must not walk it alone
-        heavy_list[atomicAdd(heavy_count, 1u)] = b;
-        return;
-    }
-    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-    bool ok = true;
-    for (uint32_t w = 0; w < Wm && ok; w++) {                    // Wm == 1 unless the fixed-base table is in use
-        const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
-        const AffL<NL, B>* tb = bases + w * tab_stride;          // 2^(c*w) * P_i
-        for (uint32_t j = beg; j < end; j++) {
-            const uint32_t e = sorted[j];
-            AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
-            if (affl_is_inf(q)) continue;
-            if (e >> 31) q = affl_neg(q, P);
-            if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
+    // work == nullptr: one lane per bucket, grid = nbuckets / 256.  work != nullptr: PERSISTENT waves — the grid is a fixed number of workgroups
+    // (msm_acc_persist per CU, default 4 = every wave slot the registers allow) and every wave takes the next 64 buckets of the size-ordered
+    // list from a global counter until the list is exhausted: no rounds of workgroups, so the 2^14 thousand-entry buckets of a c = 20 top window
+    // (the launch's 13 ms critical path, started first) never hold a half-empty round open behind them, and the tail is one 64-bucket group per
+    // wave: 16.6 -> 16.1 ms alone at 2^24, commitments -1.4 ... -2.4 % per step (profiles/r03_commit_overlap_experiment.txt).
+    const uint32_t lane = threadIdx.x & 63u;
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (;;) {
+        if (work) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(work, 64u);
+            base = (uint32_t)__shfl((int)base, 0);
+            if (base >= nbuckets) break;
+            i = (uint64_t)base + lane;
         }
+        if (i < nbuckets) {
+            const uint32_t b = order[i];
+            if (bucket_entries(offsets, b, nb, Wm) > heavy_thresh) {   // skewed scalars / a nearly empty top window: one lane must not walk it alone
+                heavy_list[atomicAdd(heavy_count, 1u)] = b;
+            } else {
+                XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+                bool ok = true;
+                for (uint32_t w = 0; w < Wm && ok; w++) {                    // Wm == 1 unless the fixed-base table is in use
+                    const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
+                    const AffL<NL, B>* tb = bases + w * tab_stride;          // 2^(c*w) * P_i
+                    for (uint32_t j = beg; j < end; j++) {
+                        const uint32_t e = sorted[j];
+                        AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                        if (affl_is_inf(q)) continue;
+                        if (e >> 31) q = affl_neg(q, P);
+                        if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
+                    }
+                }
+                if (ok) store8(buckets + b, acc);
+                else redo_list[atomicAdd(redo_count, 1u)] = b;
+            }
+        }
+        if (!work) break;
     }
-    if (ok) store8(buckets + b, acc);
-    else redo_list[atomicAdd(redo_count, 1u)] = b;
 }
 
 // Heavy buckets: HEAVY_SEGS workgroups share one bucket (strided slices), every lane accumulates a strided subset
@@ -901,6 +918,11 @@ int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, in
     return msm_table_build_t<12>(curve, d_table, n, stride, c, W, stream);
 }
 
+void msm_ws_release(MsmWorkspace& ws) {
+    if (ws.d_buf) (void)hipFree(ws.d_buf);
+    ws.d_buf = nullptr; ws.bytes = 0;
+}
+
 static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
     if (ws.bytes >= bytes) return PLONK_OK;
     if (ws.d_buf) (void)hipFree(ws.d_buf);
@@ -968,6 +990,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_order = off; off = align_up(off + nbuckets * 4, 256);
     const size_t o_redo = off; off = align_up(off + (nbuckets + 1) * 4, 256);
     const size_t o_szh = off; off = align_up(off + 2 * SIZE_BINS * 4, 256);
+    const size_t o_work = off; off = align_up(off + 4, 256);       // work counter of the persistent accumulation
     const uint64_t max_heavy = ((uint64_t)n * W) / heavy_thresh + 1;     // a bucket is heavy only above heavy_thresh entries
     const size_t o_heavy = off; off = align_up(off + (max_heavy + 1) * 4, 256);
     typedef XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> BucketL;
@@ -1051,13 +1074,32 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, ghist);
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
     hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, bin_cursor, order); }
+    // "msm_acc_persist" (default 4): the accumulation as that many workgroups per CU of persistent waves; 0 = one lane per bucket over the whole grid
+    uint32_t* work = nullptr;
+    uint32_t acc_grid = (uint32_t)((nbuckets + 255) / 256);
+    if (ws.acc_persist != 0) {
+        static int n_cu = 0;
+        if (!n_cu) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            HIP_TRY(hipGetDevice(&dev));
+            HIP_TRY(hipGetDeviceProperties(&prop, dev));
+            n_cu = std::max(prop.multiProcessorCount, 1);
+        }
+        const uint32_t pgrid = ws.acc_persist > 0 ? (uint32_t)n_cu * (uint32_t)ws.acc_persist : (uint32_t)(-ws.acc_persist);   // < 0: absolute grid (tests)
+        if (pgrid < acc_grid) {                                   // small problems keep the plain grid
+            work = (uint32_t*)(base + o_work);
+            HIP_TRY(hipMemsetAsync(work, 0, 4, stream));
+            acc_grid = pgrid;
+        }
+    }
     { ProfScope ps("msm_accumulate_kernel", stream);
     if (ws.fused_y3)
-        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, true>), dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve));
+        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, true>), dim3(acc_grid), dim3(256), 0, stream, d_bases, sorted, offsets, order,
+                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve));
     else
-        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, false>), dim3((uint32_t)((nbuckets + 255) / 256)), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, fl_params<NQ>(curve)); }
+        hipLaunchKernelGGL((msm_accumulate_kernel<NQ, false>), dim3(acc_grid), dim3(256), 0, stream, d_bases, sorted, offsets, order,
+                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_heavy", stream);
     hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, nb, Wm, tab_stride,
                        heavy, heavy + 1, hpart, fl_params<NQ>(curve));

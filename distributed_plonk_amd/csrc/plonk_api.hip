@@ -179,7 +179,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     if (ctx->d_wire) (void)hipFree(ctx->d_wire);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
-    if (ctx->msm_ws.d_buf) (void)hipFree(ctx->msm_ws.d_buf);
+    msm_ws_release(ctx->msm_ws);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipStreamDestroy(ctx->stream);
@@ -202,6 +202,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "ntt_max_log_r")) { ctx->tables.max_log_r = (int)value; return PLONK_OK; }
     if (!strcmp(key, "msm_batch_max")) { ctx->msm_ws.batch_max = (int)value; return PLONK_OK; }      // vectors per launch set of commit_many
     if (!strcmp(key, "msm_fused_y3")) { ctx->msm_ws.fused_y3 = value ? 1 : 0; return PLONK_OK; }      // default 1
+    if (!strcmp(key, "msm_acc_persist")) { ctx->msm_ws.acc_persist = (int)std::max<int64_t>(-65536, std::min<int64_t>(value, 8)); return PLONK_OK; }   // default 4; < 0: an absolute grid of -value workgroups (tests)
     if (!strcmp(key, "quotient_fuse")) { ctx->tables.quotient_fuse = (int)value; return PLONK_OK; }   // experiments, see quotient.hip
     if (!strcmp(key, "msm_slice_log")) { ctx->msm_ws.slice_log = (int)value; return PLONK_OK; }       // MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);

@@ -152,7 +152,9 @@ struct MsmWorkspace {
     int slice_log = 26;       // "msm_slice_log": MSMs above 2^slice_log points run slice by slice (workspace sizing)
     int batch_max = 32;       // "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
     int fused_y3 = 1;         // "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
+    int acc_persist = 4;      // "msm_acc_persist": workgroups per CU of the persistent bucket accumulation (0 = one lane per bucket over the whole grid; < 0: an absolute grid of that many workgroups, for tests)
 };
+void msm_ws_release(MsmWorkspace& ws);
 // Fixed-base window table (msm_engine.hip: msm_table_kernel): W planes of `stride` points, plane w = 2^(c*w) * bases.
 struct MsmTable {
     int c = 0;            // 0 = no table (plane 0 only)

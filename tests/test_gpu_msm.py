@@ -157,3 +157,44 @@ def test_msm_skewed_scalars_and_forced_windows(gpu_workers, oracle):
             assert _affine_eq(w, oracle, 0, got, oracle.msm(0, bases, rnd, inf, threads=8)), c
     finally:
         w.set_option("msm_window", 0)
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_persistent_accumulation_matches_plain_grid_and_oracle(gpu_workers, oracle, curve, cid):
+    """`msm_acc_persist`: the bucket accumulation as a fixed grid of persistent waves that take 64 buckets at a time from a global counter
+    (the default at full size, where the plain grid would be 26 rounds of workgroups).  Forced here onto tiny grids (1, 3, 40 workgroups:
+    every wave loops many times, the last group is ragged) with duplicated bases (redo path), an infinity base, a heavy bucket
+    (one scalar everywhere) and a forced window, against the plain grid and the oracle."""
+    w = gpu_workers(curve)
+    n = 1 << 13
+    bases = oracle.gen_bases(cid, 31, 200, n)
+    b, inf = _bases_with_inf(oracle, cid, bases, [7])
+    w.init(b, 0, 0)
+    rnd = oracle.from_mont(cid, oracle.rand_fr(cid, 32, n))
+    same = np.repeat(rnd[:1], n, axis=0)
+    try:
+        for name, sc, window in (("uniform", rnd, 0), ("uniform-c11", rnd, 11), ("all-equal", same, 0)):
+            w.set_option("msm_window", window)
+            want = oracle.msm(cid, bases, sc, inf, threads=8)
+            w.set_option("msm_acc_persist", 0)
+            plain = w.var_msm(MsmWorkload(0, n), sc)
+            assert _affine_eq(w, oracle, cid, plain, want), (name, "plain")
+            for grid in (1, 3, 40):
+                w.set_option("msm_acc_persist", -grid)
+                got = w.var_msm(MsmWorkload(0, n), sc)
+                assert _affine_eq(w, oracle, cid, got, want), (name, grid)
+        # a batched round through the persistent path (K scalar vectors = K * W windows of one bucket problem)
+        w.set_option("msm_window", 0)
+        w.set_option("msm_acc_persist", -5)
+        vecs = [oracle.rand_fr(cid, 40 + k, n) for k in range(3)]
+        bufs = [w.alloc(n * 32) for _ in vecs]
+        for d, v in zip(bufs, vecs):
+            d.upload(v)
+        pts = w.commit_many_dev([(d.ptr, n) for d in bufs])
+        for v, p in zip(vecs, pts):
+            assert _affine_eq(w, oracle, cid, p, oracle.msm(cid, bases, oracle.from_mont(cid, v), inf, threads=8))
+        for d in bufs:
+            d.free()
+    finally:
+        w.set_option("msm_window", 0)
+        w.set_option("msm_acc_persist", 4)

@@ -12,6 +12,8 @@ w.synth_bases(0x5EED, 0, n, bases.ptr)
 t = time.perf_counter(); w.init_dev(bases.ptr, n, 0, 0); w.sync(); print("init ms", (time.perf_counter() - t) * 1e3)
 if os.environ.get("MSM_FUSED"):
     w.set_option("msm_fused_y3", int(os.environ["MSM_FUSED"]))
+if os.environ.get("MSM_PERSIST"):
+    w.set_option("msm_acc_persist", int(os.environ["MSM_PERSIST"]))
 if os.environ.get("MSM_WINDOW"):
     w.set_option("msm_window", int(os.environ["MSM_WINDOW"]))
 sc = w.alloc(n * 32)
