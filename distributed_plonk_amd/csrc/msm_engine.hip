@@ -19,8 +19,8 @@
 //                  (msm_reduce_level_kernel, fast path + redo), then per-level sums (msm_points_sum_kernel)
 //   6. fold        V_w = Sigma + sum_l 4^l A_l per window and the W window sums -> one point (W*c doublings), on the
 //                  host; the result is returned as a normalised Jacobian triple (x, y, 1) / (1, 1, 0).
-//   (opt.)         a fixed-base window table built at `init` merges all windows into one bucket set (msm_table_kernel);
-//                  measured slower on MI355X and off by default — see the comment there.
+//   (opt.)         a fixed-base window table built at `init` (planes 2^(c*G*t) * P_i) lets a scalar's W windows share G bucket sets
+//                  (msm_table_kernel); measured a wash on MI355X and off by default — see the comment there.
 //
 // Zero scalars and digit 0 never touch a bucket (the reference filters zeros too); scalar 1 needs no
 // special case (digit 1 in window 0).  Infinity bases are skipped, P+P and P+(-P) are handled in
@@ -346,24 +346,41 @@ __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(co
 // One lane owns one bucket, so a wave runs as long as its fullest bucket.  A counting sort of the bucket
 // ids by (clamped) size, largest first, puts equally loaded buckets in the same wave.
 #define SIZE_BINS 256
-// Merged mode (fixed-base window table, see msm_table_kernel): bucket b collects the segments (w, b) of all Wm windows.
-__device__ __forceinline__ uint32_t bucket_entries(const uint32_t* offsets, uint64_t b, uint64_t nb, uint32_t Wm) {
+// Bucket sets.  Plain: one set per window.  With the fixed-base window table (msm_table_kernel): G sets per scalar vector — set s = k*G + g of
+// vector k collects the windows w = g, g + G, g + 2G, ... < W1 of that vector; the entries of (window w, bucket b) are the sorted segment
+// ((k*W1 + w) << cb) + b and their bases come from plane t = w / G of the table (2^(c*G*t) * P_i).  Plain mode is G = W1 (one segment, plane 0).
+struct SetGeom {
+    uint32_t cb;          // log2 buckets per set
+    uint32_t G;           // sets per scalar vector
+    uint32_t W1;          // windows per scalar vector
+    uint32_t bin_shift;   // size-bin resolution (entries >> bin_shift)
+    uint64_t tab_stride;  // points between the planes of the table (0: plain)
+};
+// first segment of set-bucket sb; the following ones are seg_step(g) apart
+__device__ __forceinline__ uint64_t seg_first(const SetGeom& g, uint32_t sb, uint32_t* w0) {
+    const uint32_t s = sb >> g.cb, b = sb & ((1u << g.cb) - 1u);
+    const uint32_t k = s / g.G, gi = s - k * g.G;
+    *w0 = gi;
+    return (((uint64_t)k * g.W1 + gi) << g.cb) + b;
+}
+__device__ __forceinline__ uint64_t seg_step(const SetGeom& g) { return (uint64_t)g.G << g.cb; }
+__device__ __forceinline__ uint32_t bucket_entries(const uint32_t* offsets, uint32_t sb, const SetGeom& g) {
+    uint32_t w;
+    uint64_t seg = seg_first(g, sb, &w);
     uint32_t sz = 0;
-    for (uint32_t w = 0; w < Wm; w++) sz += offsets[w * nb + b + 1] - offsets[w * nb + b];
+    for (; w < g.W1; w += g.G, seg += seg_step(g)) sz += offsets[seg + 1] - offsets[seg];
     return sz;
 }
-__device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint64_t b, uint64_t nb, uint32_t Wm) {
-    // merged buckets hold ~Wm times more entries: bin by entries / 4 so the 256 bins still resolve them
-    const uint32_t sz = Wm > 1 ? bucket_entries(offsets, b, nb, Wm) >> 2 : offsets[b + 1] - offsets[b];
+__device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint32_t sb, const SetGeom& g) {
+    const uint32_t sz = bucket_entries(offsets, sb, g) >> g.bin_shift;   // merged buckets hold more entries: the host scales them into the 256 bins
     return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
 }
-__global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint64_t nb, uint32_t Wm,
-                                                               uint32_t* __restrict__ ghist) {
+__global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g, uint32_t* __restrict__ ghist) {
     __shared__ uint32_t h[SIZE_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbuckets) atomicAdd(&h[size_bin(offsets, b, nb, Wm)], 1u);
+    if (b < nbuckets) atomicAdd(&h[size_bin(offsets, (uint32_t)b, g)], 1u);
     __syncthreads();
     if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
@@ -380,7 +397,7 @@ __global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint3
     }
     bin_cursor[threadIdx.x] = buf[threadIdx.x] - v;
 }
-__global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, uint64_t nb, uint32_t Wm,
+__global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g,
                                                                 uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order) {
     __shared__ uint32_t h[SIZE_BINS];
     __shared__ uint32_t base[SIZE_BINS];
@@ -388,7 +405,7 @@ __global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* 
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bin = 0, rank = 0;
-    if (b < nbuckets) { bin = size_bin(offsets, b, nb, Wm); rank = atomicAdd(&h[bin], 1u); }
+    if (b < nbuckets) { bin = size_bin(offsets, (uint32_t)b, g); rank = atomicAdd(&h[bin], 1u); }
     __syncthreads();
     if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
@@ -523,7 +540,7 @@ __device__ __forceinline__ void store_std(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<
 template <int NQ, bool FUSED_Y3>
 __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                             const uint32_t* __restrict__ order, uint64_t nbuckets, uint64_t nb, uint32_t Wm, uint64_t tab_stride,
+                                                             const uint32_t* __restrict__ order, uint64_t nbuckets, SetGeom geom,
                                                              uint32_t heavy_thresh, XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
                                                              uint32_t* __restrict__ redo_list, uint32_t* __restrict__ heavy_count,
                                                              uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ work,
@@ -546,21 +563,27 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
         }
         if (i < nbuckets) {
             const uint32_t b = order[i];
-            if (bucket_entries(offsets, b, nb, Wm) > heavy_thresh) {   // skewed scalars / a nearly empty top window: one lane must not walk it alone
+            const uint32_t total = bucket_entries(offsets, b, geom);
+            if (total > heavy_thresh) {   // skewed scalars / a nearly empty top window: one lane must not walk it alone
                 heavy_list[atomicAdd(heavy_count, 1u)] = b;
             } else {
+                // ONE loop over the bucket's entries, across its segments (one per table plane; plain mode: a single segment).  A loop per segment
+                // would run every segment as long as the wave's LONGEST one: the lanes of a wave are matched by total size, not per segment —
+                // measured +38 % (2^24 points) to +80 % (2^22) on the merged accumulation, which rounds 1-2 mistook for a gather penalty.
+                uint32_t w;
+                uint64_t seg = seg_first(geom, b, &w);
+                const uint64_t step = seg_step(geom);
+                uint32_t j = offsets[seg], end = offsets[seg + 1];
+                const AffL<NL, B>* tb = bases;                               // plane t: 2^(c*G*t) * P_i
                 XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
                 bool ok = true;
-                for (uint32_t w = 0; w < Wm && ok; w++) {                    // Wm == 1 unless the fixed-base table is in use
-                    const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
-                    const AffL<NL, B>* tb = bases + w * tab_stride;          // 2^(c*w) * P_i
-                    for (uint32_t j = beg; j < end; j++) {
-                        const uint32_t e = sorted[j];
-                        AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
-                        if (affl_is_inf(q)) continue;
-                        if (e >> 31) q = affl_neg(q, P);
-                        if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
-                    }
+                for (uint32_t it = 0; it < total; it++) {
+                    while (j == end) { seg += step; tb += geom.tab_stride; j = offsets[seg]; end = offsets[seg + 1]; }   // `total` guarantees a next entry
+                    const uint32_t e = sorted[j++];
+                    AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                    if (affl_is_inf(q)) continue;
+                    if (e >> 31) q = affl_neg(q, P);
+                    if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
                 }
                 if (ok) store8(buckets + b, acc);
                 else redo_list[atomicAdd(redo_count, 1u)] = b;
@@ -575,7 +598,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
 template <int NQ>
 __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                         const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                        uint64_t nb, uint32_t Wm, uint64_t tab_stride,
+                                                        SetGeom geom,
                                                         const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
                                                         XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
                                                         const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
@@ -586,9 +609,11 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>:
     for (uint32_t h = blockIdx.x; h < total; h += gridDim.x) {
         const uint32_t b = heavy_list[h];
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-        for (uint32_t w = 0; w < Wm; w++) {
-            const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
-            const AffL<NL, B>* tb = bases + w * tab_stride;
+        uint32_t w;
+        uint64_t sg = seg_first(geom, b, &w);
+        const AffL<NL, B>* tb = bases;
+        for (; w < geom.W1; w += geom.G, sg += seg_step(geom), tb += geom.tab_stride) {
+            const uint32_t beg = offsets[sg], end = offsets[sg + 1];
             for (uint32_t j = beg + seg * blockDim.x + threadIdx.x; j < end; j += HEAVY_SEGS * blockDim.x) {
                 const uint32_t e = sorted[j];
                 AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
@@ -628,7 +653,7 @@ __global__ void __launch_bounds__(64) msm_heavy_finish_kernel(const uint32_t* __
 template <int NQ>
 __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
-                                                                 uint64_t nb, uint32_t Wm, uint64_t tab_stride,
+                                                                 SetGeom geom,
                                                                  XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
                                                                  const uint32_t* __restrict__ redo_list,
                                                                  const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
@@ -637,9 +662,11 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         const uint32_t b = redo_list[i];
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
-        for (uint32_t w = 0; w < Wm; w++) {
-            const uint32_t beg = offsets[w * nb + b], end = offsets[w * nb + b + 1];
-            const AffL<NL, B>* tb = bases + w * tab_stride;
+        uint32_t w;
+        uint64_t sg = seg_first(geom, b, &w);
+        const AffL<NL, B>* tb = bases;
+        for (; w < geom.W1; w += geom.G, sg += seg_step(geom), tb += geom.tab_stride) {
+            const uint32_t beg = offsets[sg], end = offsets[sg + 1];
             for (uint32_t j = beg; j < end; j++) {
                 const uint32_t e = sorted[j];
                 AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
@@ -721,7 +748,6 @@ struct SumJobs {
     uint64_t count[16];
     uint64_t wstride[16];      // points between the inputs of consecutive windows (0: = count, the dense layout of the pyramid arrays)
 };
-#define SUM_SPLIT_MAX 16  // workgroups per (level, window) sum in merged (table) mode: 2^17 level-0 values and only one window; 1 otherwise
 // RAW: the block's sum stays in the limb form (input of a second, combining launch) instead of being converted to the standard form.
 // Large pyramids (c = 20: 2^17 level-0 values per window) are summed by `nsplit` workgroups per (level, window) and a second launch
 // folds the nsplit partials — one workgroup per (level, window) used to walk 512 points per lane: 6.6 of the 9 ms a c = 20 reduction took.
@@ -799,29 +825,30 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 }
 
 // ---------------------------------------------------------------------------------------------- fixed-base window table
-// The SRS is fixed between `init` calls (worker.rs:141), so the shifted copies T[w][i] = 2^(c*w) * P_i can be built once
-// and kept resident (W x 72 B per point: 15.7 GB for 2^24 BN254 points at c = 20 — 288 GB of HBM make this cheap).
-// With them every (point, window) digit lands in ONE bucket set of 2^(c-1) buckets instead of one set per window: the
-// window reduction shrinks W-fold, which moves the optimum to a wider window (c = 20, W = 13 instead of c = 17, W = 15
-// at 2^24).  Lane i walks its point through the W-1 shifts: c doublings (lazy XYZZ), one Fermat inversion, back to the
-// canonical affine limb form the accumulate kernel reads.
-// MEASURED (MI355X, 2^24 BN254, profiles/r01_msm_table_experiment.txt): OFF by default.  The mixed additions drop as
-// predicted, but gathering 72-byte points from a 15.7 GB table instead of the 1.2 GB one costs more than it saves
-// (accumulate 23.8 ms merged vs 17.8 ms for the same window over plane 0 only: the per-window bucket sets of the plain
-// path keep the gathers of the waves in flight inside one 1.2 GB plane, which the translation/cache hierarchy covers).
-// Kept as an option (`msm_precompute`), exercised by tests/test_gpu_msm_table.py.
+// The SRS is fixed between `init` calls (worker.rs:141), so shifted copies of it can be built once and kept resident: plane t holds
+// 2^(c*G*t) * P_i (T planes x 72 B per point; 288 GB of HBM make this cheap).  Window w = g + t*G of a scalar then reads its bases from
+// plane t and adds into the bucket set of window g: a scalar vector needs G bucket sets instead of W — the reduction pyramid, the
+// bucket ordering and the host fold shrink W/G-fold (G = 1: one set for all windows), and with fewer, fuller buckets a wider window pays.
+// Lane i walks its point through the T-1 shifts: c*G doublings (lazy XYZZ), one Fermat inversion, back to the canonical affine limb form
+// the accumulate kernel reads.
+// HISTORY: rounds 1-2 measured the merged accumulation 34 % slower per addition (23.8 vs 17.8 ms) and blamed the gathers from a 15.7 GB
+// table.  Round 3 found the cause elsewhere (profiles/r03_msm_table_experiment.txt): the kernel ran one loop PER SEGMENT, and a wave's lanes
+// are matched by their buckets' TOTAL size, so every segment ran as long as the wave's longest — +80 % at 2^22 points (3.9 GB table), +38 % at 2^24.
+// The accumulate kernel now runs one loop over all entries of a bucket, and bases gathered from 4.8 GB (2^26 points) cost what 1.2 GB costs.
+// What is left (+8 % per addition at 4 planes, +15 % at 13: the segment boundaries inside the loop) cancels what the smaller pyramid saves: OFF by
+// default (`msm_precompute` = 0), kept as an option with its tests (tests/test_gpu_msm_table.py).
 template <int NQ>
-__global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ table, uint64_t n, uint64_t stride, int c, int W,
+__global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ table, uint64_t n, uint64_t stride, int shift, int T,
                                                        const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
                                                        const FL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> pm2 /* p - 2, limb form */) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     AffL<NL, B> q = load8(table + i);
-    for (int w = 1; w < W; w++) {
+    for (int w = 1; w < T; w++) {
         if (!affl_is_inf(q)) {
             XyzzL<NL, B> a = xyzzl_dbl_affine(q, P);
-            for (int k = 1; k < c; k++) a = xyzzl_dbl(a, P);
+            for (int k = 1; k < shift; k++) a = xyzzl_dbl(a, P);
             // 1 / ZZZ by Fermat; 1/Z = ZZ / ZZZ; x = X / Z^2, y = Y / ZZZ   (an infinity gives 0 -> (0, 0) = infinity)
             FL<NL, B> inv = fl_load_const<NL, B>(P.one);
             for (int bit = NL * B - 1; bit >= 0; bit--) {
@@ -846,6 +873,7 @@ static bool sort_geometry(int cb, size_t n, int* lp_out) {
     return true;
 }
 
+#define MSM_TABLE_MAX_C 21                           // widest window the table plan considers (the level-2 sort is staged in LDS up to 2^10 buckets per partition ...)
 static double g_reduce_cost = 2.7 * 3300.0;           // VALU instructions per bucket in the reduction pyramid (round 3: the x2 for its low occupancy went
                                                       // with the split per-level sums and the LDS-staged level-2 sort: c = 20 now wins at 2^24 points)
 // measured issue cost (profiles/r01_pmc_sq_2p24.json): ~2480 VALU instructions per mixed addition, ~3300 per full
@@ -857,65 +885,80 @@ static bool window_usable(size_t n, int bits, int c) {
     const int top_bits = bits - (W - 1) * c;                   // entropy of the last window's digit
     return !(W > 1 && top_bits < std::min(c - 3, 8));          // a near-empty top window puts every point in a few buckets
 }
-static double window_cost(size_t n, int bits, int c, bool table) {
+// G = bucket sets per scalar vector (plain: G = W)
+static double window_cost(size_t n, int bits, int c, int G) {
     const int W = (bits + 1 + c - 1) / c;
-    const double sets = table ? 1.0 : (double)W;
+    const double sets = (double)std::min(std::max(G, 1), W);
     // one lane per bucket: below 4 waves per SIMD (262144 lanes) the additions are latency-bound and the SIMDs idle in
     // proportion (measured: 2^16 points at c = 8 -> 4096 lanes, 10 ms; the same points at c = 15 -> 0.3 ms)
     const double lanes = sets * (double)((size_t)1 << (c - 1));
     const double par = std::min(1.0, lanes / 262144.0);
     return (double)W * (double)n * 2480.0 / par + sets * (double)((size_t)1 << (c - 1)) * g_reduce_cost;
 }
-static int choose_window(size_t n, int bits, bool table = false, double* cost_out = nullptr) {
+static int choose_window(size_t n, int bits, double* cost_out = nullptr) {
     double best = 1e300;
     int bc = 4;
-    for (int c = 4; c <= (table ? 21 : 20); c++) {
+    for (int c = 4; c <= 20; c++) {
         if (!window_usable(n, bits, c)) continue;
-        const double cost = window_cost(n, bits, c, table);
+        const double cost = window_cost(n, bits, c, (bits + 1 + c - 1) / c);
         if (cost < best) { best = cost; bc = c; }
     }
     if (cost_out) *cost_out = best;
     return bc;
 }
 
-// Window width of the fixed-base table for an SRS of n points, 0 = no table (too small to pay off, or over budget)
-int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out) {
-    *W_out = 1;
+// Plan of the fixed-base table for an SRS of n points: window width c (0 = no table: too small to pay off, or over budget), W windows per scalar,
+// G bucket sets per scalar, T = ceil(W / G) planes.  mode 1: only when the cost model sees a gain; mode 2: always (tests).  The widest table the
+// budget allows wins ties; force_c / force_sets (options "msm_table_c" / "msm_table_sets") pin a shape (tests, experiments).
+int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int force_c, int force_sets, int* W_out, int* G_out, int* T_out) {
+    *W_out = 1; *G_out = 1; *T_out = 1;
     if (mode == 0 || n == 0) return 0;
     const int bits = fr_params(curve).bits;
-    double plain = 0, tab = 0;
-    choose_window(n, bits, false, &plain);
-    int c = choose_window(n, bits, true, &tab);
-    if (const char* ov = getenv("PLONK_MSM_TAB_C")) {          // tuning override (experiments)
-        const int oc = atoi(ov);
-        if (oc <= 0) return 0;
-        if (window_usable(n, bits, oc)) { c = oc; tab = 0; }
+    const double pb = (double)msm_limb_base_bytes(curve);
+    double plain = 0;
+    choose_window(n, bits, &plain);
+    const int fc = force_c > 0 ? force_c : (getenv("PLONK_MSM_TAB_C") ? atoi(getenv("PLONK_MSM_TAB_C")) : 0);       // "msm_table_c" / "msm_table_sets" options;
+    const int fg = force_sets > 0 ? force_sets : (getenv("PLONK_MSM_TAB_G") ? atoi(getenv("PLONK_MSM_TAB_G")) : 0);   // the variables serve tools that cannot reach the context
+    double best = 1e300;
+    int bc = 0, bG = 1;
+    for (int c = 4; c <= MSM_TABLE_MAX_C; c++) {
+        if (fc > 0 && c != fc) continue;
+        if (!window_usable(n, bits, c)) continue;
+        const int W = (bits + 1 + c - 1) / c;
+        if (W < 2) continue;
+        for (int G = 1; G < W; G++) {                            // G = W would be the plain plan
+            if (fg > 0 && G != fg) continue;
+            const int T = (W + G - 1) / G;
+            if (fg <= 0 && G != (W + T - 1) / T) continue;       // skip shapes that a table of the same size serves with fewer sets
+            if ((double)T * (double)n * pb > (double)budget_bytes) continue;
+            const double cost = window_cost(n, bits, c, G) * (1.0 + 1e-4 * T);      // ties: the smaller table
+            if (cost < best) { best = cost; bc = c; bG = G; }
+        }
     }
-    const int W = (bits + 1 + c - 1) / c;
-    if (W < 2) return 0;
-    if (mode == 1 && (n < ((size_t)1 << 16) || tab > 0.93 * plain)) return 0;
-    if ((double)W * (double)n * (double)msm_limb_base_bytes(curve) > (double)budget_bytes) return 0;
-    *W_out = W;
-    return c;
+    if (!bc) return 0;
+    if (mode == 1 && (n < ((size_t)1 << 16) || best > 0.97 * plain)) return 0;
+    const int W = (bits + 1 + bc - 1) / bc;
+    *W_out = W; *G_out = bG; *T_out = (W + bG - 1) / bG;
+    return bc;
 }
 
-template <int NQ> static int msm_table_build_t(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream) {
+template <int NQ> static int msm_table_build_t(int curve, void* d_table, size_t n, size_t stride, int shift, int T, hipStream_t stream) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     Fp<NQ> pm2;
     uint64_t br = 2;
     for (int i = 0; i < NQ; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
-    hipLaunchKernelGGL(msm_table_kernel<NQ>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, stream, (AffL<NL, B>*)d_table, (uint64_t)n, (uint64_t)stride, c, W,
+    hipLaunchKernelGGL(msm_table_kernel<NQ>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, stream, (AffL<NL, B>*)d_table, (uint64_t)n, (uint64_t)stride, shift, T,
                        fl_params<NQ>(curve), fl_from_sat<NL, B, NQ>(pm2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm_table launch: %s", hipGetErrorString(e));
     return PLONK_OK;
 }
-// d_table: W planes of `stride` points, plane 0 already holds the bases (bases_to_limbs)
-int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream) {
-    if (n == 0 || W < 2) return PLONK_OK;
-    if (curve == PLONK_BN254) return msm_table_build_t<8>(curve, d_table, n, stride, c, W, stream);
-    return msm_table_build_t<12>(curve, d_table, n, stride, c, W, stream);
+// d_table: T planes of `stride` points, plane 0 already holds the bases (bases_to_limbs); plane t = 2^(shift * t) * plane 0, shift = c * G
+int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int shift, int T, hipStream_t stream) {
+    if (n == 0 || T < 2) return PLONK_OK;
+    if (curve == PLONK_BN254) return msm_table_build_t<8>(curve, d_table, n, stride, shift, T, stream);
+    return msm_table_build_t<12>(curve, d_table, n, stride, shift, T, stream);
 }
 
 void msm_ws_release(MsmWorkspace& ws) {
@@ -935,6 +978,19 @@ static int ensure_ws(MsmWorkspace& ws, size_t bytes) {
 static size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 
+// Window width and bucket sets per scalar vector for an MSM over n points: the table's shape when one is resident and beats the best plain plan
+// for THIS n (small sub-ranges and forced windows do not use it), else the plain plan (G = W1).
+static int plan_window(size_t n, int bits, int window_bits, const MsmTable& tab, int* G_out) {
+    if (window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
+        double plain = 0;
+        choose_window(n, bits, &plain);
+        if (window_cost(n, bits, tab.c, tab.G) < plain) { *G_out = tab.G; return tab.c; }
+    }
+    const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits);
+    *G_out = (bits + 1 + c - 1) / c;
+    return c;
+}
+
 // K >= 1 scalar vectors against the SAME bases in one set of launches (the independent commitments of a prover round): vector k
 // supplies the windows k*W1 .. (k+1)*W1 - 1 of one big (window, bucket) problem, so the sort, the bucket accumulation and the
 // reduction pyramid each run once over K times the work — no per-MSM launch gaps, wave tails or host round trips, which is what
@@ -944,26 +1000,24 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
                      size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
-    // fixed-base table: use it when its window beats the best per-window plan for THIS n (small sub-ranges do not)
-    bool merged = false;
-    if (K == 1 && window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
-        double plain = 0;
-        choose_window(n, bits, false, &plain);
-        merged = window_cost(n, bits, tab.c, true) < plain;
-    }
-    const int c = merged ? tab.c : (window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits));
+    int G = 1;
+    const int c = plan_window(n, bits, window_bits, tab, &G);
     const int W1 = (bits + 1 + c - 1) / c;             // windows per scalar vector (signed digits: one spare bit for the last carry)
-    if (merged && W1 != tab.W) return plonk_fail(PLONK_ERR_STATE, "msm: table built for %d windows, plan has %d", tab.W, W1);
+    const bool merged = G < W1;                        // fixed-base table in use: G bucket sets per vector, window g + t*G reads plane t
+    if (merged && (W1 != tab.W || G != tab.G)) return plonk_fail(PLONK_ERR_STATE, "msm: table built for %d windows in %d sets, plan has %d in %d", tab.W, tab.G, W1, G);
     const int W = K * W1;                              // windows of the whole batch
     const int cb = c - 1;                              // 2^(c-1) buckets per window
     const uint64_t nb = (uint64_t)1 << cb;
-    const uint32_t Wm = merged ? (uint32_t)W : 1u;     // windows merged into one bucket set
-    const int Wr = merged ? 1 : W;                     // bucket sets left to reduce
+    const int Wr = K * G;                              // bucket sets to accumulate and reduce
     const uint64_t nsub = (uint64_t)W * nb;            // (window, bucket) segments the sort produces
     const uint64_t nbuckets = (uint64_t)Wr * nb;       // accumulators
-    const uint64_t tab_stride = merged ? tab.stride : 0;
+    if (nbuckets >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm: %llu buckets", (unsigned long long)nbuckets);
     const uint64_t avg = ((uint64_t)n * W) / nbuckets + 1;
     const uint32_t heavy_thresh = (uint32_t)std::max<uint64_t>(HEAVY_BUCKET, 4 * avg);
+    SetGeom sg;
+    sg.cb = (uint32_t)cb; sg.G = (uint32_t)G; sg.W1 = (uint32_t)W1; sg.tab_stride = merged ? tab.stride : 0;
+    sg.bin_shift = 0;
+    while ((avg >> sg.bin_shift) > 96) sg.bin_shift++;        // keep the average bucket inside the 256 size bins
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
     SortGeom g;
     g.n = n; g.W = W; g.cb = cb;
@@ -1008,9 +1062,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_buckets = off; off = align_up(off + nbuckets * sizeof(BucketL), 256);
     const size_t o_acc = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
-    const uint32_t nsplit = merged ? SUM_SPLIT_MAX : 1;
+    const uint32_t nsplit = 1;
     // plain mode: the per-(level, window) sums of large pyramids are split over `gsplit` workgroups and folded by a second launch
-    const uint32_t gsplit = merged ? 1 : (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (nlev ? lev_nch[0] : 1) / 8192));
+    const uint32_t gsplit = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (nlev ? lev_nch[0] : 1) / 8192));
     const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * nsplit * sizeof(XyzzPt<NQ>), 256);
     const size_t o_wpart = off; off = align_up(off + (gsplit > 1 ? (size_t)Wr * (nlev + 1) * gsplit * sizeof(BucketL) : 0), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
@@ -1071,9 +1125,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
     HIP_TRY(hipMemsetAsync(heavy, 0, 4, stream));
     const uint32_t bgrid = (uint32_t)((nbuckets + 255) / 256);
-    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, ghist);
+    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, ghist);
     hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
-    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, nb, Wm, bin_cursor, order); }
+    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, bin_cursor, order); }
     // "msm_acc_persist" (default 4): the accumulation as that many workgroups per CU of persistent waves; 0 = one lane per bucket over the whole grid
     uint32_t* work = nullptr;
     uint32_t acc_grid = (uint32_t)((nbuckets + 255) / 256);
@@ -1096,16 +1150,16 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     { ProfScope ps("msm_accumulate_kernel", stream);
     if (ws.fused_y3)
         hipLaunchKernelGGL((msm_accumulate_kernel<NQ, true>), dim3(acc_grid), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve));
+                           nbuckets, sg, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve));
     else
         hipLaunchKernelGGL((msm_accumulate_kernel<NQ, false>), dim3(acc_grid), dim3(256), 0, stream, d_bases, sorted, offsets, order,
-                           nbuckets, nb, Wm, tab_stride, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve)); }
+                           nbuckets, sg, heavy_thresh, buckets, redo, redo + 1, heavy, heavy + 1, work, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_heavy", stream);
-    hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, nb, Wm, tab_stride,
+    hipLaunchKernelGGL(msm_heavy_kernel<NQ>, dim3(128, HEAVY_SEGS), dim3(256), 256 * sizeof(BucketL), stream, d_bases, sorted, offsets, sg,
                        heavy, heavy + 1, hpart, fl_params<NQ>(curve));
     hipLaunchKernelGGL(msm_heavy_finish_kernel<NQ>, dim3(16), dim3(64), 0, stream, heavy, heavy + 1, hpart, buckets, fl_params<NQ>(curve)); }
     { ProfScope ps("msm_accumulate_redo_kernel", stream);
-    hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, nb, Wm, tab_stride, buckets, redo,
+    hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, sg, buckets, redo,
                        redo + 1, fl_params<NQ>(curve)); }
     {
         ProfScope ps("msm_reduce", stream);
@@ -1150,7 +1204,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * nsplit);
     HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
-    const int Wk = merged ? 1 : W1;                    // bucket sets per scalar vector
+    const int Wk = G;                                  // bucket sets per scalar vector: total = sum_g 2^(c*g) * V_(k, g)
     for (int kk = 0; kk < K; kk++) {
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     for (int w = (kk + 1) * Wk - 1; w >= kk * Wk; w--) {
@@ -1191,7 +1245,8 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* const* d_sc
         const size_t m = std::min(SLICE, n - s);
         // windows per vector for this slice size -> how many vectors fit one launch set
         const int bits = fr_params(curve).bits;
-        const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(m, bits);
+        int G_ = 1;
+        const int c = plan_window(m, bits, window_bits, tab, &G_);
         const int W1 = (bits + 1 + c - 1) / c;
         const uint64_t per = (uint64_t)m * W1;
         int group = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)K, (0xfffffff0ull / per)));

@@ -64,8 +64,9 @@ struct plonk_ctx {
     void* d_bases = nullptr;                    // plane 0 of the fixed-base window table (msm_table) when one is built
     size_t n_bases = 0;
     MsmTable msm_table;
-    int msm_precompute = 0;                     // 0 off (default: measured slower on MI355X), 1 when the cost model likes it, 2 always
+    int msm_precompute = 0;                     // 0 off (default: measured a wash on MI355X, DESIGN.md §4.2, profiles/r03_msm_table_experiment.txt), 1 when the cost model likes it, 2 always
     size_t msm_table_budget = (size_t)64 << 30;
+    int msm_table_c = 0, msm_table_sets = 0;    // > 0: pin the table's window width / bucket sets per scalar (tests, experiments); 0: the cost model
     // domains (State.domain / quot_domain and their r/c splits are derived on demand)
     size_t domain_size = 0, quot_domain_size = 0;
     std::map<uint64_t, FftTask> tasks;          // State.fft_tasks
@@ -197,6 +198,8 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
+    if (!strcmp(key, "msm_table_c")) { ctx->msm_table_c = (int)value; return PLONK_OK; }              // takes effect at the next init
+    if (!strcmp(key, "msm_table_sets")) { ctx->msm_table_sets = (int)value; return PLONK_OK; }        // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     // every knob lives in the context it was set on (another context, possibly driven from another host thread, is not affected)
     if (!strcmp(key, "ntt_max_log_r")) { ctx->tables.max_log_r = (int)value; return PLONK_OK; }
@@ -243,19 +246,19 @@ static int set_domains(plonk_ctx* ctx, size_t domain_size, size_t quot_domain_si
 
 // SRS -> resident limb form, plus the fixed-base window table when it pays off (one-time work per `init`)
 static int install_bases(plonk_ctx* ctx, const void* d_xy, size_t n_bases) {
-    int W = 1;
-    const int c = msm_table_plan(ctx->curve, n_bases, ctx->msm_precompute, ctx->msm_table_budget, &W);
+    int W = 1, G = 1, T = 1;
+    const int c = msm_table_plan(ctx->curve, n_bases, ctx->msm_precompute, ctx->msm_table_budget, ctx->msm_table_c, ctx->msm_table_sets, &W, &G, &T);
     const size_t pb = msm_limb_base_bytes(ctx->curve);
-    if (hipMalloc(&ctx->d_bases, n_bases * pb * (size_t)W) != hipSuccess) {
+    if (hipMalloc(&ctx->d_bases, n_bases * pb * (size_t)T) != hipSuccess) {
         (void)hipGetLastError();
-        W = 1;                                  // no room for the table: plain bases
+        T = 1;                                  // no room for the table: plain bases
         HIP_TRY(hipMalloc(&ctx->d_bases, n_bases * pb));
     }
     int rc = bases_to_limbs(ctx->curve, d_xy, n_bases, ctx->d_bases, ctx->stream);
     ctx->msm_table = MsmTable();
-    if (!rc && W > 1) {
-        rc = msm_table_build(ctx->curve, ctx->d_bases, n_bases, n_bases, c, W, ctx->stream);
-        ctx->msm_table.c = c; ctx->msm_table.W = W; ctx->msm_table.stride = n_bases;
+    if (!rc && T > 1) {
+        rc = msm_table_build(ctx->curve, ctx->d_bases, n_bases, n_bases, c * G, T, ctx->stream);
+        ctx->msm_table.c = c; ctx->msm_table.W = W; ctx->msm_table.G = G; ctx->msm_table.T = T; ctx->msm_table.stride = n_bases;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!rc) ctx->n_bases = n_bases;

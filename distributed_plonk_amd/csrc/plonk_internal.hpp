@@ -155,10 +155,13 @@ struct MsmWorkspace {
     int acc_persist = 4;      // "msm_acc_persist": workgroups per CU of the persistent bucket accumulation (0 = one lane per bucket over the whole grid; < 0: an absolute grid of that many workgroups, for tests)
 };
 void msm_ws_release(MsmWorkspace& ws);
-// Fixed-base window table (msm_engine.hip: msm_table_kernel): W planes of `stride` points, plane w = 2^(c*w) * bases.
+// Fixed-base window table (msm_engine.hip: msm_table_kernel): T planes of `stride` points, plane t = 2^(c*G*t) * bases; a scalar vector's W windows
+// accumulate into G bucket sets (window g + t*G reads plane t).
 struct MsmTable {
     int c = 0;            // 0 = no table (plane 0 only)
-    int W = 1;
+    int W = 1;            // windows per scalar at this width
+    int G = 1;            // bucket sets per scalar
+    int T = 1;            // planes = ceil(W / G)
     uint64_t stride = 0;  // points per plane (= n_bases)
 };
 // bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point); with a table,
@@ -170,8 +173,8 @@ int msm_run(int curve, const void* d_bases, const uint32_t* d_scalars, bool scal
 // K scalar vectors (lens[k] valid entries, zero beyond) against the same bases[0 .. n): h_out_jac receives K Jacobian triples.
 int msm_run_many(int curve, const void* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont, size_t n,
                  uint32_t* h_out_jac, MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream);
-int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int* W_out);
-int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int c, int W, hipStream_t stream);
+int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int force_c, int force_sets, int* W_out, int* G_out, int* T_out);
+int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int shift, int T, hipStream_t stream);
 int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);
 int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf);
 int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream);

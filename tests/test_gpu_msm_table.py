@@ -29,6 +29,8 @@ def forced_table(gpu_workers):
     yield get
     for w in used:
         w.set_option("msm_precompute", 0)
+        w.set_option("msm_table_c", 0)
+        w.set_option("msm_table_sets", 0)
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
@@ -95,3 +97,38 @@ def test_table_on_off_agree_and_forced_window_bypasses_it(forced_table, oracle):
     assert _affine_eq(w, oracle, 0, w.var_msm(MsmWorkload(0, n), sc), want)
     for got in (a, b, c):
         assert _affine_eq(w, oracle, 0, got, want)
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("c,sets", [(8, 1), (8, 3), (8, 5), (8, 16), (11, 2), (11, 7), (13, 4)])
+def test_table_with_several_bucket_sets(forced_table, oracle, curve, cid, c, sets):
+    """Partial tables: T = ceil(W / G) planes 2^(c*G*t) * P_i, G bucket sets per scalar (window g + t*G -> set g, plane t) — the shape the
+    plan picks when the full table does not fit its budget.  Every (c, G) pinned through the options, single MSMs, sub-ranges and a
+    batched round (K vectors -> K*G sets), duplicated bases and an infinity base, against the oracle."""
+    w = forced_table(curve)
+    w.set_option("msm_table_c", c)
+    w.set_option("msm_table_sets", sets)
+    n = 3000
+    bases = oracle.gen_bases(cid, 77, 120, n)
+    inf = np.zeros(n, dtype=np.uint8)
+    bases[11] = 0
+    inf[11] = 1
+    w.init(bases, 0, 0)
+    sc = oracle.from_mont(cid, oracle.rand_fr(cid, 78, n))
+    sc[5] = 0
+    assert _affine_eq(w, oracle, cid, w.var_msm(MsmWorkload(0, n), sc), oracle.msm(cid, bases, sc, inf, threads=8))
+    lo, hi = 700, 2900
+    assert _affine_eq(w, oracle, cid, w.var_msm(MsmWorkload(lo, hi), sc[lo:hi]), oracle.msm(cid, bases[lo:hi], sc[lo:hi], inf[lo:hi], threads=8))
+    vecs = [oracle.rand_fr(cid, 80 + k, ln) for k, ln in enumerate((n, n - 700, 0, 17))]
+    bufs = [w.alloc(max(len(v), 1) * 32) for v in vecs]
+    for d, v in zip(bufs, vecs):
+        if len(v):
+            d.upload(v)
+    pts = w.commit_many_dev([(d.ptr, len(v)) for d, v in zip(bufs, vecs)])
+    for v, p in zip(vecs, pts):
+        if len(v):
+            assert _affine_eq(w, oracle, cid, p, oracle.commit_polynomial(cid, bases, v, inf=inf, threads=8))
+        else:
+            assert w.g1_to_affine(p)[1]                          # the empty polynomial commits to zero
+    for d in bufs:
+        d.free()

@@ -8,7 +8,11 @@ n = 1 << log_n
 w = PlonkWorker(curve=os.environ.get("CURVE", "bn254"))
 q = w.q64
 bases = w.alloc(n * 16 * q)
-w.synth_bases(0x5EED, 0, n, bases.ptr)
+w.synth_bases(0x5EED, int(os.environ.get("MSM_TILE", "0")), n, bases.ptr)       # MSM_TILE=2048: 2^11 points tiled (gathers from L2)
+if os.environ.get("MSM_PRECOMPUTE"):
+    w.set_option("msm_precompute", int(os.environ["MSM_PRECOMPUTE"]))       # fixed-base window table (takes effect at init)
+    w.set_option("msm_table_c", int(os.environ.get("MSM_TAB_C", "0")))
+    w.set_option("msm_table_sets", int(os.environ.get("MSM_TAB_G", "0")))
 t = time.perf_counter(); w.init_dev(bases.ptr, n, 0, 0); w.sync(); print("init ms", (time.perf_counter() - t) * 1e3)
 if os.environ.get("MSM_FUSED"):
     w.set_option("msm_fused_y3", int(os.environ["MSM_FUSED"]))
