@@ -984,7 +984,7 @@ static int plan_window(size_t n, int bits, int window_bits, const MsmTable& tab,
     if (window_bits <= 0 && tab.c > 0 && window_usable(n, bits, tab.c)) {
         double plain = 0;
         choose_window(n, bits, &plain);
-        if (window_cost(n, bits, tab.c, tab.G) < plain) { *G_out = tab.G; return tab.c; }
+        if (tab.force || window_cost(n, bits, tab.c, tab.G) < plain) { *G_out = tab.G; return tab.c; }
     }
     const int c = window_bits > 0 ? std::min(std::max(window_bits, 2), 20) : choose_window(n, bits);
     *G_out = (bits + 1 + c - 1) / c;

@@ -259,6 +259,7 @@ static int install_bases(plonk_ctx* ctx, const void* d_xy, size_t n_bases) {
     if (!rc && T > 1) {
         rc = msm_table_build(ctx->curve, ctx->d_bases, n_bases, n_bases, c * G, T, ctx->stream);
         ctx->msm_table.c = c; ctx->msm_table.W = W; ctx->msm_table.G = G; ctx->msm_table.T = T; ctx->msm_table.stride = n_bases;
+        ctx->msm_table.force = ctx->msm_precompute == 2;
     }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     if (!rc) ctx->n_bases = n_bases;

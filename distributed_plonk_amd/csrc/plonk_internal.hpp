@@ -163,6 +163,7 @@ struct MsmTable {
     int G = 1;            // bucket sets per scalar
     int T = 1;            // planes = ceil(W / G)
     uint64_t stride = 0;  // points per plane (= n_bases)
+    bool force = false;   // msm_precompute = 2: use the table for every MSM it can serve, whatever the cost model says (tests, experiments)
 };
 // bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point); with a table,
 // the pointer addresses plane 0 (+ the range start) and the other planes follow at multiples of tab.stride.
