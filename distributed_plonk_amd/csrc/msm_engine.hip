@@ -129,6 +129,7 @@ struct SortGeom {
     uint32_t nreal;              // W << lp : real partitions; the W "digit == 0" partitions follow them
     uint32_t idx_bits;           // > 0: level-1 entries carry the FULL point index in idx_bits bits (low_bits + 1 + idx_bits <= 32), so the
                                  // level-2 workgroup needs no search for the slice; 0: index within the slice only (wide windows / huge n)
+    uint32_t stage_cap;          // entries the staged level-2 kernel orders in LDS at a time (what its LDS budget leaves beside the counters and slice starts)
 };
 
 __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blk_hist) {
@@ -279,25 +280,27 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
 
 // Level 2 for WIDE windows (2^low_bits >= 256 buckets per partition, i.e. c >= 19 at 2^24 points): the direct scatter above keeps
 // 512 one-cache-line runs open per workgroup for the workgroup's whole life, and with ~2000 workgroups in flight those partial lines
-// fall out of L2 before they are full (6.2 ms at c = 20 against 1.5 ms at c = 17 for the same bytes).  Here the partition (<= STAGE_CAP
-// entries; larger ones — skewed scalars — take the direct path) is ordered in LDS and leaves in consecutive addresses: counts ->
-// exclusive scan -> ranks into the LDS buffer -> coalesced copy-out.  1024 lanes on ~78 KiB of LDS: two workgroups = eight waves per
-// SIMD, like the level-1 scatter.  tmp is read twice; its 64 KiB per partition are L2 / Infinity-Cache resident.
-#define STAGE_CAP 18432u
+// fall out of L2 before they are full (6.2 ms at c = 20 against 1.5 ms at c = 17 for the same bytes).  Here the partition is ordered in
+// LDS and leaves in consecutive addresses: counts -> exclusive scan -> ranks into the LDS buffer -> coalesced copy-out.  1024 lanes on
+// ~78 KiB of LDS: two workgroups = eight waves per SIMD, like the level-1 scatter.  A partition larger than the buffer (g.stage_cap
+// entries: above 2^24 points a partition holds 2^15 and more, and skewed scalars can fill one at any size) is ordered in several CHUNKS
+// of consecutive buckets: every chunk streams the partition again (its 128 - 256 KiB are L2 / Infinity-Cache resident) and stages only
+// the entries of its own buckets; a single chunk that still does not fit (one huge bucket) takes the direct path.  Late round 3: before,
+// such partitions — all of them at 2^25 and 2^26 points — fell back to the direct kernel: sort 17.3 / 35.6 ms beside 30.6 / 59.9 ms of accumulation.
 #define STAGE_THREADS 1024
+#define STAGE_MAX_CHUNKS 8u
 __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                                               uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
     extern __shared__ uint32_t lds[];
     const uint32_t nlow = 1u << g.low_bits;
     uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors (relative to the partition start)
     uint32_t* run0 = lds + nlow;               // [nblk] start of every slice's run inside this partition (idx_bits == 0 only)
-    uint32_t* buf = run0 + (g.idx_bits ? 0 : g.nblk);      // [STAGE_CAP] final entries in bucket order
-    uint32_t* strip = buf;                     // [STAGE_THREADS] scratch of the scan, dead before buf is filled
+    uint32_t* buf = run0 + (g.idx_bits ? 0 : g.nblk);      // [stage_cap] final entries in bucket order
+    uint32_t* strip = buf;                     // [STAGE_THREADS] scratch of the scan, dead before buf is filled (stage_cap >= STAGE_THREADS)
     const uint64_t pid = blockIdx.x;
     const uint32_t* po = blk_off + pid * g.nblk;
     const uint32_t pbeg = po[0], pend = po[g.nblk], len = pend - pbeg;
     const int sh = g.idx_bits ? (int)g.idx_bits + 1 : SORT_SLICE_LOG + 1;
-    const bool staged = len <= STAGE_CAP;
     for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) cnt[k] = 0;
     if (!g.idx_bits)
         for (uint32_t k = threadIdx.x; k < g.nblk; k += blockDim.x) run0[k] = po[k];
@@ -324,22 +327,38 @@ __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(co
     __syncthreads();
     const uint32_t in_mask = SORT_SLICE - 1;
     const uint32_t imask = g.idx_bits ? (1u << g.idx_bits) - 1 : 0;
-    for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
-        const uint32_t e = tmp[j];
-        uint32_t val;
-        if (g.idx_bits) {
-            val = (e & imask) | (((e >> g.idx_bits) & 1u) << 31);
-        } else {
-            uint32_t lo = 0, hi = g.nblk;      // slice = largest b with run0[b] <= j
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run0[mid] <= j) lo = mid; else hi = mid; }
-            val = ((lo << SORT_SLICE_LOG) + (e & in_mask)) | (((e >> SORT_SLICE_LOG) & 1u) << 31);
+    // chunks of consecutive buckets: one when the partition fits the buffer, else sized for 3/4 of it (bucket sizes fluctuate)
+    const uint32_t cap = g.stage_cap;
+    // (a partition far beyond that — the 2^14-bucket top window of a c = 20 decomposition puts 2^19 entries in each of its partitions — would stream
+    //  itself dozens of times from one workgroup: it takes the direct path in one pass, as before)
+    uint32_t nch = len <= cap ? 1u : min(nlow, (len + (cap - cap / 4) - 1) / (cap - cap / 4));
+    const bool direct = nch > STAGE_MAX_CHUNKS;
+    if (direct) nch = 1;
+    const uint32_t bper = (nlow + nch - 1) / nch;
+    for (uint32_t k0 = 0; k0 < nlow; k0 += bper) {
+        const uint32_t k1 = k0 + bper < nlow ? k0 + bper : nlow;
+        const uint32_t base = cnt[k0], cend = k1 < nlow ? cnt[k1] : len;       // cursors of this chunk's buckets are still at their starts
+        const bool staged = !direct && cend - base <= cap;
+        __syncthreads();                       // all lanes hold base / cend before the cursors move
+        for (uint32_t j = pbeg + threadIdx.x; j < pend; j += blockDim.x) {
+            const uint32_t e = tmp[j], bk = e >> sh;
+            if (bk < k0 || bk >= k1) continue;
+            uint32_t val;
+            if (g.idx_bits) {
+                val = (e & imask) | (((e >> g.idx_bits) & 1u) << 31);
+            } else {
+                uint32_t lo = 0, hi = g.nblk;  // slice = largest b with run0[b] <= j
+                while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (run0[mid] <= j) lo = mid; else hi = mid; }
+                val = ((lo << SORT_SLICE_LOG) + (e & in_mask)) | (((e >> SORT_SLICE_LOG) & 1u) << 31);
+            }
+            const uint32_t pos = atomicAdd(&cnt[bk], 1u);
+            if (staged) buf[pos - base] = val; else sorted[pbeg + pos] = val;
         }
-        const uint32_t pos = atomicAdd(&cnt[e >> sh], 1u);
-        if (staged) buf[pos] = val; else sorted[pbeg + pos] = val;
+        __syncthreads();
+        if (staged)
+            for (uint32_t j = threadIdx.x; j < cend - base; j += blockDim.x) sorted[pbeg + base + j] = buf[j];
+        __syncthreads();                       // the buffer is free for the next chunk
     }
-    if (!staged) return;
-    __syncthreads();
-    for (uint32_t j = threadIdx.x; j < len; j += blockDim.x) sorted[pbeg + j] = buf[j];
 }
 
 // ---------------------------------------------------------------------------------------------- 3b: schedule buckets by size
@@ -1020,7 +1039,7 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     while ((avg >> sg.bin_shift) > 96) sg.bin_shift++;        // keep the average bucket inside the 256 size bins
     if ((uint64_t)n * W >= 0xffffffffull) return plonk_fail(PLONK_ERR_ARG, "msm slice too large");
     SortGeom g;
-    g.n = n; g.W = W; g.cb = cb;
+    g.n = n; g.W = W; g.cb = cb; g.stage_cap = 0;
     if (!sort_geometry(cb, n, &g.lp)) return plonk_fail(PLONK_ERR_ARG, "msm: window %d too wide for %zu points", c, n);
     g.low_bits = cb - g.lp;
     g.nblk = (uint32_t)((n + SORT_SLICE - 1) / SORT_SLICE);
@@ -1064,7 +1083,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_sarr = off; off = align_up(off + pyr * sizeof(BucketL), 256);
     const uint32_t nsplit = 1;
     // plain mode: the per-(level, window) sums of large pyramids are split over `gsplit` workgroups and folded by a second launch
-    const uint32_t gsplit = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (nlev ? lev_nch[0] : 1) / 8192));
+    // (one workgroup per 2048 level-0 values: at 2^13 values per window — c = 16, the 2^20-point plan — a single workgroup walked 32 points per lane
+    //  before its 8-step tree, the deepest dependent chain of a small MSM's reduction)
+    const uint32_t gsplit = (uint32_t)std::min<uint64_t>(32, std::max<uint64_t>(1, (nlev ? lev_nch[0] : 1) / 2048));
     const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * nsplit * sizeof(XyzzPt<NQ>), 256);
     const size_t o_wpart = off; off = align_up(off + (gsplit > 1 ? (size_t)Wr * (nlev + 1) * gsplit * sizeof(BucketL) : 0), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
@@ -1109,8 +1130,12 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     }
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(SCATTER_THREADS), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
                        blk_off, tmp);
-    const size_t lds_staged = (((size_t)1 << g.low_bits) + (g.idx_bits ? 0 : g.nblk) + STAGE_CAP) * 4;
-    if (g.low_bits >= 8 && lds_staged <= 78 * 1024 && !getenv("PLONK_MSM_NO_STAGED_SORT")) {
+    // the staged level-2 kernel: 78 KiB of LDS per workgroup (two per CU); what the counters and the slice starts leave is the staging buffer
+    const size_t lds_fixed = (((size_t)1 << g.low_bits) + (g.idx_bits ? 0 : g.nblk)) * 4;
+    const size_t lds_staged = 78 * 1024;
+    g.stage_cap = lds_fixed + 4096 * 4 <= lds_staged ? (uint32_t)((lds_staged - lds_fixed) / 4) : 0;
+    if (ws.sort_stage_cap > 0 && g.stage_cap) g.stage_cap = std::min<uint32_t>(g.stage_cap, std::max<uint32_t>((uint32_t)ws.sort_stage_cap, STAGE_THREADS));   // tests: force the chunked path
+    if (g.low_bits >= 8 && g.stage_cap >= STAGE_THREADS && !getenv("PLONK_MSM_NO_STAGED_SORT")) {
         static bool attr2 = false;
         if (!attr2) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_partition_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));

@@ -198,3 +198,28 @@ def test_persistent_accumulation_matches_plain_grid_and_oracle(gpu_workers, orac
     finally:
         w.set_option("msm_window", 0)
         w.set_option("msm_acc_persist", 4)
+
+
+def test_level2_sort_in_chunks_matches_single_chunk_and_oracle(gpu_workers, oracle):
+    """The staged level-2 sort orders a partition in LDS; a partition larger than its buffer (every partition above 2^24 points; skewed
+    scalars at any size) is ordered in several chunks of consecutive buckets.  Forced here with a 1024-entry buffer at 2^18 points and a
+    20-bit window (256-entry partitions fit, the top window's and the skewed vector's do not), against the default buffer and the oracle."""
+    w = gpu_workers("bn254")
+    n = 1 << 18
+    bases = oracle.gen_bases(0, 51, 1 << 10, n)
+    w.init(bases, 0, 0)
+    rnd = oracle.from_mont(0, oracle.rand_fr(0, 52, n))
+    skew = rnd.copy()
+    skew[:, 0] &= np.uint64(0xFFF)                              # window 0: 2^18 points in 4096 buckets of 4 partitions
+    try:
+        w.set_option("msm_window", 20)
+        for name, sc in (("uniform", rnd), ("skewed", skew)):
+            want = oracle.msm(0, bases, sc, threads=8)
+            w.set_option("msm_sort_stage_cap", 0)
+            assert _affine_eq(w, oracle, 0, w.var_msm(MsmWorkload(0, n), sc), want), (name, "default buffer")
+            for cap in (1024, 3000):
+                w.set_option("msm_sort_stage_cap", cap)
+                assert _affine_eq(w, oracle, 0, w.var_msm(MsmWorkload(0, n), sc), want), (name, cap)
+    finally:
+        w.set_option("msm_window", 0)
+        w.set_option("msm_sort_stage_cap", 0)
