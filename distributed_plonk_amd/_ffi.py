@@ -140,6 +140,11 @@ def lib():
         except Exception:  # pragma: no cover - torch is optional for the C ABI itself
             pass
         L = C.CDLL(LIB_PATH)
+        if hasattr(L, "plonk_hostemu_marker") and os.environ.get("PLONK_ALLOW_HOSTEMU") != "1":
+            # tests/hostemu builds the kernel sources for the CPU so the test suite can execute them without a GPU; that library is
+            # test infrastructure and never a compute path of this package: refuse it unless the test harness itself opted in
+            raise ImportError(f"{LIB_PATH} is the host EMULATION of libplonk_hip.so (tests/hostemu): distributed_plonk_amd has no CPU "
+                              "path. Unset PLONK_HIP_LIB, or set PLONK_ALLOW_HOSTEMU=1 if you are the test harness.")
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)          # AttributeError here = header/library mismatch: fail loudly
             fn.restype = res
