@@ -64,7 +64,7 @@ def build(asan=False, force=False, verbose=True):
 
     with cf.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
-    subprocess.check_call(["g++", "-shared", "-pthread", *(["-fsanitize=address"] if asan else []), *objs, "-ldl", "-o", out])
+    subprocess.check_call(["g++", "-shared", "-pthread", *(["-fsanitize=address"] if asan else []), *objs, "-ldl", "-lrt", "-o", out])
     if verbose:
         print("built", out)
     return out

@@ -297,9 +297,19 @@ const char* hipGetErrorString(hipError_t e) {
     }
 }
 hipError_t hipGetLastError() { return hipSuccess; }
-hipError_t hipSetDevice(int dev) { return dev == 0 ? hipSuccess : hipErrorInvalidValue; }
-hipError_t hipGetDevice(int* dev) { *dev = 0; return hipSuccess; }
-hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+// HIPEMU_DEVICES "GPUs" (default 1) that all are this host: a multi-rank test gives every rank process its own device index
+static int device_count() {
+    const char* e = getenv("HIPEMU_DEVICES");
+    return e ? std::max(1, atoi(e)) : 1;
+}
+static thread_local int tl_device = 0;
+hipError_t hipSetDevice(int dev) {
+    if (dev < 0 || dev >= device_count()) return hipErrorInvalidValue;
+    tl_device = dev;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int* dev) { *dev = tl_device; return hipSuccess; }
+hipError_t hipGetDeviceCount(int* n) { *n = device_count(); return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));
     snprintf(p->name, sizeof(p->name), "host emulation (tests/hostemu)");

@@ -26,8 +26,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TAU = 0x1234567_89ABCDEF_0FEDCBA9_87654321_13579BDF_2468ACE0_0F0F0F0F
 
 
+def _emulated():
+    """tests/test_hostemu.py runs this module's rank programs on CPU: the kernel sources compiled for the host (tests/hostemu), every rank a
+    process with its own emulated device, shared memory under the library's comm_* interface in place of RCCL."""
+    return os.environ.get("PLONK_ALLOW_HOSTEMU") == "1"
+
+
 def _world_sizes():
-    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if _emulated():
+        have = int(os.environ.get("HIPEMU_DEVICES", "1"))
+    else:
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
     return [pytest.param(w, marks=pytest.mark.skipif(have < w, reason=f"needs {w} GPUs, this box has {have}")) for w in (1, 2, 4, 8)]
 
 
@@ -64,7 +73,8 @@ def _setup(rank, world, port):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
-    torch.cuda.set_device(rank)
+    if not _emulated():
+        torch.cuda.set_device(rank)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     return dist
 
