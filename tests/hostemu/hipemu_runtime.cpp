@@ -18,6 +18,7 @@
 #include <vector>
 
 #if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/asan_interface.h>
 #include <sanitizer/common_interface_defs.h>
 #define HIPEMU_ASAN 1
 #endif
@@ -183,6 +184,7 @@ void run_block(Worker* w, dim3 block) {
 // ---------------------------------------------------------------------------------------------- the pool
 struct Job {
     dim3 grid, block;
+    size_t shmem = 0;
     const std::function<void()>* body = nullptr;
     std::atomic<uint64_t> next{0};
     uint64_t nblocks = 0;
@@ -198,7 +200,22 @@ uint64_t g_generation = 0;
 int g_busy = 0;
 std::vector<std::thread>& g_pool = *new std::vector<std::thread>;
 
+// HIPEMU_FILL=<0..255>: fresh "device" allocations and every workgroup's dynamic LDS start out filled with this byte instead of
+// whatever malloc returns — a run whose result changes with the fill pattern reads memory it never wrote.
+int fill_byte() {
+    static int v = [] {
+        const char* e = getenv("HIPEMU_FILL");
+        return e ? (atoi(e) & 255) : -1;
+    }();
+    return v;
+}
+
 void work_on(Worker* w, Job* job) {
+#if defined(HIPEMU_ASAN)
+    // only the bytes the launch asked for are LDS; the rest of the window is poisoned so an overrun is reported
+    __asan_unpoison_memory_region(w->smem, SMEM_BYTES);
+    __asan_poison_memory_region(w->smem + job->shmem, SMEM_BYTES - job->shmem);
+#endif
     gridDim = job->grid;
     blockDim = job->block;
     w->body = job->body;
@@ -208,6 +225,7 @@ void work_on(Worker* w, Job* job) {
         blockIdx.x = (uint32_t)(b % job->grid.x);
         blockIdx.y = (uint32_t)((b / job->grid.x) % job->grid.y);
         blockIdx.z = (uint32_t)(b / ((uint64_t)job->grid.x * job->grid.y));
+        if (fill_byte() >= 0) memset(w->smem, fill_byte(), job->shmem);      // LDS holds garbage when a workgroup starts
         run_block(w, job->block);
     }
 }
@@ -253,7 +271,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& th
     if (!nblocks || !(block.x * block.y * block.z)) return;
     std::lock_guard<std::mutex> launch_lock(g_launch_mutex);
     Job job;
-    job.grid = grid; job.block = block; job.body = &thread_body; job.nblocks = nblocks;
+    job.grid = grid; job.block = block; job.body = &thread_body; job.nblocks = nblocks; job.shmem = shmem;
     std::unique_lock<std::mutex> lk(g_mutex);
     if (g_pool.empty())
         for (int i = 0; i < pool_size(); i++) { g_pool.emplace_back(pool_main); g_pool.back().detach(); }
@@ -325,6 +343,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 hipError_t hipMalloc(void** p, size_t bytes) {
     void* m = nullptr;
     if (posix_memalign(&m, 256, bytes ? bytes : 256)) { *p = nullptr; return hipErrorOutOfMemory; }
+    if (fill_byte() >= 0) memset(m, fill_byte(), bytes);
     *p = m;
     return hipSuccess;
 }
