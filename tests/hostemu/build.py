@@ -1,6 +1,6 @@
 """Build the HOST EMULATION of libplonk_hip.so (test infrastructure; see hip/hip_runtime.h in this directory).
 
-    python -m tests.hostemu.build [--asan] [--force]
+    python -m tests.hostemu.build [--asan | --ubsan] [--force]
 
 The kernel sources are taken as they are from distributed_plonk_amd/csrc; the one construct a header cannot emulate —
 `extern __shared__ T name[];`, the dynamic LDS window — is rewritten on a COPY under _build/src/ into a pointer to the emulated
@@ -42,8 +42,8 @@ def _stage_sources(src_dir):
     return newest
 
 
-def build(asan=False, force=False, verbose=True):
-    variant = "asan" if asan else "plain"
+def build(asan=False, force=False, verbose=True, ubsan=False):
+    variant = "ubsan" if ubsan else ("asan" if asan else "plain")
     bdir = os.path.join(HERE, "_build", variant)
     src_dir = os.path.join(HERE, "_build", "src")
     os.makedirs(bdir, exist_ok=True)
@@ -53,7 +53,8 @@ def build(asan=False, force=False, verbose=True):
         return out
     flags = ["-std=c++17", "-fPIC", "-pthread", "-I", HERE, "-I", src_dir, "-I", os.path.join(ROOT, "include"), "-include", "hip/hip_runtime.h",
              "-Wno-unknown-pragmas", "-Wno-attributes", "-fno-strict-aliasing"]
-    flags += ["-O1", "-g", "-fsanitize=address", "-fno-omit-frame-pointer"] if asan else ["-O2"]
+    san = ["-fsanitize=undefined", "-fno-sanitize-recover=undefined"] if ubsan else (["-fsanitize=address"] if asan else [])
+    flags += ["-O1", "-g", "-fno-omit-frame-pointer", *san] if san else ["-O2"]
     jobs = [(os.path.join(src_dir, u.replace(".hip", ".cpp")), os.path.join(bdir, u.replace(".hip", ".o"))) for u in UNITS]
     jobs += [(os.path.join(HERE, f), os.path.join(bdir, f.replace(".cpp", ".o"))) for f in ("hipemu_runtime.cpp", "comm_local.cpp")]
 
@@ -64,11 +65,11 @@ def build(asan=False, force=False, verbose=True):
 
     with cf.ThreadPoolExecutor(max_workers=len(jobs)) as ex:
         objs = list(ex.map(compile_one, jobs))
-    subprocess.check_call(["g++", "-shared", "-pthread", *(["-fsanitize=address"] if asan else []), *objs, "-ldl", "-lrt", "-o", out])
+    subprocess.check_call(["g++", "-shared", "-pthread", *san, *objs, "-ldl", "-lrt", "-o", out])
     if verbose:
         print("built", out)
     return out
 
 
 if __name__ == "__main__":
-    build(asan="--asan" in sys.argv, force="--force" in sys.argv)
+    build(asan="--asan" in sys.argv, ubsan="--ubsan" in sys.argv, force="--force" in sys.argv)

@@ -131,6 +131,8 @@ void make_fiber(Fiber& f) {
     f.state = DONE;
 }
 
+int sweep_order();
+
 void run_block(Worker* w, dim3 block) {
     const uint32_t nt = block.x * block.y * block.z;
     while (w->fibers.size() < nt) {
@@ -143,9 +145,22 @@ void run_block(Worker* w, dim3 block) {
     for (uint32_t t = 0; t < nt; t++) { w->fibers[t].state = READY; w->fibers[t].shfl_seq = 0; }
     uint32_t live = nt;
     const uint32_t nwaves = (nt + 63) / 64;
+    const int order = sweep_order();
+    uint64_t lcg = 0x9E3779B97F4A7C15ull * (1 + blockIdx.x + 131ull * blockIdx.y);
     while (live) {
         bool progressed = false;
-        for (uint32_t t = 0; t < nt; t++) {
+        // HIPEMU_ORDER: the order in which a sweep resumes the runnable threads of a workgroup — 0 ascending (default), 1 descending,
+        // 2 a fresh pseudo-random rotation + direction per sweep.  Between two barriers the threads of a block run one after another, so a
+        // result that depends on this order is a missing barrier (or code that leans on wave-lockstep execution).
+        uint32_t start = 0;
+        bool down = order == 1;
+        if (order == 2) {
+            lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+            start = (uint32_t)(lcg >> 33) % nt;
+            down = (lcg >> 32) & 1;
+        }
+        for (uint32_t i = 0; i < nt; i++) {
+            const uint32_t t = down ? (start + nt - i - (order == 2 ? 0 : 1)) % nt : (start + i) % nt;
             Fiber& f = w->fibers[t];
             if (f.state != READY) continue;
             threadIdx.x = t % block.x;
@@ -202,6 +217,13 @@ std::vector<std::thread>& g_pool = *new std::vector<std::thread>;
 
 // HIPEMU_FILL=<0..255>: fresh "device" allocations and every workgroup's dynamic LDS start out filled with this byte instead of
 // whatever malloc returns — a run whose result changes with the fill pattern reads memory it never wrote.
+int sweep_order() {
+    static int v = [] {
+        const char* e = getenv("HIPEMU_ORDER");
+        return e ? atoi(e) : 0;
+    }();
+    return v;
+}
 int fill_byte() {
     static int v = [] {
         const char* e = getenv("HIPEMU_FILL");
