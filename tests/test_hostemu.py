@@ -103,3 +103,20 @@ def test_distributed_transform_steps_and_coset_classes(emu_env):
 def test_batched_commitments_and_fixed_base_table(emu_env):
     _pytest(emu_env, ["tests/test_gpu_commit_many.py"], k="not full_size and not group_limit")
     _pytest(emu_env, ["tests/test_gpu_msm_table.py"], k="bn254")
+
+
+def test_compiled_cpp_host_program(emu_env, tmp_path):
+    """tests/host_cpp/host_check.cpp — the reference's worker / dispatcher orchestration as compiled C++ on the bare C ABI (host/plonk_host.hpp):
+    distributed FFT in all four modes on S = 1, 2, 4 in-process workers, sharded MSM, commit_polynomial, a batched prover round — with no Python
+    between the program and the (emulated) library; BN254 here, both curves on the GPU (tests/test_host_cpp.py)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_cpp import _build
+    from oracle import oracle as O
+    O.lib()
+    exe = _build(tmp_path)
+    shadow = tmp_path / "emu"
+    shadow.mkdir()
+    os.symlink(emu_env["PLONK_HIP_LIB"], shadow / "libplonk_hip.so")            # DT_RUNPATH yields to LD_LIBRARY_PATH
+    env = dict(emu_env, LD_LIBRARY_PATH=str(shadow) + os.pathsep + emu_env.get("LD_LIBRARY_PATH", ""))
+    res = subprocess.run([exe, os.path.join(ROOT, "oracle", "libplonk_oracle.so"), "0"], capture_output=True, text=True, timeout=900, env=env)
+    assert res.returncode == 0 and "host_check ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
