@@ -133,10 +133,21 @@ class ResultLine:
         self._lock = threading.Lock()
         self._leg = (None, None)                 # (name, deadline on time.monotonic())
 
+    @staticmethod
+    def _scrub(x):
+        """an emulated dry run carries no timing of anything: drop every clock-derived field, keep the verdicts"""
+        if isinstance(x, dict):
+            return {k: ResultLine._scrub(v) for k, v in x.items()
+                    if not (k == "ms" or k.endswith("_ms") or k.startswith("ms_") or "_ms_" in k or "constraints_per_s" in k or k.startswith("proof_ms"))}
+        if isinstance(x, list):
+            return [ResultLine._scrub(v) for v in x]
+        return x
+
     def emit(self):
         with self._lock:
             if self.rank == 0 and not self._emitted.is_set():
-                os.write(self.fd, (json.dumps(self.out) + "\n").encode())
+                line = self._scrub(self.out) if isinstance(self.out, dict) and self.out.get("emulated") else self.out
+                os.write(self.fd, (json.dumps(line) + "\n").encode())
             self._emitted.set()
 
     def arm(self, name, seconds):
@@ -188,12 +199,26 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    if not torch.cuda.is_available():
+    # tests/test_hostemu.py only: a DRY RUN of this program's control flow (the N > 1 legs above all) against the host emulation of the
+    # library — rank processes under gloo, no GPU, tiny sizes.  Its JSON line says `emulated` and carries no value.
+    emulated = os.environ.get("PLONK_ALLOW_HOSTEMU") == "1"
+    if emulated:
+        args.no_cpu_baseline = args.no_other_configs = True
+        if args.transport != "rccl":
+            raise SystemExit("bench.py under the host emulation: only the default in-library transport has a stand-in (tests/hostemu/comm_local.cpp)")
+    elif not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    if not emulated:
+        torch.cuda.set_device(local_rank)
+    pg_kwargs = dict(backend="gloo") if emulated else dict(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    def dev_sync():
+        if not emulated:
+            torch.cuda.synchronize()
+
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group(**pg_kwargs)
 
     from distributed_plonk_amd.dispatcher import RankProver, gather_points, split_rc
     from distributed_plonk_amd.worker import PlonkWorker
@@ -210,7 +235,7 @@ def main():
     pl = plan(args, S)
     if not pl["ok"]:
         raise SystemExit("bench.py: " + "; ".join(pl["problems"]))
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cpu") if emulated else torch.device("cuda", local_rank)
     # N > 1: two contexts (two HIP streams) per rank, so that the all-to-all of one transform overlaps the
     # row / column passes of the next (the 26 size-8n transforms of a proof are independent polynomials)
     multi = S > 1 or args.multi_path
@@ -234,7 +259,7 @@ def main():
     if args.multi_path and world == 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group(rank=0, world_size=1, **pg_kwargs)
     if (world > 1 or args.multi_path) and transport == "rccl" and not sim:
         # one RCCL communicator per context (two streams -> two communicators), created in the same order on every rank; the
         # 128-byte ids travel once through the launcher's rendezvous — nothing else of the data path touches torch
@@ -453,7 +478,7 @@ def main():
     torch_comm = None
     if multi and transport == "torch" and not sim:
         from distributed_plonk_amd.class_prover import TorchComm
-        torch_comm = TorchComm(w, dev)
+        torch_comm = TorchComm(w, None if emulated else dev)
     scheme = args.scheme if multi else "single"
     step_ref2d = step
     if scheme == "classes":
@@ -462,7 +487,7 @@ def main():
     def full_sync():
         for x in set(workers) | set(cworkers):
             x.sync()
-        torch.cuda.synchronize()
+        dev_sync()
         if world > 1:
             dist.barrier()
 
@@ -613,6 +638,11 @@ def main():
                                "exposed_in_transform_phase_ms_per_step": round(max(phases_ms["transforms"] - ntt_ms, 0.0), 3),
                                "note": "rank 0; HIP events on the issuing stream around each RCCL call; a collective's time includes waiting for "
                                        "the slowest peer; exposed = host-clock transform phase minus the pass kernels' own time"}
+    if out is not None and emulated:
+        # a dry run of the control flow on the host emulation: whatever the clock said is not a measurement of anything
+        out.update(metric="EMULATED DRY RUN of bench.py's control flow (tests/hostemu, no GPU): NOT a measurement", value=None, ms_per_step=None,
+                   phases_ms=None, roofline=None, roofline_other=None, kernels=None, emulated=True)
+        out.pop("exchange", None)
     guard.arm(None, 0)
     guard.out = out
     emit, arm = guard.emit, guard.arm
@@ -659,6 +689,9 @@ def main():
             from distributed_plonk_amd import fr as _fr2
 
             def dev_i64(ptr, nbytes):
+                if emulated:                      # "device" memory of the emulation is host memory
+                    import ctypes
+                    return torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.int64)
                 return torch.as_tensor(_DevPtr(ptr, nbytes), device=dev)
 
             def all_ranks(flag):
@@ -682,7 +715,7 @@ def main():
             provers[0].fft_dev(rowsT.ptr + rank * (r_n // S) * c_n * 32, outn.ptr, n, False, True, False, out_layout=1)
             w.ntt_dev(full.ptr, ref.ptr, n, True, False)
             w.sync()
-            torch.cuda.synchronize()
+            dev_sync()
             got = dev_i64(outn.ptr, n_loc * 32).view(r_n, c_n // S, 4)
             want = dev_i64(ref.ptr, n * 32).view(r_n, c_n, 4)[:, rank * (c_n // S):(rank + 1) * (c_n // S), :]
             mv["distributed_intt_n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
@@ -699,7 +732,7 @@ def main():
                 provers[0].fft_dev(rows_m.ptr + rank * (r_m // S) * L * 32, outm.ptr, m, True, False, True, out_layout=1, row_len=L)
                 w.coset_eval_dev(p_pad.ptr, poly_len, m, f2.to_limbs(f2.generator), refm.ptr)
                 w.sync()
-                torch.cuda.synchronize()
+                dev_sync()
                 got = dev_i64(outm.ptr, m_loc * 32).view(r_m, c_m // S, 4)
                 want = dev_i64(refm.ptr, m * 32).view(r_m, c_m, 4)[:, rank * (c_m // S):(rank + 1) * (c_m // S), :]
                 mv["distributed_zero_padded_coset_fft_8n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
@@ -1001,7 +1034,7 @@ def main():
             if world == 1 and not dist.is_initialized() and not sim:
                 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
                 os.environ.setdefault("MASTER_PORT", "29653")
-                dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+                dist.init_process_group(rank=0, world_size=1, **pg_kwargs)
             fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
             TAU = 0x2F0D5EED0C0FFEE0123456789ABCDEF0FEDCBA98765432100F1E2D3C4B5A697 % fld.p
             G_, r_ = (sim, 0) if sim else (world, rank)
@@ -1034,7 +1067,7 @@ def main():
                     return out_
                 comm = LibComm(w, bootstrap=_boot)
             else:
-                comm = TorchComm(w, dev)
+                comm = TorchComm(w, None if emulated else dev)
             cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
             cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
             pub = inst.public_inputs()

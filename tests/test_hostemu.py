@@ -120,3 +120,41 @@ def test_compiled_cpp_host_program(emu_env, tmp_path):
     env = dict(emu_env, LD_LIBRARY_PATH=str(shadow) + os.pathsep + emu_env.get("LD_LIBRARY_PATH", ""))
     res = subprocess.run([exe, os.path.join(ROOT, "oracle", "libplonk_oracle.so"), "0"], capture_output=True, text=True, timeout=900, env=env)
     assert res.returncode == 0 and "host_check ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
+
+
+def _bench_dry_run(env, world, port, extra=()):
+    """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one rank per device), against the emulation at a tiny size:
+    a DRY RUN of the program's control flow.  The line it prints says `emulated`, has no value and no clock-derived field."""
+    import json
+    e = dict(env, HIPEMU_DEVICES="8", HIPEMU_THREADS="2", PLONK_BENCH_HEADLINE_BUDGET_S="800", PLONK_BENCH_LEG_BUDGET_S="600")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "bench.py", "--gpus", str(world), "--steps", "1", "--warmup", "1", "--log-n", "9", *extra]
+    r = subprocess.run(cmd, cwd=ROOT, env=e, capture_output=True, text=True, timeout=1200)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("world,extra", [(2, ()), (4, ("--scheme", "classes"))])
+def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
+    """The N > 1 legs of bench.py have never met more than one real GPU; here every one of them executes: two lanes of distributed transforms
+    with an exchange each, the sharded batched commitments and their point all-gather, the other scheme, the verification leg (distributed
+    iNTT and zero-padded coset FFT against single-rank recomputation on every rank, sharded commitment against all shards on one rank) and
+    the class prover with a sharded key, whose proof rank 0 hands to the verifier."""
+    from conftest import free_port
+    d = _bench_dry_run(emu_env, world, free_port(), extra)
+    assert d["emulated"] is True and d["value"] is None and d["n_gpus"] == world
+    assert not [k for k in d if k.endswith("_ms") or k.startswith("ms_")], "an emulated run must not carry timings"
+    assert d["verified"] is True and all(d["verification"].values()), d["verification"]
+    assert d.get("aborted_optional_leg") is None
+    assert "error" not in (d["other_scheme"] or {}), d["other_scheme"]
+    cp = d["next_rows"]["class_prover"]
+    assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
+
+
+def test_differential_fuzz_slice(emu_env):
+    """A fixed-seed slice of tools/fuzz_abi.py (random operations, shapes, flags and options against the oracle); long runs are a manual tool —
+    5 000 operations on the plain and the AddressSanitizer builds found no mismatch when this was written."""
+    r = subprocess.run([sys.executable, "tools/fuzz_abi.py", "--seconds", "200", "--max-ops", "120", "--seed", "5", "--max-log", "10"], cwd=ROOT, env=emu_env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "fuzz ok: 120 operations" in r.stdout, (r.stdout + r.stderr)[-2000:]

@@ -1,0 +1,323 @@
+#!/usr/bin/env python3
+"""Differential fuzzing of the C ABI against the CPU oracle: random operations with random shapes, flags and options — sizes that
+are not in any fixed test list (odd lengths, single elements, lengths around the class / pass / slice boundaries), special field
+values, repeated and infinite bases, forced Pippenger windows — every result compared bit-for-bit with the oracle.
+
+    python tools/fuzz_abi.py --seconds 600 [--seed 1] [--curve bn254|bls12_381|both] [--max-log 13]
+
+It drives whatever library `distributed_plonk_amd._ffi` loads: libplonk_hip.so on an MI355X, or — in the GPU-less build container —
+the host emulation (tests/hostemu; PLONK_HIP_LIB=tests/hostemu/_build/plain/libplonk_hostemu.so PLONK_ALLOW_HOSTEMU=1), where it
+is also worth running against the AddressSanitizer build.  The first mismatch prints the operation and its parameters (enough to
+replay it with --seed / --only) and exits 1.  tests/test_hostemu.py runs a short fixed-seed slice of it in the CPU suite.
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+class Fuzz:
+    def __init__(self, curve, cid, seed, max_log):
+        from distributed_plonk_amd import fr as _fr
+        from distributed_plonk_amd.worker import PlonkWorker
+        from oracle import oracle as O
+        self.O, self.cid, self.curve = O, cid, curve
+        self.w = PlonkWorker(me=0, device=0, curve=curve)
+        self.f = _fr.FIELDS[curve]
+        self.rs = np.random.RandomState(seed)
+        self.max_log = max_log
+        self.counter = 0
+        self.n_bases = 0
+
+    # ---------------------------------------------------------------- inputs
+    def seed(self):
+        self.counter += 1
+        return int(self.rs.randint(1, 1 << 30)) + self.counter
+
+    def fr(self, n):
+        """n field elements (Montgomery limbs): random, with a sprinkling of 0, 1, p - 1 and small values"""
+        v = self.O.rand_fr(self.cid, self.seed(), max(n, 1))[:n].copy()
+        if n and self.rs.rand() < 0.5:
+            special = [self.f.to_limbs(x) for x in (0, 1, self.f.p - 1, 2, self.f.p - 2)]
+            for _ in range(int(self.rs.randint(1, 4))):
+                v[int(self.rs.randint(0, n))] = special[int(self.rs.randint(0, len(special)))]
+        if n and self.rs.rand() < 0.05:
+            v[:] = 0
+        return v
+
+    def one(self):
+        return self.fr(3)[int(self.rs.randint(0, 3))]
+
+    def up(self, arr):
+        b = self.w.alloc(max(arr.nbytes, 32))
+        if arr.nbytes:
+            b.upload(np.ascontiguousarray(arr))
+        return b
+
+    # ---------------------------------------------------------------- operations
+    def op_ntt(self):
+        log_n = int(self.rs.randint(0, self.max_log + 1))
+        n = 1 << log_n
+        inv, coset = bool(self.rs.randint(0, 2)), bool(self.rs.randint(0, 2))
+        v = self.fr(n)
+        d_in, d_out = self.up(v), self.w.alloc(n * 32)
+        self.w.ntt_dev(d_in.ptr, d_out.ptr, n, inv, coset)
+        got = d_out.download((n, 4))
+        d_in.free(); d_out.free()
+        return np.array_equal(got, self.O.ntt(self.cid, v, inv, coset, threads=4)), dict(log_n=log_n, inv=inv, coset=coset)
+
+    def op_coset_eval_interp(self):
+        log_s = int(self.rs.randint(1, self.max_log + 1))
+        size = 1 << log_s
+        pick = self.rs.rand()
+        if pick < 0.3:
+            length = int(self.rs.randint(1, 4 * size + 1))
+        elif pick < 0.6:                                         # around the class boundaries size / 2^k (+ the 3 folded coefficients)
+            length = max(1, (size >> int(self.rs.randint(0, min(log_s, 5) + 1))) + int(self.rs.randint(-2, 5)))
+        else:
+            length = int(self.rs.randint(1, size + 4))
+        length = min(length, 4 * size)
+        shift_i = int.from_bytes(self.rs.bytes(31), "little") % self.f.p or 5
+        shift = self.f.to_limbs(shift_i)
+        poly = self.fr(length)
+        d_p, d_o = self.up(poly), self.w.alloc(size * 32)
+        self.w.coset_eval_dev(d_p.ptr, length, size, shift, d_o.ptr)
+        got = d_o.download((size, 4))
+        # expected: fold the coefficients beyond `size` (X^size = shift^size on the coset), scale by shift^i, plain NTT
+        p = self.f.p
+        folded = [0] * size
+        ssz = pow(shift_i, size, p)
+        for i in range(length):
+            folded[i % size] = (folded[i % size] + self.f.from_limbs(poly[i]) * pow(ssz, i // size, p)) % p
+        sp = 1
+        for i in range(size):
+            folded[i] = folded[i] * sp % p
+            sp = sp * shift_i % p
+        want = self.O.ntt(self.cid, self.f.vec_to_limbs(folded), False, False, threads=4)
+        ok = np.array_equal(got, want)
+        info = dict(log_size=log_s, length=length)
+        if ok and self.rs.rand() < 0.5:                          # and back: interpolation of a window of coefficients
+            i0 = int(self.rs.randint(0, size))
+            count = int(self.rs.randint(1, size - i0 + 1))
+            scale_i = int.from_bytes(self.rs.bytes(31), "little") % p or 1
+            d_c = self.w.alloc(count * 32)
+            self.w.coset_interp_dev(d_o.ptr, size, shift, self.f.to_limbs(scale_i), i0, count, d_c.ptr)
+            back = d_c.download((count, 4))
+            d_c.free()
+            # the interpolant of the evaluations is the FOLDED polynomial (before the shift scaling)
+            sinv = pow(shift_i, -1, p)
+            coeff = [0] * size
+            for i in range(length):
+                coeff[i % size] = (coeff[i % size] + self.f.from_limbs(poly[i]) * pow(ssz, i // size, p)) % p
+            want_c = self.f.vec_to_limbs([scale_i * coeff[i0 + t] % p for t in range(count)])
+            ok = np.array_equal(back, want_c)
+            info.update(interp=(i0, count))
+            del sinv
+        d_p.free(); d_o.free()
+        return ok, info
+
+    def ensure_bases(self, n):
+        """a fresh SRS now and then: distinct points, tiled points (equal bases in one bucket), a few points at infinity"""
+        if self.n_bases >= n and self.rs.rand() < 0.8:
+            return
+        n_new = max(n, int(self.rs.randint(1, 1 << min(self.max_log, 12)) + 1))
+        unique = n_new if self.rs.rand() < 0.5 else int(self.rs.randint(1, min(n_new, 64) + 1))
+        bases = self.O.gen_bases(self.cid, self.seed(), unique, n_new)
+        inf = np.zeros(n_new, dtype=np.uint8)
+        for _ in range(int(self.rs.randint(0, 3))):
+            i = int(self.rs.randint(0, n_new))
+            bases[i] = 0                                              # (0, 0) is infinity in the XY layout
+            inf[i] = 1
+        self.bases, self.inf, self.n_bases = bases, inf, n_new
+        self.w.init(bases, 1 << self.max_log, 8 << self.max_log)
+
+    def scalars(self, n):
+        s = self.O.from_mont(self.cid, self.fr(n))
+        if n and self.rs.rand() < 0.3:                                # skew: many equal digits
+            s[self.rs.rand(n) < 0.7] = s[0]
+        return s
+
+    def affine_eq(self, jac, want_jac):
+        a, ai = self.w.g1_to_affine(jac)
+        b, bi = self.O.jac_to_affine(self.cid, want_jac)
+        return ai == bi and np.array_equal(a, b)
+
+    def op_msm(self):
+        from distributed_plonk_amd._ffi import MsmWorkload
+        n = int(self.rs.randint(1, 1 << min(self.max_log, 12)) + 1)
+        self.ensure_bases(n)
+        start = int(self.rs.randint(0, self.n_bases - n + 1))
+        window = int(self.rs.choice([0, 0, 0, 2, 3, 5, 8, 11, 13]))
+        persist = int(self.rs.choice([4, 4, 0, -1, -3]))
+        self.w.set_option("msm_window", window)
+        self.w.set_option("msm_acc_persist", persist)
+        sc = self.scalars(n)
+        try:
+            jac = self.w.var_msm(MsmWorkload(start, start + n), sc)
+        finally:
+            self.w.set_option("msm_window", 0)
+            self.w.set_option("msm_acc_persist", 4)
+        return self.affine_eq(jac, self.O.msm(self.cid, self.bases[start:start + n], sc, inf=self.inf[start:start + n], threads=4)), dict(n=n, start=start, window=window, persist=persist)
+
+    def op_commit_many(self):
+        K = int(self.rs.randint(1, 7))
+        n = int(self.rs.randint(1, 1 << min(self.max_log, 11)) + 1)
+        self.ensure_bases(n)
+        start = int(self.rs.randint(0, self.n_bases - n + 1))
+        lens = [int(self.rs.randint(0, n + 1)) for _ in range(K)]
+        lens[int(self.rs.randint(0, K))] = n
+        polys = [self.fr(ln) for ln in lens]
+        bufs = [self.up(p_) for p_ in polys]
+        jacs = self.w.commit_many_dev([(b.ptr, ln) for b, ln in zip(bufs, lens)], start=start)
+        ok = True
+        for j, (p_, ln) in enumerate(zip(polys, lens)):
+            want = self.O.commit_polynomial(self.cid, self.bases[start:start + max(ln, 1)], p_ if ln else self.f.vec_to_limbs([0]),
+                                            inf=self.inf[start:start + max(ln, 1)], threads=4)
+            ok = ok and self.affine_eq(jacs[j], want)
+        for b in bufs:
+            b.free()
+        return ok, dict(K=K, n=n, start=start, lens=lens)
+
+    def op_poly(self):
+        n = int(self.rs.randint(1, 1 << self.max_log) + 1)
+        poly = self.fr(n)
+        z = self.one()
+        d_p = self.up(poly)
+        ok = np.array_equal(self.w.poly_eval_dev(d_p.ptr, n, z), self.O.poly_eval(self.cid, poly, z))
+        info = dict(n=n, what="eval")
+        if ok and n >= 2:
+            d_q = self.w.alloc(n * 32)
+            self.w.poly_div_linear_dev(d_p.ptr, n, z, d_q.ptr)
+            ok = np.array_equal(d_q.download((n - 1, 4)), self.O.poly_div_linear(self.cid, poly, z))
+            d_q.free()
+            info["what"] = "div_linear"
+        if ok:
+            top = int(self.rs.randint(0, n))
+            poly2 = poly.copy()
+            poly2[top + 1:] = 0
+            d2 = self.up(poly2)
+            want = -1
+            for i in range(n - 1, -1, -1):
+                if poly2[i].any():
+                    want = i
+                    break
+            ok = self.w.poly_degree_dev(d2.ptr, n) == want
+            d2.free()
+            info["what"] = "degree"
+        d_p.free()
+        return ok, info
+
+    def op_lincomb(self):
+        T = int(self.rs.randint(1, 25))
+        out_len = int(self.rs.randint(1, 1 << min(self.max_log, 12)) + 1)
+        lens = [int(self.rs.randint(1, out_len + 1)) for _ in range(T)]
+        polys = [self.fr(ln) for ln in lens]
+        coeffs = self.fr(T)
+        bufs = [self.up(p_) for p_ in polys]
+        d_o = self.w.alloc(out_len * 32)
+        self.w.poly_lincomb_dev([(b.ptr, ln) for b, ln in zip(bufs, lens)], coeffs, d_o.ptr, out_len)
+        got = d_o.download((out_len, 4))
+        padded = []
+        for p_ in polys:
+            q = np.zeros((out_len, 4), dtype=np.uint64)
+            q[:len(p_)] = p_
+            padded.append(q)
+        want = self.O.poly_lincomb(self.cid, padded, coeffs)
+        for b in bufs:
+            b.free()
+        d_o.free()
+        return np.array_equal(got, want[:out_len]), dict(T=T, out_len=out_len, lens=lens)
+
+    def op_perm_product(self):
+        n = int(self.rs.randint(2, 1 << min(self.max_log, 12)) + 1)
+        # plain random values: with the special ones a denominator can vanish, which is an error here as it is a panic in the reference
+        wires = self.O.rand_fr(self.cid, self.seed(), 5 * n).reshape(5, n, 4)
+        id_perm = self.O.rand_fr(self.cid, self.seed(), 5 * n)
+        perm_idx = self.rs.permutation(5 * n).astype(np.uint64)
+        beta, gamma = self.O.rand_fr(self.cid, self.seed(), 2)
+        dw, di, dp = self.up(wires), self.up(id_perm), self.up(perm_idx)
+        out = self.w.alloc(n * 32)
+        self.w.perm_product_dev([dw.ptr + i * n * 32 for i in range(5)], di.ptr, dp.ptr, beta, gamma, n, out.ptr)
+        got = out.download((n, 4))
+        try:
+            want = self.O.perm_product(self.cid, wires, id_perm, perm_idx, beta, gamma)
+        finally:
+            for b in (dw, di, dp, out):
+                b.free()
+        return np.array_equal(got, want), dict(n=n)
+
+    def op_transpose(self):
+        rows, cols = int(self.rs.randint(1, 200)), int(self.rs.randint(1, 200))
+        v = self.fr(rows * cols)
+        got = self.w.transpose(v, rows, cols)
+        return np.array_equal(got, np.ascontiguousarray(v.reshape(rows, cols, 4).transpose(1, 0, 2)).reshape(-1, 4)), dict(rows=rows, cols=cols)
+
+    def op_distributed_fft(self):
+        from distributed_plonk_amd.dispatcher import Dispatcher
+        from distributed_plonk_amd.worker import PlonkWorker
+        log_n = int(self.rs.randint(2, min(self.max_log, 12) + 1))
+        n = 1 << log_n
+        S = int(self.rs.choice([1, 2, 4]))
+        r = 1 << (log_n >> 1)
+        if r % S or (n // r) % S:
+            S = 1
+        inv, coset = bool(self.rs.randint(0, 2)), bool(self.rs.randint(0, 2))
+        ws = [PlonkWorker(me=i, device=0, curve=self.curve) for i in range(S)]
+        try:
+            d = Dispatcher(ws)
+            d.init(None, n, 8 * n)
+            v = self.fr(n)
+            got = d.fft(v, is_quot=False, is_inv=inv, is_coset=coset)
+        finally:
+            for x in ws:
+                x.close()
+        return np.array_equal(got, self.O.ntt(self.cid, v, inv, coset, threads=4)), dict(log_n=log_n, S=S, inv=inv, coset=coset)
+
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft"]
+
+    def close(self):
+        self.w.close()
+
+
+def run(seconds, seed, curves, max_log, only=None, max_ops=None, verbose=True):
+    t_end = time.time() + seconds
+    fz = [Fuzz(c, cid, seed + 1000 * cid, max_log) for c, cid in curves]
+    counts = {}
+    it = 0
+    try:
+        while time.time() < t_end and (max_ops is None or it < max_ops):
+            f = fz[it % len(fz)]
+            name = only or Fuzz.OPS[int(f.rs.randint(0, len(Fuzz.OPS)))]
+            ok, info = getattr(f, "op_" + name)()
+            counts[name] = counts.get(name, 0) + 1
+            it += 1
+            if not ok:
+                print(f"MISMATCH curve={f.curve} op={name} iteration={it} seed={seed} params={info}", flush=True)
+                return 1, counts
+    finally:
+        for f in fz:
+            f.close()
+    if verbose:
+        print(f"fuzz ok: {it} operations, no mismatch; per op {counts}", flush=True)
+    return 0, counts
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=60)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--curve", default="both", choices=["bn254", "bls12_381", "both"])
+    ap.add_argument("--max-log", type=int, default=13)
+    ap.add_argument("--only", default=None, choices=Fuzz.OPS)
+    ap.add_argument("--max-ops", type=int, default=None)
+    a = ap.parse_args()
+    cs = [("bn254", 0), ("bls12_381", 1)]
+    if a.curve != "both":
+        cs = [c for c in cs if c[0] == a.curve]
+    raise SystemExit(run(a.seconds, a.seed, cs, a.max_log, a.only, a.max_ops)[0])
