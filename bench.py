@@ -253,6 +253,12 @@ def main():
     if os.environ.get("PLONK_BENCH_ACC_PERSIST") is not None:    # experiment knob: workgroups per CU of the persistent accumulation (0 = plain grid)
         for x in workers:
             x.set_option("msm_acc_persist", int(os.environ["PLONK_BENCH_ACC_PERSIST"]))
+    experiment_opts = {}
+    for kv in filter(None, os.environ.get("PLONK_BENCH_OPTS", "").split(",")):   # experiment knob: "key=value,..." through plonk_set_option on every context
+        k_, v_ = kv.split("=")                                                    # (e.g. msm_reduce_grid=1); recorded in config.experiment_opts
+        experiment_opts[k_.strip()] = int(v_)
+        for x in workers:
+            x.set_option(k_.strip(), int(v_))
     noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
     transport = args.transport if (world > 1 or args.multi_path) else "torch"
     rccl_info = None
@@ -615,9 +621,12 @@ def main():
                                             ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
                                              "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs")) +
                                             f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
-                       "coset_inputs": "n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else "dense 8n (plonk_ntt_dev / distributed 2-D transform)",
+                       "coset_inputs": ("n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else
+                                        "n+3 coefficients on every rank, class-local zero-padding-aware transforms (plonk_coset_eval_dev)" if scheme == "classes" and multi else
+                                        "zero-padded decimated rows, ceil((n+3)/r) leading coefficients each (plonk_fft1_dev_compact)" if rows_compact else
+                                        "dense 8n (plonk_ntt_dev / distributed 2-D transform)"),
                        "commit_batching": "plonk_commit_many_dev per prover round (5, 1, 5, 2), split over two contexts" if commit_batch else "one MSM per commitment",
-                       "rccl": rccl_info},
+                       "rccl": rccl_info, **({"experiment_opts": experiment_opts} if experiment_opts else {})},
             "roofline": roofline_entry(dominant) if dominant else None,
             "roofline_other": [roofline_entry(k) for k in roof if k != dominant],
             "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}

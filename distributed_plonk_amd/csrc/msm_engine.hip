@@ -797,6 +797,90 @@ __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzP
     }
 }
 
+// ---------------------------------------------------------------------------------------------- 5b: window reduction as a grid
+// "msm_reduce_grid" (experiment, off by default): V_w = sum_j (j+1) B_j with the bucket index split as j = hi * L + lo
+// (L = 2^ceil(cb/2) columns, H = 2^cb / L rows):
+//     V_w = sum_lo (lo+1) R_lo + L * sum_hi hi * C_hi,      R_lo = sum_hi B[hi][lo] (column sums),  C_hi = sum_lo B[hi][lo] (row sums),
+// and a weighted sum of <= 1024 points is taken bit by bit: sum_i k_i X_i = sum_b 2^b * (sum of the X_i whose weight k_i has bit b) — the
+// host's Horner supplies the 2^b.  Same two additions per bucket as the pyramid, but every sum is a TREE: the serial depth of a window's
+// reduction is T + log2(SEG) additions for the row / column sums (one launch, both kinds side by side) plus <= 2 + 8 for the bit sums,
+// against 5 additions for each of the pyramid's (c-1)/2 dependent launches and a 16-deep per-level sum.  What it targets is the latency-
+// bound reduction of SMALL problems (2^20 points: 8 + 2 launches, 1.7 ms beside 2.4 ms of accumulation); at 2^24 points the work is the same.
+//
+// One workgroup of 256 lanes = CW outputs x SEG interleaved segments; a lane adds T = Y / SEG inputs, then the SEG partial sums of an
+// output meet in an LDS tree.  kind 0 (blockIdx.x < colblocks): column sums — lane (seg, cx), consecutive lanes read consecutive columns
+// of one row; kind 1: row sums — lane (cx, seg), consecutive lanes read consecutive entries of one row.
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_grid_sums_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ in, uint32_t logL, uint32_t logH,
+                                                            uint32_t log_segc, uint32_t log_segr, uint32_t colblocks,
+                                                            XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_r,
+                                                            XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_c,
+                                                            const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
+    const uint32_t tid = threadIdx.x, w = blockIdx.y;
+    const bool col = blockIdx.x < colblocks;
+    const uint32_t blk = col ? blockIdx.x : blockIdx.x - colblocks;
+    const uint32_t log_seg = col ? log_segc : log_segr;
+    const uint32_t SEG = 1u << log_seg, CW = 256u >> log_seg;
+    const uint32_t seg = col ? tid / CW : tid & (SEG - 1);
+    const uint32_t cx = col ? tid % CW : tid >> log_seg;
+    const uint32_t X = 1u << (col ? logL : logH), Y = 1u << (col ? logH : logL);
+    const uint32_t x = blk * CW + cx;
+    const XyzzL<NL, B>* E = in + ((uint64_t)w << (logL + logH));
+    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+    if (x < X) {
+        for (uint32_t y = seg; y < Y; y += SEG) {
+            const uint64_t j = col ? ((uint64_t)y << logL) + x : ((uint64_t)x << logL) + y;
+            acc = xyzzl_add(acc, load8(E + j), P);
+        }
+    }
+    sh[tid] = acc;
+    __syncthreads();
+    const uint32_t stride = col ? CW : 1u;
+    for (uint32_t d = SEG >> 1; d > 0; d >>= 1) {
+        if (seg < d) {
+            const XyzzL<NL, B> a = sh[tid], b2 = sh[tid + d * stride];
+            sh[tid] = xyzzl_add(a, b2, P);
+        }
+        __syncthreads();
+    }
+    if (seg == 0 && x < X) store8((col ? out_r : out_c) + (uint64_t)w * X + x, sh[tid]);
+}
+
+// block (b, w): b <= logL: the column sums R_lo whose weight (lo + 1) has bit b;  b > logL: the row sums C_hi whose weight hi has bit b - logL - 1.
+// The indices with the bit set are enumerated (no lane walks an entry it skips); standard-form result at out[w * nbits + b].
+template <int NQ>
+__global__ void __launch_bounds__(256) msm_bit_sums_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ r_sums,
+                                                           const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ c_sums, uint32_t logL, uint32_t logH,
+                                                           XyzzPt<NQ>* __restrict__ out, const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
+    const uint32_t b = blockIdx.x, w = blockIdx.y, nbits = logL + 1 + logH;
+    const bool cols = b <= logL;
+    const uint32_t bit = cols ? b : b - logL - 1;
+    const uint32_t n = 1u << (cols ? logL : logH), add = cols ? 1u : 0u;
+    const XyzzL<NL, B>* src = (cols ? r_sums : c_sums) + (uint64_t)w * n;
+    XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
+    const uint32_t half = n > 1 ? n >> 1 : 1;
+    for (uint32_t u = threadIdx.x; u < half; u += blockDim.x) {
+        const uint32_t k = ((u >> bit) << (bit + 1)) | (1u << bit) | (u & ((1u << bit) - 1));      // u-th weight with bit `bit` set
+        if (k >= add && k - add < n) acc = xyzzl_add(acc, load8(src + (k - add)), P);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int d = blockDim.x / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) {
+            const XyzzL<NL, B> a = sh[threadIdx.x], b2 = sh[threadIdx.x + d];
+            sh[threadIdx.x] = xyzzl_add(a, b2, P);
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) store_std<NQ>(out + (uint64_t)w * nbits + b, sh[0], P);
+}
+
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
 // arkworks GroupAffine { x, y, infinity: bool } padded to 8 bytes: stride 16*Q64 + 8 bytes.
 template <int NQ>
@@ -1089,6 +1173,11 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     const size_t o_wsum = off; off = align_up(off + (size_t)Wr * (nlev + 1) * nsplit * sizeof(XyzzPt<NQ>), 256);
     const size_t o_wpart = off; off = align_up(off + (gsplit > 1 ? (size_t)Wr * (nlev + 1) * gsplit * sizeof(BucketL) : 0), 256);
     const size_t o_hpart = off; off = align_up(off + max_heavy * HEAVY_SEGS * sizeof(BucketL), 256);
+    // "msm_reduce_grid": buckets of a set as an H x L grid (5b); row / column sums in the limb form, then logL + 1 + logH bit sums per set
+    const bool grid_mode = ws.reduce_grid != 0 && cb >= 2;
+    const uint32_t g_logL = (uint32_t)(cb + 1) / 2, g_logH = (uint32_t)cb - g_logL, g_nbits = g_logL + 1 + g_logH;
+    const size_t o_grc = off; off = align_up(off + (grid_mode ? (size_t)Wr * (((size_t)1 << g_logL) + ((size_t)1 << g_logH)) * sizeof(BucketL) : 0), 256);
+    const size_t o_gbits = off; off = align_up(off + (grid_mode ? (size_t)Wr * g_nbits * sizeof(XyzzPt<NQ>) : 0), 256);
     int rc = ensure_ws(ws, off);
     if (rc) return rc;
     char* base = (char*)ws.d_buf;
@@ -1110,6 +1199,9 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     XyzzPt<NQ>* wsum = (XyzzPt<NQ>*)(base + o_wsum);
     BucketL* hpart = (BucketL*)(base + o_hpart);
     BucketL* wpart = (BucketL*)(base + o_wpart);
+    BucketL* grid_r = (BucketL*)(base + o_grc);
+    BucketL* grid_c = grid_r + ((size_t)Wr << g_logL);
+    XyzzPt<NQ>* gbits = (XyzzPt<NQ>*)(base + o_gbits);
 
     const size_t lds1 = ((size_t)(1u << g.lp) + 1) * 4;
     { ProfScope ps("msm_digits_kernel", stream);
@@ -1186,7 +1278,22 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     { ProfScope ps("msm_accumulate_redo_kernel", stream);
     hipLaunchKernelGGL(msm_accumulate_redo_kernel<NQ>, dim3(256), dim3(64), 0, stream, d_bases, sorted, offsets, sg, buckets, redo,
                        redo + 1, fl_params<NQ>(curve)); }
-    {
+    if (grid_mode) {
+        ProfScope ps("msm_reduce", stream);
+        // segments per output: 64 interleaved segments keep the serial part shortest; problems with lanes to spare trade a tree level for a longer
+        // serial part (T up to 8 inputs per lane) while the launch still has >= 2^18 lanes — fewer LDS tree additions per bucket
+        auto pick_seg = [&](uint32_t logY) {
+            uint32_t ls = std::min<uint32_t>(logY, 6);
+            while (ls > 3 && (logY - ls) < 3 && (((uint64_t)Wr << cb) >> (logY - ls + 1)) >= ((uint64_t)1 << 18)) ls--;
+            return ls;
+        };
+        const uint32_t log_segc = pick_seg(g_logH), log_segr = pick_seg(g_logL);
+        const uint32_t cwc = 256u >> log_segc, cwr = 256u >> log_segr;
+        const uint32_t colblocks = (uint32_t)((((uint64_t)1 << g_logL) + cwc - 1) / cwc), rowblocks = (uint32_t)((((uint64_t)1 << g_logH) + cwr - 1) / cwr);
+        hipLaunchKernelGGL(msm_grid_sums_kernel<NQ>, dim3(colblocks + rowblocks, Wr), dim3(256), 256 * sizeof(BucketL), stream, buckets, g_logL, g_logH, log_segc, log_segr,
+                           colblocks, grid_r, grid_c, fl_params<NQ>(curve));
+        hipLaunchKernelGGL(msm_bit_sums_kernel<NQ>, dim3(g_nbits, Wr), dim3(256), 256 * sizeof(BucketL), stream, grid_r, grid_c, g_logL, g_logH, gbits, fl_params<NQ>(curve));
+    } else {
         ProfScope ps("msm_reduce", stream);
         SumJobs jobs;
         memset(&jobs, 0, sizeof jobs);
@@ -1226,13 +1333,28 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm launch: %s", hipGetErrorString(e));
 
-    std::vector<XyzzPt<NQ>> h((size_t)Wr * (nlev + 1) * nsplit);
-    HIP_TRY(hipMemcpyAsync(h.data(), wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
+    std::vector<XyzzPt<NQ>> h(grid_mode ? (size_t)Wr * g_nbits : (size_t)Wr * (nlev + 1) * nsplit);
+    HIP_TRY(hipMemcpyAsync(h.data(), grid_mode ? gbits : wsum, h.size() * sizeof(XyzzPt<NQ>), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     const int Wk = G;                                  // bucket sets per scalar vector: total = sum_g 2^(c*g) * V_(k, g)
     for (int kk = 0; kk < K; kk++) {
     XyzzPt<NQ> total = xyzz_inf<NQ>();
     for (int w = (kk + 1) * Wk - 1; w >= kk * Wk; w--) {
+        if (grid_mode) {
+            // V_w = sum_(b <= logL) 2^b TR_b + 2^logL * sum_(b < logH) 2^b TC_b: one Horner over the merged coefficients, from the top bit
+            const XyzzPt<NQ>* tr = h.data() + (size_t)w * g_nbits;
+            const XyzzPt<NQ>* tc = tr + g_logL + 1;
+            XyzzPt<NQ> v = xyzz_inf<NQ>();
+            for (int b = (int)(g_logL + (g_logH ? g_logH - 1 : 0)); b >= 0; b--) {
+                if (!xyzz_is_inf(v)) v = xyzz_dbl(v, P);
+                if (b <= (int)g_logL) v = xyzz_add(v, tr[b], P);
+                if (b >= (int)g_logL && b - (int)g_logL < (int)g_logH) v = xyzz_add(v, tc[b - g_logL], P);
+            }
+            if (!xyzz_is_inf(total))
+                for (int k = 0; k < c; k++) total = xyzz_dbl(total, P);
+            total = xyzz_add(total, v, P);
+            continue;
+        }
         // V_w = Sigma + sum_l K^l A_l  (Horner from the top level)
         const XyzzPt<NQ>* hw = h.data() + (size_t)w * (nlev + 1) * nsplit;
         auto part = [&](int l) {                     // the partial sums of (level l, window w)

@@ -207,6 +207,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_fused_y3")) { ctx->msm_ws.fused_y3 = value ? 1 : 0; return PLONK_OK; }      // default 1
     if (!strcmp(key, "msm_sort_stage_cap")) { ctx->msm_ws.sort_stage_cap = (int)std::max<int64_t>(0, value); return PLONK_OK; }   // tests: force the chunked level-2 sort
     if (!strcmp(key, "msm_acc_persist")) { ctx->msm_ws.acc_persist = (int)std::max<int64_t>(-65536, std::min<int64_t>(value, 8)); return PLONK_OK; }   // default 4; < 0: an absolute grid of -value workgroups (tests)
+    if (!strcmp(key, "msm_reduce_grid")) { ctx->msm_ws.reduce_grid = value ? 1 : 0; return PLONK_OK; }   // experiment: grid reduction (msm_engine.hip, 5b); default 0
     if (!strcmp(key, "quotient_fuse")) { ctx->tables.quotient_fuse = (int)value; return PLONK_OK; }   // experiments, see quotient.hip
     if (!strcmp(key, "msm_slice_log")) { ctx->msm_ws.slice_log = (int)value; return PLONK_OK; }       // MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);

@@ -153,6 +153,7 @@ struct MsmWorkspace {
     int batch_max = 32;       // "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
     int fused_y3 = 1;         // "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
     int sort_stage_cap = 0;   // "msm_sort_stage_cap": > 0 caps the LDS staging buffer of the level-2 sort (entries; tests force its chunked path), 0 = what the LDS budget leaves
+    int reduce_grid = 0;      // "msm_reduce_grid": 1 = the window reduction as row / column tree sums + bit sums (msm_grid_sums_kernel) instead of the running-sum pyramid; experiment, not measured yet
     int acc_persist = 4;      // "msm_acc_persist": workgroups per CU of the persistent bucket accumulation (0 = one lane per bucket over the whole grid; < 0: an absolute grid of that many workgroups, for tests)
 };
 void msm_ws_release(MsmWorkspace& ws);

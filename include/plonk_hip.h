@@ -282,7 +282,8 @@ int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, c
  * persistent bucket accumulation, default 4; 0 = one lane per bucket over the whole grid; < 0 = an absolute grid, for tests),
  * "msm_precompute" (fixed-base window table built at the next init: 0 off = default, 1 when the cost model predicts a gain, 2 always),
  * "msm_table_c" / "msm_table_sets" / "msm_table_budget_mib" (the table's window width, bucket sets per scalar and memory budget; 0 = the plan's
- * choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_fused_y3", "quotient_fuse"
+ * choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_reduce_grid" (experiment, default 0: the window
+ * reduction as tree sums over the bucket grid instead of the running-sum pyramid), "msm_fused_y3", "quotient_fuse"
  * (kernel-formulation experiments).  INTEGRATION.md §6 has the table. */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
 /* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP

@@ -200,6 +200,56 @@ def test_persistent_accumulation_matches_plain_grid_and_oracle(gpu_workers, orac
         w.set_option("msm_acc_persist", 4)
 
 
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_grid_reduction_matches_pyramid_and_oracle(gpu_workers, oracle, curve, cid):
+    """`msm_reduce_grid` (experiment, off by default): the window reduction V = sum_j (j+1) B_j as row / column tree sums of the H x L bucket
+    grid plus bit sums of the <= 1024 row / column totals (msm_engine.hip, 5b) instead of the running-sum pyramid.  Every window width from
+    3 bits (a 2 x 2 grid) to 13 (64 x 64) and the plan's own choice — odd and even bucket-index widths, grids narrower than a workgroup's
+    column / row coverage — with duplicated bases (P + P inside the trees), an infinity base, all scalars equal (one non-empty bucket per window:
+    every other tree input is the point at infinity), scalars 0 / 1 / p - 1, and a batched round; against the pyramid and the oracle."""
+    w = gpu_workers(curve)
+    n = 1 << 12
+    bases = oracle.gen_bases(cid, 77, 300, n)
+    b, inf = _bases_with_inf(oracle, cid, bases, [5, 6])
+    w.init(b, 0, 0)
+    rnd = oracle.from_mont(cid, oracle.rand_fr(cid, 78, n))
+    rnd[0] = 0
+    rnd[1] = [1, 0, 0, 0]
+    rnd[2] = oracle.field_const(cid, 0, 0) - np.array([1, 0, 0, 0], dtype=np.uint64)
+    same = np.repeat(rnd[9:10], n, axis=0)
+    try:
+        for name, sc, windows in (("uniform", rnd, (0, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13)), ("all-equal", same, (0, 4, 7, 12))):
+            want = oracle.msm(cid, bases, sc, inf, threads=8)
+            for window in windows:
+                w.set_option("msm_window", window)
+                w.set_option("msm_reduce_grid", 0)
+                pyramid = w.var_msm(MsmWorkload(0, n), sc)
+                w.set_option("msm_reduce_grid", 1)
+                grid = w.var_msm(MsmWorkload(0, n), sc)
+                assert _affine_eq(w, oracle, cid, pyramid, want), (name, window, "pyramid")
+                assert _affine_eq(w, oracle, cid, grid, want), (name, window, "grid")
+        # a sub-range of the resident bases and a batched round (K vectors = K * W bucket sets reduced by one pair of launches), ragged lengths
+        w.set_option("msm_window", 0)
+        lo, hi = 100, 3001
+        assert _affine_eq(w, oracle, cid, w.var_msm(MsmWorkload(lo, hi), rnd[lo:hi]), oracle.msm(cid, bases[lo:hi], rnd[lo:hi], inf[lo:hi], threads=8))
+        lens = (n, n - 37, 1, 0)
+        vecs = [oracle.rand_fr(cid, 90 + k, n) for k in range(len(lens))]
+        bufs = [w.alloc(n * 32) for _ in vecs]
+        for d, v in zip(bufs, vecs):
+            d.upload(v)
+        pts = w.commit_many_dev([(d.ptr, ln) for d, ln in zip(bufs, lens)])
+        for v, ln, p_ in zip(vecs, lens, pts):
+            if ln:
+                assert _affine_eq(w, oracle, cid, p_, oracle.msm(cid, bases[:ln], oracle.from_mont(cid, v)[:ln], inf[:ln], threads=8)), ln
+            else:
+                assert w.g1_to_affine(p_)[1], "the empty polynomial commits to the point at infinity"
+        for d in bufs:
+            d.free()
+    finally:
+        w.set_option("msm_window", 0)
+        w.set_option("msm_reduce_grid", 0)
+
+
 def test_level2_sort_in_chunks_matches_single_chunk_and_oracle(gpu_workers, oracle):
     """The staged level-2 sort orders a partition in LDS; a partition larger than its buffer (every partition above 2^24 points; skewed
     scalars at any size) is ordered in several chunks of consecutive buckets.  Forced here with a 1024-entry buffer at 2^18 points and a

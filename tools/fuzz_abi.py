@@ -155,15 +155,19 @@ class Fuzz:
         start = int(self.rs.randint(0, self.n_bases - n + 1))
         window = int(self.rs.choice([0, 0, 0, 2, 3, 5, 8, 11, 13]))
         persist = int(self.rs.choice([4, 4, 0, -1, -3]))
+        grid = int(self.rs.choice([0, 1]))
         self.w.set_option("msm_window", window)
         self.w.set_option("msm_acc_persist", persist)
+        self.w.set_option("msm_reduce_grid", grid)
         sc = self.scalars(n)
         try:
             jac = self.w.var_msm(MsmWorkload(start, start + n), sc)
         finally:
             self.w.set_option("msm_window", 0)
             self.w.set_option("msm_acc_persist", 4)
-        return self.affine_eq(jac, self.O.msm(self.cid, self.bases[start:start + n], sc, inf=self.inf[start:start + n], threads=4)), dict(n=n, start=start, window=window, persist=persist)
+            self.w.set_option("msm_reduce_grid", 0)
+        return (self.affine_eq(jac, self.O.msm(self.cid, self.bases[start:start + n], sc, inf=self.inf[start:start + n], threads=4)),
+                dict(n=n, start=start, window=window, persist=persist, grid=grid))
 
     def op_commit_many(self):
         K = int(self.rs.randint(1, 7))
@@ -174,7 +178,12 @@ class Fuzz:
         lens[int(self.rs.randint(0, K))] = n
         polys = [self.fr(ln) for ln in lens]
         bufs = [self.up(p_) for p_ in polys]
-        jacs = self.w.commit_many_dev([(b.ptr, ln) for b, ln in zip(bufs, lens)], start=start)
+        grid = int(self.rs.choice([0, 1]))
+        self.w.set_option("msm_reduce_grid", grid)
+        try:
+            jacs = self.w.commit_many_dev([(b.ptr, ln) for b, ln in zip(bufs, lens)], start=start)
+        finally:
+            self.w.set_option("msm_reduce_grid", 0)
         ok = True
         for j, (p_, ln) in enumerate(zip(polys, lens)):
             want = self.O.commit_polynomial(self.cid, self.bases[start:start + max(ln, 1)], p_ if ln else self.f.vec_to_limbs([0]),
@@ -182,7 +191,7 @@ class Fuzz:
             ok = ok and self.affine_eq(jacs[j], want)
         for b in bufs:
             b.free()
-        return ok, dict(K=K, n=n, start=start, lens=lens)
+        return ok, dict(K=K, n=n, start=start, lens=lens, grid=grid)
 
     def op_poly(self):
         n = int(self.rs.randint(1, 1 << self.max_log) + 1)

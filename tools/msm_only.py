@@ -18,6 +18,8 @@ if os.environ.get("MSM_FUSED"):
     w.set_option("msm_fused_y3", int(os.environ["MSM_FUSED"]))
 if os.environ.get("MSM_PERSIST"):
     w.set_option("msm_acc_persist", int(os.environ["MSM_PERSIST"]))
+if os.environ.get("MSM_REDUCE_GRID"):
+    w.set_option("msm_reduce_grid", int(os.environ["MSM_REDUCE_GRID"]))     # window reduction as row / column tree sums + bit sums (experiment)
 if os.environ.get("MSM_WINDOW"):
     w.set_option("msm_window", int(os.environ["MSM_WINDOW"]))
 sc = w.alloc(n * 32)
