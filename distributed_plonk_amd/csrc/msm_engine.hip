@@ -1214,11 +1214,8 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     hipLaunchKernelGGL(scan_top_kernel, dim3(1), dim3(1024), 0, stream, bsums, nscan_blocks, blk_off + nhist);
     hipLaunchKernelGGL(scan_apply_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums, blk_off);
     {
-        static bool attr_set = false;
-        if (!attr_set) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr_set = true;
-        }
+        static DeviceOnce attr;
+        HIP_TRY(attr.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_scatter_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }));
     }
     hipLaunchKernelGGL(sort_scatter_kernel, dim3(g.nblk, W), dim3(SCATTER_THREADS), (2 * ((size_t)(1u << g.lp) + 1) + 1 + SORT_SLICE) * 4, stream, dig, g,
                        blk_off, tmp);
@@ -1228,11 +1225,8 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     g.stage_cap = lds_fixed + 4096 * 4 <= lds_staged ? (uint32_t)((lds_staged - lds_fixed) / 4) : 0;
     if (ws.sort_stage_cap > 0 && g.stage_cap) g.stage_cap = std::min<uint32_t>(g.stage_cap, std::max<uint32_t>((uint32_t)ws.sort_stage_cap, STAGE_THREADS));   // tests: force the chunked path
     if (g.low_bits >= 8 && g.stage_cap >= STAGE_THREADS && !getenv("PLONK_MSM_NO_STAGED_SORT")) {
-        static bool attr2 = false;
-        if (!attr2) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_partition_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-            attr2 = true;
-        }
+        static DeviceOnce attr2;
+        HIP_TRY(attr2.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_partition_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }));
         hipLaunchKernelGGL(sort_partition_staged_kernel, dim3(g.nreal), dim3(STAGE_THREADS), lds_staged, stream, tmp, g, blk_off, sorted, offsets);
     } else {
         hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets);

@@ -350,13 +350,10 @@ static int ntt_ept() {
 
 template <int LOG_R, int EPT, bool SWZ = false, bool SHOUP = false>
 static hipError_t launch_one_e(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT, SWZ, SHOUP>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    static DeviceOnce attr;
+    hipError_t e = attr.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&ntt_pass_kernel<LOG_R, EPT, SWZ, SHOUP>),
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); });
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL((ntt_pass_kernel<LOG_R, EPT, SWZ, SHOUP>), dim3((uint32_t)grid), dim3(threads), lds, stream, P);
     return hipGetLastError();
 }

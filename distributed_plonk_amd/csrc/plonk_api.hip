@@ -156,7 +156,16 @@ extern "C" int plonk_create(plonk_ctx** out, int device, int curve) {
     HIP_TRY(hipGetDeviceCount(&ndev));
     if (device < 0 || device >= ndev) return plonk_fail(PLONK_ERR_HIP, "plonk_create: device %d not present (%d visible)", device, ndev);
     HIP_TRY(hipSetDevice(device));
-    std::unique_ptr<plonk_ctx> ctx(new plonk_ctx());
+    struct Partial {                // a context that fails half-way gives its stream / events / tables back
+        void operator()(plonk_ctx* c) const {
+            ntt_tables_destroy(c->tables);
+            if (c->ev0) (void)hipEventDestroy(c->ev0);
+            if (c->ev1) (void)hipEventDestroy(c->ev1);
+            if (c->stream) (void)hipStreamDestroy(c->stream);
+            delete c;
+        }
+    };
+    std::unique_ptr<plonk_ctx, Partial> ctx(new plonk_ctx());
     ctx->device = device;
     ctx->curve = curve;
     HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
@@ -278,19 +287,21 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
     ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
         const size_t ab = aff_bytes(ctx->curve);
-        void* d_xy = nullptr;
-        HIP_TRY(hipMalloc(&d_xy, n_bases * ab));
+        struct Staging {            // the (x, y) staging copy is released on every exit, after the stream has finished with it
+            void* p = nullptr; hipStream_t s;
+            ~Staging() { if (p) { (void)hipStreamSynchronize(s); (void)hipFree(p); } }
+        } d_xy;
+        d_xy.s = ctx->stream;
+        HIP_TRY(hipMalloc(&d_xy.p, n_bases * ab));
         if (base_layout == PLONK_BASES_XY) {
-            HIP_TRY(hipMemcpyAsync(d_xy, bases, n_bases * ab, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(d_xy.p, bases, n_bases * ab, hipMemcpyHostToDevice, ctx->stream));
         } else {
             const size_t rb = ark_aff_bytes(ctx->curve) * n_bases;
             if ((rc = ensure_scratch(ctx, rb))) return rc;
             HIP_TRY(hipMemcpyAsync(ctx->d_scratch, bases, rb, hipMemcpyHostToDevice, ctx->stream));
-            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy, ctx->stream))) return rc;
+            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy.p, ctx->stream))) return rc;
         }
-        rc = install_bases(ctx, d_xy, n_bases);
-        (void)hipFree(d_xy);
-        if (rc) return rc;
+        if ((rc = install_bases(ctx, d_xy.p, n_bases))) return rc;
     }
     return PLONK_OK;
 }

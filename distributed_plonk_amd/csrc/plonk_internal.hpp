@@ -28,6 +28,23 @@ typedef FpParams<8> FrParams;
 char* plonk_last_error_buf();
 int plonk_fail(int code, const char* fmt, ...);
 
+// Raised dynamic-LDS limits are a per-DEVICE property of a kernel: a guard remembers the devices it has set the attribute on (one process per GPU is
+// the deployment, but a second worker on another device of the same process must not launch without it).  Two host threads racing on a fresh device
+// both set the same value.
+struct DeviceOnce {
+    uint64_t done = 0;                      // bit d: device d has the attribute (devices >= 64 set it on every call)
+    template <class F> hipError_t run(F&& set) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        const uint64_t bit = dev >= 0 && dev < 64 ? (uint64_t)1 << dev : 0;
+        if (bit && (__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) return hipSuccess;
+        e = set();
+        if (e == hipSuccess && bit) __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+        return e;
+    }
+};
+
 // ----------------------------------------------------------------------------------------------- per-kernel timing
 // HIP-event timing of individual kernel launches on the stream they are launched on (bench.py's
 // roofline leg).  Disabled by default (no events are created).
