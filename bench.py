@@ -18,6 +18,8 @@ N == 1: everything on one GPU.  Default n = 2^24, the size BASELINE.json's metri
 N  > 1: launched by torchrun, one rank per GPU.  Same n (strong scaling): every NTT is the reference's
         2-D transform — row pass, ONE RCCL all-to-all over xGMI, column pass — and every MSM is
         index-sharded with a 96-byte all-gather + host add.
+        Reported beside `value`, never part of it: `other_scheme` (rank-local coset classes, 2 collectives per step) and
+        `polynomial_parallel` (SURVEY §8e's alternative: whole operations per rank, whole SRS on every rank, no data-path collective).
 Only rank 0 prints, one JSON line.  The CPU baseline leg (rank 0, N == 1) times the oracle (a C
 restatement of the reference's arkworks algorithms) on a bounded sample; it is a reported baseline.
 """
@@ -34,6 +36,32 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 N_NTT_SMALL, N_NTT_BIG, N_MSM = 7, 26, 13
+
+
+# ---- polynomial-level parallelism (NTT row: "Alternative for N that fits one GPU: polynomial-level parallelism (25 independent
+# coset-FFTs -> GPUs), zero communication - report both").  The 46 operations of a step are independent objects; a rank takes WHOLE operations.
+# Relative costs measured on one MI355X at n = 2^24 (profiles/r03_bench_2p24_final.json: 8n zero-padded coset FFT 15.2 ms, dense 8n coset iFFT
+# ~19 ms, size-n iNTT 1.9 ms, commitment 21.5 ms); the longest-processing-time rule needs ratios, not absolute times.
+POLY_OP_COST = {"commit": 21.5, "coset_ifft_8n": 19.0, "coset_fft_8n": 15.2, "intt_n": 1.9}
+
+
+def poly_parallel_assignment(n_ranks, nbig=N_NTT_BIG, n_small=N_NTT_SMALL, n_msm=N_MSM, cost=None):
+    """-> (ops_of_rank, load_of_rank): every operation of one step on exactly one rank.  An operation is (kind, index): index = the
+    commitment / polynomial / vector number of the single-GPU step, so the union over ranks is the single-GPU step on the same inputs.
+    Longest-processing-time-first: operations by descending cost, each to the least loaded rank (ties: the lowest rank)."""
+    cost = cost or POLY_OP_COST
+    ops = [("commit", i) for i in range(n_msm)]
+    if nbig:
+        ops += [("coset_ifft_8n", 0)] + [("coset_fft_8n", i) for i in range(nbig - 1)]
+    ops += [("intt_n", i) for i in range(n_small)]
+    ops.sort(key=lambda o: -cost[o[0]])                      # stable: equal-cost operations keep their index order
+    mine = [[] for _ in range(n_ranks)]
+    load = [0.0] * n_ranks
+    for o in ops:
+        g = min(range(n_ranks), key=lambda r: (load[r], r))
+        mine[g].append(o)
+        load[g] += cost[o[0]]
+    return mine, load
 
 
 def parse():
@@ -56,6 +84,8 @@ def parse():
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the compact re-runs at BASELINE.json's configs[1] (2^20 BN254) and configs[3] (2^22 BLS12-381)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    ap.add_argument("--no-poly-parallel", action="store_true",
+                    help="N > 1: skip the polynomial-level-parallel leg (whole operations per rank, no data-path collective; SURVEY §8e's alternative)")
     ap.add_argument("--simulate-ranks", type=int, default=0,
                     help="diagnostic: run rank 0's share of an S-rank job on ONE GPU with a no-op exchange (results are garbage, "
                          "timings are one rank's compute without communication)")
@@ -685,6 +715,190 @@ def main():
         if rank == 0:
             out["other_scheme"] = other_scheme
 
+
+    # ---- N > 1: polynomial-level parallelism ("Alternative for N that fits one GPU: polynomial-level parallelism ... zero
+    # communication - report both"), two steps after one warm-up, outside `value`.  The 46 operations of a step are independent objects:
+    # every rank holds the whole SRS (1 GiB at 2^24; the reference replicates it too, dispatcher.rs:213-216) and takes WHOLE operations of
+    # the single-GPU step (poly_parallel_assignment: longest-processing-time-first) on the single-GPU step's own inputs, so the union over
+    # the ranks IS the single-GPU step.  No data-path collective; the 13 commitments reach rank 0 in one 1.2 KiB all-gather (the varMsm
+    # replies).  --simulate-ranks S: the most loaded rank's share on one GPU (compute only, nothing to simulate away but that gather).
+    if multi and nbig and not args.no_poly_parallel:
+        arm("polynomial_parallel", LEG_BUDGET_S)
+        pp, pbufs, pw = {}, [], []
+        try:
+            from distributed_plonk_amd import fr as _frp
+            fp_ = _frp.FIELDS[args.curve]
+            mine_all, load = poly_parallel_assignment(S, nbig)
+            me_p = max(range(S), key=lambda r_: load[r_]) if sim else rank
+            my_ops = mine_all[me_p]
+            owner = {op: r_ for r_, ops_ in enumerate(mine_all) for op in ops_}
+            c_idx = [i for k_, i in my_ops if k_ == "commit"]
+            f_idx = [i for k_, i in my_ops if k_ == "coset_fft_8n"]
+            s_idx = [i for k_, i in my_ops if k_ == "intt_n"]
+            has_inv = ("coset_ifft_8n", 0) in my_ops
+            pw = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(2)]
+            for k_, v_ in experiment_opts.items():
+                for x in pw:
+                    x.set_option(k_, v_)
+
+            def palloc(nbytes):
+                pbufs.append(pw[0].alloc(nbytes))
+                return pbufs[-1]
+
+            gen_p = fp_.to_limbs(fp_.generator)
+            tiled = 0 if args.bases == "distinct" else min(n, 1 << 11)
+            bases_full = palloc(n * 16 * q64)
+            pw[0].synth_bases(0x5EED, tiled, n, bases_full.ptr)                 # the single-GPU run's SRS, on every rank
+            for x in pw:
+                x.init_dev(bases_full.ptr, n, n, m)
+                x.sync()
+            p_scal, p_poly, p_small = {}, {}, {}
+            for i in c_idx:
+                p_scal[i] = palloc(n * 32)
+                pw[0].synth_fr(0x5CA1A5 + i, p_scal[i].ptr, n)
+            for i in f_idx:
+                p_poly[i] = palloc(poly_len * 32)
+                pw[0].synth_fr(0xC0EFF + i, p_poly[i].ptr, poly_len)
+            for i in s_idx:
+                p_small[i] = [palloc(n * 32), palloc(n * 32)]
+                pw[0].synth_fr(0xD15EA5E + i, p_small[i][0].ptr, n)
+            out_m = palloc(m * 32) if f_idx else None
+            inv_m = [palloc(m * 32), palloc(m * 32)] if has_inv else None
+            if has_inv:
+                pw[0].synth_fr(0xBADC0DE, inv_m[0].ptr, m)
+            pw[0].sync()
+
+            def pstep():
+                for i in s_idx:
+                    pair = p_small[i]
+                    pw[0].ntt_dev(pair[0].ptr, pair[1].ptr, n, True, False)
+                    pair[0], pair[1] = pair[1], pair[0]
+                for i in f_idx:
+                    pw[0].coset_eval_dev(p_poly[i].ptr, poly_len, m, gen_p, out_m.ptr)
+                if has_inv:
+                    pw[0].ntt_dev(inv_m[0].ptr, inv_m[1].ptr, m, True, True)
+                    inv_m[0], inv_m[1] = inv_m[1], inv_m[0]
+                pw[0].sync()
+                parts, errs = {}, []
+
+                def run(lane):
+                    try:
+                        mine_c = c_idx[lane::2]
+                        if mine_c:
+                            pts = pw[lane].commit_many_dev([(p_scal[i].ptr, n) for i in mine_c])
+                            for j, i in enumerate(mine_c):
+                                parts[i] = pts[j]
+                    except BaseException as ex_:     # noqa: BLE001 - re-raised below
+                        errs.append(ex_)
+
+                th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
+                for t_ in th:
+                    t_.start()
+                for t_ in th:
+                    t_.join()
+                if errs:
+                    raise errs[0]
+                table = np.zeros((N_MSM, 3 * q64), dtype=np.uint64)
+                for i, pt in parts.items():
+                    table[i] = pt
+                if sim:
+                    return table
+                flat = table.reshape(-1)
+                gathered = list(w.comm_allgather_host(flat, world)) if transport == "rccl" else gather_points(flat, None, dev)
+                return np.stack([np.asarray(gathered[owner[("commit", i)]]).reshape(N_MSM, 3 * q64)[i] for i in range(N_MSM)])
+
+            def psync():
+                for x in pw:
+                    x.sync()
+                dev_sync()
+                if world > 1:
+                    dist.barrier()
+
+            pstep()
+            psync()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                commits_tab = pstep()
+            psync()
+            dt3 = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt3], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt3 = float(t.item())
+
+            def every_rank(flag):
+                if world == 1:
+                    return bool(flag)
+                t_ = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(t_, op=dist.ReduceOp.MIN)
+                return bool(t_.item())
+
+            pv_ = {}
+            if not args.no_verify:
+                # (a) a forward coset FFT of this rank: sampled outputs against Horner evaluations by an unrelated kernel
+                ok = True
+                if f_idx:
+                    i0 = f_idx[0]
+                    w_m_ = fp_.root_of_unity(m)
+                    pw[0].coset_eval_dev(p_poly[i0].ptr, poly_len, m, gen_p, out_m.ptr)
+                    for k2 in (0, 1, 9, (12345 + i0) % m, m - 1):
+                        x_ = fp_.to_limbs(fp_.generator * pow(w_m_, k2, fp_.p) % fp_.p)
+                        ok &= bool(np.array_equal(out_m.download((1, 4), byte_offset=k2 * 32)[0], pw[0].poly_eval_dev(p_poly[i0].ptr, poly_len, x_)))
+                pv_["coset_fft_samples_vs_poly_eval_on_every_rank"] = every_rank(ok)
+                # (b) a commitment of this rank: the batched launch set against the single-MSM path on the other context
+                ok = True
+                if c_idx:
+                    a_, ai = pw[0].g1_to_affine(commits_tab[c_idx[0]])
+                    b_, bi = pw[1].g1_to_affine(pw[1].commit_dev(p_scal[c_idx[0]].ptr, n))
+                    ok = bool(ai == bi and np.array_equal(a_, b_))
+                pv_["commitment_batched_vs_single_msm_on_every_rank"] = every_rank(ok)
+                # (c) rank 0 recomputes a commitment that ANOTHER rank produced and compares it with what the gather delivered
+                ok = ok_exact = True
+                if not sim and world > 1 and rank == 0:
+                    j = next(i for i in range(N_MSM - 1, -1, -1) if owner[("commit", i)] != 0)
+                    tmp = palloc(n * 32)
+                    pw[0].synth_fr(0x5CA1A5 + j, tmp.ptr, n)
+                    a_, ai = pw[0].g1_to_affine(commits_tab[j])
+                    b_, bi = pw[0].g1_to_affine(pw[0].commit_dev(tmp.ptr, n))
+                    ok = bool(ai == bi and np.array_equal(a_, b_))
+                    # ... and against the exact expected point from the CPU oracle (small MSMs of the aggregated scalars, oracle/checks.py)
+                    from oracle import checks as _chk, oracle as _O
+                    cid_ = _O.CURVE_IDS[args.curve]
+                    sc_ = _O.from_mont(cid_, tmp.download((n, 4)))
+                    want_ = _chk.msm_expected_distinct(cid_, 0x5EED, sc_) if args.bases == "distinct" else _chk.msm_expected_tiled(cid_, 0x5EED, tiled, sc_)
+                    e_, ei = _O.jac_to_affine(cid_, want_)
+                    ok_exact = bool(ai == ei and np.array_equal(a_, e_))
+                    del sc_
+                if not sim and world > 1:
+                    pv_["gathered_commitment_of_another_rank_vs_recomputation_on_rank_0"] = every_rank(ok)
+                    pv_["gathered_commitment_of_another_rank_vs_oracle_exact"] = every_rank(ok_exact)
+            pp = {"scheme": "polynomial_parallel", "steps": 2, "ms_per_step": round(dt3 / 2 * 1e3, 3), "constraints_per_s": round(n / (dt3 / 2), 1),
+                  "ranks": S, "operations_per_rank": [{k_: sum(1 for o in ops_ if o[0] == k_) for k_ in POLY_OP_COST} for ops_ in mine_all],
+                  "modelled_load_ms_per_rank": [round(x, 1) for x in load],
+                  "data_path_collectives_per_step": 0, "result_collectives_per_step": 0 if sim else 1,
+                  "verified": (bool(pv_) and all(pv_.values())) if not args.no_verify else None, "verification": pv_ or None,
+                  "note": "whole operations per rank (longest-processing-time-first over the step's 13 commitments, 25 zero-padded 8n coset FFTs, "
+                          "the 8n coset iFFT and 7 size-n iNTTs), the whole SRS on every rank, the single-GPU step's inputs; the only collective "
+                          "is the 1.2 KiB all-gather that brings the 13 commitments to rank 0"
+                          + (f"; SIMULATED: the most loaded rank ({me_p}) of {S} on one GPU" if sim else "")}
+            if emulated:
+                pp.update(ms_per_step=None, constraints_per_s=None, modelled_load_ms_per_rank=None)
+        except Exception as ex:
+            pp = {"scheme": "polynomial_parallel", "error": repr(ex)}
+        finally:
+            for b in pbufs:
+                try:
+                    b.free()
+                except Exception:       # noqa: BLE001 - best-effort release of a diagnostic leg's buffers
+                    pass
+            for x in pw:
+                try:
+                    x.close()
+                except Exception:       # noqa: BLE001
+                    pass
+        arm(None, 0)
+        if rank == 0:
+            out["polynomial_parallel"] = pp
 
     # ---- N > 1 (and --multi-path): the distributed code path that was just timed, checked on every rank against a single-rank
     # recomputation with the whole-vector path (which tests/ and the N = 1 run check against the oracle): one size-n inverse transform

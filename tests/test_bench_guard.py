@@ -59,3 +59,24 @@ def test_finished_leg_prints_one_complete_line():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert "aborted_optional_leg" not in d and d["other_scheme"]["ms_per_step"] == 1.0
+
+
+def test_polynomial_parallel_assignment_covers_the_step_once_and_balances():
+    """bench.py's polynomial-level-parallel leg (whole operations per rank, no data-path collective): every operation of the
+    step — 13 commitments, 25 forward 8n coset FFTs, the 8n coset iFFT, 7 size-n iNTTs — lands on exactly one rank, and the modelled load
+    of the busiest rank stays within one commitment of the mean (longest-processing-time-first)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    want = {("commit", i) for i in range(13)} | {("coset_fft_8n", i) for i in range(25)} | {("coset_ifft_8n", 0)} | {("intt_n", i) for i in range(7)}
+    for ranks in (1, 2, 3, 4, 8, 16, 64):
+        mine, load = bench.poly_parallel_assignment(ranks)
+        flat = [op for ops in mine for op in ops]
+        assert len(flat) == len(want) == 46 and set(flat) == want, ranks
+        for ops, l in zip(mine, load):
+            assert abs(sum(bench.POLY_OP_COST[k] for k, _ in ops) - l) < 1e-9
+        assert max(load) <= sum(load) / ranks + max(bench.POLY_OP_COST.values()), (ranks, load)
+    _, load8 = bench.poly_parallel_assignment(8)
+    assert sum(load8) / max(load8) > 7.5          # 8 ranks: within 7 % of a perfect split before any measurement
+    # the n-domain-only step (configs[4]) has no 8n transform
+    mine, _ = bench.poly_parallel_assignment(4, nbig=0)
+    assert sorted(op for ops in mine for op in ops) == sorted([("commit", i) for i in range(13)] + [("intt_n", i) for i in range(7)])

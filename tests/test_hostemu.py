@@ -138,9 +138,9 @@ def _bench_dry_run(env, world, port, extra=()):
 @pytest.mark.parametrize("world,extra", [(2, ()), (4, ("--scheme", "classes"))])
 def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     """The N > 1 legs of bench.py have never met more than one real GPU; here every one of them executes: two lanes of distributed transforms
-    with an exchange each, the sharded batched commitments and their point all-gather, the other scheme, the verification leg (distributed
-    iNTT and zero-padded coset FFT against single-rank recomputation on every rank, sharded commitment against all shards on one rank) and
-    the class prover with a sharded key, whose proof rank 0 hands to the verifier."""
+    with an exchange each, the sharded batched commitments and their point all-gather, the other scheme, the polynomial-level-parallel leg (whole operations per
+    rank, no data-path collective), the verification leg (distributed iNTT and zero-padded coset FFT against single-rank recomputation on every rank,
+    sharded commitment against all shards on one rank) and the class prover with a sharded key, whose proof rank 0 hands to the verifier."""
     from conftest import free_port
     d = _bench_dry_run(emu_env, world, free_port(), extra)
     assert d["emulated"] is True and d["value"] is None and d["n_gpus"] == world
@@ -148,6 +148,9 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     assert d["verified"] is True and all(d["verification"].values()), d["verification"]
     assert d.get("aborted_optional_leg") is None
     assert "error" not in (d["other_scheme"] or {}), d["other_scheme"]
+    pp = d["polynomial_parallel"]            # whole operations per rank: checked on every rank, one gathered commitment against the oracle
+    assert pp["verified"] is True and pp["ranks"] == world and pp["data_path_collectives_per_step"] == 0, pp
+    assert sum(sum(r.values()) for r in pp["operations_per_rank"]) == 7 + 26 + 13, pp
     cp = d["next_rows"]["class_prover"]
     assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
 
