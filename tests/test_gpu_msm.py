@@ -90,6 +90,47 @@ def test_commit_and_round1(gpu_workers, oracle, curve, cid):
     assert _affine_eq(w, oracle, cid, got, cm)
 
 
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n", [5, 10])
+def test_circuit_shaped_commitments(gpu_workers, oracle, curve, cid, log_n):
+    """SURVEY §8d's circuit-shaped inputs: the prover's commit key is n + 3 powers padded with G1Affine::zero() — arkworks' (0, 1, true) —
+    to a multiple of 32 (dispatcher.rs:541-542, dispatcher2.rs:207-208), shipped as raw `[G1Affine]` memory (utils.rs:27-33), and
+    commit_polynomial zero-pads n, n + 2 or n + 3 coefficients to that length (dispatcher.rs:1048-1050).  Whole-key commitments of each
+    length, and the sharded form of dispatcher2.rs:870-890 (S contiguous ranges of the PADDED key; the last ranges see only zero scalars
+    and infinite bases), against the oracle."""
+    from distributed_plonk_amd import _ffi
+    w = gpu_workers(curve)
+    q = w.q64
+    n = 1 << log_n
+    real = n + 3
+    L = ((real + 31) >> 5) << 5
+    bases = oracle.gen_bases(cid, 41 + log_n, real, L)         # L distinct-seeded points; the tail is overwritten by infinity below
+    inf = np.zeros(L, dtype=np.uint8)
+    inf[real:] = 1
+    stride = 16 * q + 8
+    raw = np.zeros((L, stride), dtype=np.uint8)
+    raw[:, :16 * q] = bases.view(np.uint8).reshape(L, 16 * q)
+    one = oracle.field_const(cid, 1, 1).view(np.uint8)
+    raw[real:, :8 * q] = 0
+    raw[real:, 8 * q:16 * q] = one
+    raw[real:, 16 * q] = 1
+    w.init(raw, n, 8 * n, layout=_ffi.PLONK_BASES_ARK)
+    for k, ln in enumerate((n, n + 2, n + 3)):                  # selector / wire / permutation polynomial lengths
+        coeffs = oracle.rand_fr(cid, 50 + k, ln)
+        want = oracle.commit_polynomial(cid, bases, coeffs, inf, threads=4)
+        assert _affine_eq(w, oracle, cid, w.commit(coeffs), want), ln
+        # the reference's sharded form: scalars = into_repr(coeffs) zero-padded to the key length, S ranges [i*L/S, (i+1)*L/S)
+        sc = np.zeros((L, 4), dtype=np.uint64)
+        sc[:ln] = oracle.from_mont(cid, coeffs)
+        for S in (1, 2, 8):
+            acc = None
+            for i in range(S):
+                lo, hi = i * L // S, (i + 1) * L // S
+                part = w.var_msm(MsmWorkload(lo, hi), sc[lo:hi])
+                acc = part if acc is None else w.g1_add(acc, part)
+            assert _affine_eq(w, oracle, cid, acc, want), (ln, S)
+
+
 def test_synth_inputs_match_oracle(gpu_workers, oracle):
     for curve, cid in [("bn254", 0), ("bls12_381", 1)]:
         w = gpu_workers(curve)
