@@ -319,7 +319,7 @@ __global__ void __launch_bounds__(64) quotient_gen_inv_kernel(Fr* __restrict__ o
     for (int k = QINV_CH - 1; k >= 0; k--) {
         const F29 r = f29_mul(inv, pre[k], fp);            // 1 / d[k]
         inv = f29_mul(d[k], inv, fp);
-        store_fr(out + base + k, f29_to_sat(f29_canon(r, fp)));
+        if (base + k < m) store_fr(out + base + k, f29_to_sat(f29_canon(r, fp)));     // a table shorter than one lane's chunk (a coset class of a tiny domain) ends inside it
     }
 }
 

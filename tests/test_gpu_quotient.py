@@ -82,3 +82,27 @@ def test_quotient_kernel_variants_agree_with_oracle(gpu_workers, oracle, curve, 
     finally:
         w.set_option("quotient_fuse", 0)
     buf.free(); out.free()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,G", [(1, 8), (1, 4), (2, 8), (3, 8), (2, 2), (4, 8)])
+def test_quotient_coset_class_of_a_tiny_domain(gpu_workers, oracle, curve, cid, log_n, G):
+    """One coset class (points s + G*k) of domains so small that the class holds fewer points (2 ... 16) than one lane of the
+    1/(x - 1) table generator handles (16): found by tools/fuzz_abi.py's `quotient` operation under AddressSanitizer — the generator
+    stored its whole chunk, past the end of the m/G-entry table (regression test; on the host emulation's ASan build this is an error,
+    on the GPU the values must match the oracle for every class)."""
+    w = gpu_workers(curve)
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    vecs = oracle.rand_fr(cid, 6100 + 8 * log_n + G, 25 * m).reshape(25, m, 4)
+    ch = oracle.rand_fr(cid, 80, 8)
+    want = oracle.quotient_evals(cid, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8])
+    mL = m // G
+    out = w.alloc(mL * 32)
+    for s in range(G):
+        buf = w.alloc(25 * mL * 32).upload(np.ascontiguousarray(vecs[:, s::G]))
+        ptr = [buf.ptr + j * mL * 32 for j in range(25)]
+        w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr, class_stride=G, class_offset=s)
+        assert np.array_equal(out.download((mL, 4)), want[s::G]), s
+        buf.free()
+    out.free()

@@ -288,7 +288,38 @@ class Fuzz:
                 x.close()
         return np.array_equal(got, self.O.ntt(self.cid, v, inv, coset, threads=4)), dict(log_n=log_n, S=S, inv=inv, coset=coset)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft"]
+    def op_quotient(self):
+        """dispatcher2.rs:362-504: the quotient's coset evaluations — every kernel formulation behind `quotient_fuse`, whole domain or one
+        coset class (class_stride G | 8: the vectors hold the points class_offset + G*k), sparse / extreme inputs."""
+        log_n = int(self.rs.randint(1, max(2, min(self.max_log - 3, 8) + 1)))
+        n, m = 1 << log_n, 8 << log_n
+        self.w.init(None, n, m)
+        self.n_bases = 0                                              # the SRS is gone: the next MSM re-installs one
+        vecs = self.fr(25 * m).reshape(25, m, 4)
+        pick = self.rs.rand()
+        if pick < 0.3:                                                # real selector vectors are sparse
+            vecs[0:13, ::int(self.rs.randint(2, 6))] = 0
+        elif pick < 0.45:                                             # the largest lazy sums the bound bookkeeping allows
+            vecs[:, : m // 2] = self.f.to_limbs(self.f.p - 1)
+        ch = self.fr(8)
+        variant = int(self.rs.randint(0, 6))
+        G = int(self.rs.choice([1, 1, 2, 4, 8]))
+        off = int(self.rs.randint(0, G))
+        want = self.O.quotient_evals(self.cid, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8], threads=4)
+        mine = np.ascontiguousarray(vecs[:, off::G]) if G > 1 else vecs
+        mL = m // G
+        buf, out = self.up(mine), self.w.alloc(mL * 32)
+        ptr = [buf.ptr + j * mL * 32 for j in range(25)]
+        try:
+            self.w.set_option("quotient_fuse", variant)
+            self.w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr, class_stride=G, class_offset=off)
+            got = out.download((mL, 4))
+        finally:
+            self.w.set_option("quotient_fuse", 0)
+            buf.free(); out.free()
+        return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
+
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient"]
 
     def close(self):
         self.w.close()
