@@ -288,6 +288,75 @@ class Fuzz:
                 x.close()
         return np.array_equal(got, self.O.ntt(self.cid, v, inv, coset, threads=4)), dict(log_n=log_n, S=S, inv=inv, coset=coset)
 
+    def op_round1(self):
+        """worker.rs:383-408: evaluations -> ifft -> + blinders * Z_H -> commitment over the whole SRS; the polynomial stays in the context."""
+        log_n = int(self.rs.randint(1, min(self.max_log, 11) + 1))
+        n = 1 << log_n
+        n_b = n + 2 + int(self.rs.randint(0, 40))
+        unique = n_b if self.rs.rand() < 0.5 else int(self.rs.randint(1, min(n_b, 64) + 1))
+        bases = self.O.gen_bases(self.cid, self.seed(), unique, n_b)
+        inf = np.zeros(n_b, dtype=np.uint8)
+        if self.rs.rand() < 0.5:
+            i = int(self.rs.randint(0, n_b))
+            bases[i] = 0
+            inf[i] = 1
+        self.w.init(bases, n, 8 * n)
+        self.n_bases = 0                                              # the next MSM operation installs its own SRS
+        evals, bl = self.fr(n), self.fr(2)
+        poly, cm = self.O.round1(self.cid, bases, evals, bl, inf, threads=4)
+        got = self.w.round1(evals, bl)
+        ok = np.array_equal(self.w.get_wire(n + 2), poly)
+        g, gi = self.w.g1_to_affine(got)
+        o, oi = self.O.jac_to_affine(self.cid, cm)
+        return ok and gi == oi and np.array_equal(g, o), dict(log_n=log_n, n_bases=n_b, unique=unique)
+
+    def op_compact_rows_fft(self):
+        """plonk_fft1_dev_compact: the distributed forward transform of a ZERO-PADDED vector from the leading coefficients of every decimated row
+        (dispatcher2.rs:746-766), random domain, rank count, polynomial length (from a handful of coefficients to nearly dense), plain / coset."""
+        from distributed_plonk_amd.dispatcher import Dispatcher, make_fft_workloads, split_rc
+        from distributed_plonk_amd.worker import PlonkWorker
+        log_n = int(self.rs.randint(2, min(self.max_log, 13) + 1))
+        N = 1 << log_n
+        r, c = split_rc(N)
+        S = int(self.rs.choice([1, 2, 4, 8]))
+        while r % S or c % S:
+            S //= 2
+        pick = self.rs.rand()
+        if pick < 0.4:
+            length = max(1, N // 8 + int(self.rs.randint(0, 4)))                # the prover's n, n + 2, n + 3 coefficients on the 8n domain
+        elif pick < 0.7:
+            length = int(self.rs.randint(1, N + 1))
+        else:                                                                    # around the class boundaries N / 2^k
+            length = max(1, min(N, (N >> int(self.rs.randint(0, min(log_n, 5) + 1))) + int(self.rs.randint(-3, 4))))
+        row_len = min(c, (length + r - 1) // r)
+        coset = bool(self.rs.randint(0, 2))
+        coeffs = self.fr(length)
+        v = np.zeros((N, 4), dtype=np.uint64)
+        v[:length] = coeffs
+        t = np.ascontiguousarray(v.reshape(c, r, 4).transpose(1, 0, 2))          # t[b][a] = v[a*r + b]
+        ws = [PlonkWorker(me=i, device=0, curve=self.curve) for i in range(S)]
+        bufs = []
+        try:
+            d = Dispatcher(ws)
+            d.init(None, N, 0)
+            wl = make_fft_workloads(N, S)
+            for i, x in enumerate(ws):
+                x.fft_init(77, wl, False, False, coset)
+                rows = np.ascontiguousarray(t[wl[i].row_start:wl[i].row_end, :row_len])
+                bufs.append(x.alloc(max(rows.nbytes, 32)).upload(rows))
+                x.fft1_dev_compact(77, bufs[-1].ptr, row_len)
+            d._fft2_prepare_all(77)
+            u = np.empty((c, r, 4), dtype=np.uint64)
+            for i, x in enumerate(ws):
+                u[wl[i].col_start:wl[i].col_end] = x.fft2(77, r)
+            got = np.ascontiguousarray(u.transpose(1, 0, 2)).reshape(-1, 4)
+        finally:
+            for b in bufs:
+                b.free()
+            for x in ws:
+                x.close()
+        return np.array_equal(got, self.O.ntt(self.cid, v, False, coset, threads=4)), dict(log_n=log_n, S=S, length=length, coset=coset)
+
     def op_quotient(self):
         """dispatcher2.rs:362-504: the quotient's coset evaluations — every kernel formulation behind `quotient_fuse`, whole domain or one
         coset class (class_stride G | 8: the vectors hold the points class_offset + G*k), sparse / extreme inputs."""
@@ -319,7 +388,7 @@ class Fuzz:
             buf.free(); out.free()
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient"]
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1"]
 
     def close(self):
         self.w.close()
