@@ -650,14 +650,19 @@ struct BlindParams {
 // poly[i] -= b_i ; poly[n+i] += b_i   ((sum b_i X^i)(X^n - 1) + poly), dispatcher2.rs:311-312,347-348 / worker.rs:400-401
 __global__ void blind_kernel(Fr* poly, uint64_t n, const BlindParams B, const FrParams P) {
     const int i = threadIdx.x;
-    if (i < B.k) {
-        store_fr(poly + i, fp_sub(load_fr(poly + i), B.b[i], P));
-        store_fr(poly + n + i, fp_add(load_fr(poly + n + i), B.b[i], P));
+    if (n >= (uint64_t)B.k) {                  // the two index ranges are disjoint: one lane per blinder
+        if (i < B.k) {
+            store_fr(poly + i, fp_sub(load_fr(poly + i), B.b[i], P));
+            store_fr(poly + n + i, fp_add(load_fr(poly + n + i), B.b[i], P));
+        }
+    } else if (i == 0) {                       // a domain smaller than the mask (n = 2, three blinders): [0, k) and [n, n + k) overlap, one lane does all
+        for (int j = 0; j < B.k; j++) store_fr(poly + j, fp_sub(load_fr(poly + j), B.b[j], P));
+        for (int j = 0; j < B.k; j++) store_fr(poly + n + j, fp_add(load_fr(poly + n + j), B.b[j], P));
     }
 }
 int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, size_t k, hipStream_t stream) {
     if (k == 0) return PLONK_OK;
-    if (k > 4 || n < k) return plonk_fail(PLONK_ERR_ARG, "blind: %zu blinders for n = %zu (1..4)", k, n);
+    if (k > 4 || n == 0) return plonk_fail(PLONK_ERR_ARG, "blind: %zu blinders for n = %zu (1..4 blinders, n >= 1)", k, n);
     BlindParams B;
     memset(&B, 0, sizeof B);
     for (size_t i = 0; i < k; i++) {

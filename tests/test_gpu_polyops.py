@@ -206,5 +206,14 @@ def test_poly_lincomb_and_blind(gpu_workers, oracle, curve, cid):
         w.blind_dev(d.ptr, n, bl)
         assert np.array_equal(d.download((n + k, 4)), oracle.blind(cid, polys[0], n, bl))
         d.free()
+    # a domain smaller than the mask (n = 1, 2 with three blinders): the two index ranges overlap (found by tools/fuzz_abi.py's prove_verify)
+    for n_small, k in ((2, 3), (1, 3), (1, 2), (2, 2), (3, 3)):
+        base = np.zeros((n_small + k, 4), dtype=np.uint64)
+        base[:n_small] = polys[0][:n_small]
+        bl = oracle.rand_fr(cid, 650 + 8 * n_small + k, k)
+        d = w.alloc((n_small + k) * 32).upload(base)
+        w.blind_dev(d.ptr, n_small, bl)
+        assert np.array_equal(d.download((n_small + k, 4)), oracle.blind(cid, polys[0][:n_small], n_small, bl)), (n_small, k)
+        d.free()
     for b in bufs + [out]:
         b.free()

@@ -310,6 +310,51 @@ class Fuzz:
         o, oi = self.O.jac_to_affine(self.cid, cm)
         return ok and gi == oi and np.array_equal(g, o), dict(log_n=log_n, n_bases=n_b, unique=unique)
 
+    def op_prove_verify(self):
+        """The reference's end-to-end test (dispatcher2.rs:1273-1295: prove, then verify) on a random instance: a satisfied circuit and a
+        trapdoor SRS generated on the device, the five rounds with the merlin transcript and the quotient-degree check on, both quotient
+        routes, key cosets cached or not; the proof must be accepted by oracle/verifier_ref.py, which must also have drawn the prover's
+        challenges, and a flipped evaluation must be rejected."""
+        from distributed_plonk_amd.prover import Prover
+        from distributed_plonk_amd.synthetic import SyntheticInstance
+        from distributed_plonk_amd.transcript import PlonkTranscript
+        from oracle import bigint_ref as B, verifier_ref as V
+        # n >= 4: the quotient's numerator has degree 6n + 7, which the reference's 8n-point domain only holds from n = 4 on
+        log_n = int(self.rs.randint(2, min(self.max_log, 7) + 1))
+        mode = "classes6" if (log_n >= 4 and self.rs.rand() < 0.5) else "coset8n"
+        cache = bool(self.rs.randint(0, 2))
+        n_in = int(self.rs.randint(0, min(1 << log_n, 6) + 1))
+        tau = int.from_bytes(self.rs.bytes(31), "little") % self.f.p or 7
+        seed = self.seed()
+        inst = SyntheticInstance(self.w, log_n, seed=seed, num_inputs=n_in, tau=tau)
+        self.n_bases = 0                                              # the instance installed its own commit key
+        pv = Prover(self.w, log_n, quotient_mode=mode, cache_key_cosets=cache)
+        info = dict(log_n=log_n, mode=mode, cache=cache, num_inputs=n_in, seed=seed)
+        try:
+            pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+            pub = inst.public_inputs()
+            fs = pv.fiat_shamir(pub)
+            # blinders: plain random values (a zero blinder lowers the quotient's degree and fails the reference's degree check too)
+            bl = dict(wires=self.O.rand_fr(self.cid, self.seed(), 10).reshape(5, 2, 4), perm=self.O.rand_fr(self.cid, self.seed(), 3))
+            proof = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=True)
+            vk = pv.verifying_key()
+            cv = B.CURVES[self.curve]
+            out = V.verify(cv, vk, pub, proof, tau, transcript=PlonkTranscript(self.curve))
+            ok = all(np.array_equal(out["challenges"][k_], fs.drawn[k_]) for k_ in ("beta", "gamma", "alpha", "zeta", "v"))
+            bad = [x.copy() for x in proof["wires_evals"]]
+            bad[int(self.rs.randint(0, 5))][0] ^= np.uint64(1)
+            try:
+                V.verify(cv, vk, pub, dict(proof, wires_evals=bad), tau, transcript=PlonkTranscript(self.curve))
+                ok = False
+            except V.VerificationError:
+                pass
+        except V.VerificationError as ex:
+            ok, info["rejected"] = False, str(ex)[:200]
+        finally:
+            pv.close()
+            inst.close()
+        return ok, info
+
     def op_compact_rows_fft(self):
         """plonk_fft1_dev_compact: the distributed forward transform of a ZERO-PADDED vector from the leading coefficients of every decimated row
         (dispatcher2.rs:746-766), random domain, rank count, polynomial length (from a handful of coefficients to nearly dense), plain / coset."""
@@ -388,7 +433,7 @@ class Fuzz:
             buf.free(); out.free()
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1"]
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify"]
 
     def close(self):
         self.w.close()
