@@ -355,6 +355,49 @@ class Fuzz:
             inst.close()
         return ok, info
 
+    def op_class_prove(self):
+        """The multi-rank prover by coset classes (class_prover.py) as G threads sharing the device: random size, rank count, whole or
+        sharded commit key; every rank must produce the oracle prover's proof (commitments, evaluations, quotient / linearisation / batch
+        polynomials) for the same circuit, blinders and challenges."""
+        from distributed_plonk_amd.class_prover import ClassProver, key_shard_range, run_local_ranks
+        from oracle import prover_ref as P
+        log_n = int(self.rs.randint(3, min(self.max_log, 7) + 1))
+        n = 1 << log_n
+        G = int(self.rs.choice([2, 4, 8]))
+        sharded = bool(self.rs.randint(0, 2))
+        seed = self.seed()
+        circ = P.make_circuit(self.cid, log_n, seed=seed)
+        ck, inf = P.make_ck(self.cid, n, seed=seed + 1, unique=min(64, n))
+        bl = dict(wires=self.O.rand_fr(self.cid, seed + 2, 10).reshape(5, 2, 4), perm=self.O.rand_fr(self.cid, seed + 3, 3))
+        ch = {k: self.O.rand_fr(self.cid, seed + 10 + i, 1)[0] for i, k in enumerate(("beta", "gamma", "alpha", "zeta", "v"))}
+        K = len(ck)
+
+        def rank_main(comm, w):
+            klo, khi = key_shard_range(K, comm.rank, comm.size) if sharded else (0, K)
+            w.init(ck[klo:khi], n, 8 * n)
+            pv = ClassProver(w, log_n, comm, key_range=(klo, khi) if sharded else None)
+            try:
+                pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+                return pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+            finally:
+                pv.close()
+
+        results = run_local_ranks(G, rank_main, curve=self.curve)
+        want = P.prove_rounds(self.cid, log_n, ck, inf, circ, bl, ch, threads=4)
+        same = lambda a, b: a[1] == b[1] and np.array_equal(a[0], b[0])
+        ok = True
+        for got in results:
+            for key in ("wires_poly_comms", "split_quot_poly_comms"):
+                ok &= len(got[key]) == 5 and all(same(g, x) for g, x in zip(got[key], want[key]))
+            for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+                ok &= same(got[key], want[key])
+            for key in ("wires_evals", "wire_sigma_evals"):
+                ok &= bool(np.array_equal(np.stack(got[key]), np.stack(want[key])))
+            ok &= bool(np.array_equal(got["perm_next_eval"], want["perm_next_eval"]))
+            for key in ("quot_poly", "lin_poly", "batch_poly"):
+                ok &= bool(np.array_equal(got["_debug"][key], want[key]))
+        return bool(ok), dict(log_n=log_n, G=G, sharded=sharded, seed=seed)
+
     def op_compact_rows_fft(self):
         """plonk_fft1_dev_compact: the distributed forward transform of a ZERO-PADDED vector from the leading coefficients of every decimated row
         (dispatcher2.rs:746-766), random domain, rank count, polynomial length (from a handful of coefficients to nearly dense), plain / coset."""
@@ -433,7 +476,7 @@ class Fuzz:
             buf.free(); out.free()
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify"]
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove"]
 
     def close(self):
         self.w.close()
