@@ -584,18 +584,27 @@ def main():
         roof["msm_accumulate_kernel"] = {"bytes_per_launch": msm_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"]}
     # PMC-derived numbers (HBM traffic, VALU instruction counts) come from separate rocprofv3 counter runs of this same command,
     # committed as profiles/pmc_current.json (tools/pmc_collect.py).  They are quoted ONLY when that file was collected from the
-    # kernel sources this library was built from (source hash) and for this workload; otherwise the fields stay null.
+    # kernel sources this library was built from (source hash) — or, per kernel, from byte-identical machine code — and for this
+    # workload; otherwise the fields stay null.
     pmc, pmc_note = {}, None
     try:
         from distributed_plonk_amd.build import source_hash
         with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
             db = json.load(f)
-        if db.get("source_hash") != source_hash():
-            pmc_note = f"profiles/pmc_current.json was collected from other kernel sources ({db.get('source_hash')} != {source_hash()}): not quoted"
-        elif db.get("config") != f"2^{args.log_n}@{args.curve}@{world}" or args.dense_coset:
+        if db.get("config") != f"2^{args.log_n}@{args.curve}@{world}" or args.dense_coset:
             pmc_note = f"profiles/pmc_current.json holds {db.get('config')} (padded coset inputs): not this workload"
-        else:
+        elif db.get("source_hash") == source_hash():
             pmc = db["kernels"]
+        else:
+            # other sources than the collection's: a kernel's numbers are still quoted when its MACHINE CODE (every instantiation, hashed
+            # from the objects: distributed_plonk_amd/codehash.py) is byte-identical to what the counters ran — an edit elsewhere
+            # (an error path of the C ABI, a new kernel beside it) does not touch it
+            from distributed_plonk_amd.build import code_hashes
+            now, then = code_hashes(), db.get("code_hashes") or {}
+            same = sorted(k_ for k_ in then if now.get(k_) == then[k_])
+            pmc = {k_: v_ for k_, v_ in db["kernels"].items() if k_.split("<")[0] in same}
+            pmc_note = (f"profiles/pmc_current.json was collected from other kernel sources ({db.get('source_hash')} != {source_hash()}); quoted only for "
+                        f"kernels whose gfx950 machine code is byte-identical to the collection's: {', '.join(k_ for k_ in same if k_ in db['kernels']) or 'none'}")
     except Exception as ex:
         pmc_note = f"no PMC profile: {ex!r}"
 
@@ -610,7 +619,7 @@ def main():
         insts = ent["SQ_INSTS_VALU"]
         issue_ms = insts * 4.5 / (1024 * 2.4e9) * 1e3
         return {"insts_per_launch": round(insts), "issue_ms_at_4.5clk": round(issue_ms, 3), "frac_of_launch": round(issue_ms / avg_ms, 3),
-                "source": "profiles/pmc_current.json (source-hash checked), profiles/r01_valu_microbench.txt"}
+                "source": "profiles/pmc_current.json (source- or machine-code-hash checked), profiles/r01_valu_microbench.txt"}
 
     def roofline_entry(name):
         r = roof[name]

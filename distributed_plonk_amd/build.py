@@ -91,7 +91,27 @@ def build(force=False, verbose=True):
         subprocess.check_call([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-ldl", "-o", OUT])      # librccl is dlopen'ed (comm_rccl.hip)
         if verbose:
             print("built", OUT)
+    code_hashes(refresh=True)
     return OUT
+
+
+CODE_HASHES = os.path.join(LIBDIR, "kernel_code_hashes.json")
+
+
+def code_hashes(refresh=False) -> dict:
+    """{kernel base name: hash of its gfx950 machine code, all instantiations} of the objects this library was linked from
+    (codehash.py); written beside the .so at build time so that it travels with it.  {} when neither the file nor the objects exist."""
+    import json
+    from . import codehash
+    try:
+        objs = [os.path.join(OBJDIR, f) for f in os.listdir(OBJDIR) if f.endswith(".o")] if os.path.isdir(OBJDIR) else []
+        stale = not os.path.exists(CODE_HASHES) or any(os.path.getmtime(o) > os.path.getmtime(CODE_HASHES) for o in objs)
+        if objs and (refresh or stale):
+            return codehash.write_hashes(OBJDIR, CODE_HASHES)
+        with open(CODE_HASHES) as f:       # on the GPU box the objects stay behind (.gpurunignore): the file written at build time speaks for them
+            return json.load(f)
+    except Exception:       # noqa: BLE001 - a diagnostic: bench.py then falls back to the all-sources hash
+        return {}
 
 
 if __name__ == "__main__":

@@ -129,3 +129,40 @@ def test_bench_and_entry_contract_files_exist():
     for f in ["bench.py", "__graft_entry__.py", "DESIGN.md", "INTEGRATION.md", "include/plonk_hip.h", "oracle/plonk_oracle.c", "ffi/plonk_hip.rs",
               "tools/preflight_multi.sh"]:
         assert os.path.exists(os.path.join(ROOT, f)), f
+
+
+def test_kernel_machine_code_hashes():
+    """distributed_plonk_amd/codehash.py: the per-kernel hashes of the gfx950 machine code that let bench.py keep quoting PMC-derived
+    numbers (profiles/pmc_current.json) for a kernel whose code did not change while other sources did.  Needs the objects of the
+    in-tree build (`__graft_entry__.build()`); no GPU."""
+    import hashlib
+    import json
+    import re
+    from distributed_plonk_amd import build, codehash
+    objdir = build.OBJDIR
+    if not (os.path.isdir(objdir) and os.path.exists(os.path.join(objdir, "ntt_engine.o"))):
+        pytest.skip("the HIP library has not been built in this tree")
+    hashes = codehash.kernel_code_hashes(objdir)
+    # every kernel the sources declare is a FUNC symbol of some code object
+    declared = set()
+    for f in os.listdir(build.CSRC):
+        if f.endswith((".hip", ".hpp")):
+            txt = open(os.path.join(build.CSRC, f)).read()
+            declared |= set(re.findall(r"__global__\s+void\s+(?:__launch_bounds__\([^)]*\)\s+)?(\w+)\s*\(", txt))
+    declared -= {"ntt_steps0123_xlane", "__attribute__"}      # (a kernel declared with an attribute list before its name: its name is still found at another site or is checked by the GPU tests)
+    missing = sorted(k for k in declared if k not in hashes)
+    assert len(declared) > 40 and not missing, missing
+    # the hash is over the code bytes: one flipped byte in one instantiation changes that kernel's hash and no other
+    co = bytearray(codehash.device_code_object(os.path.join(objdir, "ntt_engine.o")))
+    syms = codehash.kernel_symbols(bytes(co))
+    name = next(k for k in sorted(syms) if codehash.base_name(k) == "ntt_pass_kernel")
+    at, _size = codehash.kernel_symbol_ranges(bytes(co))[name]
+    co[at + 8] ^= 1
+    syms2 = codehash.kernel_symbols(bytes(co))
+    changed = [k for k in syms if hashlib.sha256(syms[k]).digest() != hashlib.sha256(syms2[k]).digest()]
+    assert changed == [name]
+    # what build() wrote beside the library is what the objects say, and the committed PMC file names kernels that exist
+    if os.path.exists(build.CODE_HASHES) and os.path.getmtime(build.CODE_HASHES) >= os.path.getmtime(os.path.join(objdir, "ntt_engine.o")):
+        assert json.load(open(build.CODE_HASHES)) == hashes
+    db = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
+    assert set(db.get("code_hashes", {})) <= set(hashes)

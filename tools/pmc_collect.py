@@ -49,7 +49,8 @@ def main():
             if c in row:
                 ent[c] = round(row[c])
         kernels[name] = ent
-    out = {"source_hash": source_hash(), "config": f"2^{log_n}@{curve}@{world}", "kernels": kernels,
+    from distributed_plonk_amd.build import code_hashes
+    out = {"source_hash": source_hash(), "code_hashes": code_hashes(), "config": f"2^{log_n}@{curve}@{world}", "kernels": kernels,
            "how": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-next-rows "
                   "--no-other-configs --no-verify ; averages per launch"}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
