@@ -145,9 +145,18 @@ def plan(args, S):
         hbm = (2 * 2 * (n // S) * 32 + 2 * 2 * (me_ // S) * 32           # reference2d lanes
                + (2 * n * 32 + (n + 3) * 32 + 2 * (me_ // S) * 32 + 3 * me_ * 32 if me_ else 0)     # classes: bn, poly, out/mine, contrib/recv/quot
                + 2 * (n // S) * limb_bytes + (n // S) * q_bytes + (me_ // S) * 32 * 2 + 2 * msm_ws + 3 * (n // S) * 32)
+    pp = None
+    if S > 1 and not args.n_domain_only:
+        # the polynomial-level-parallel leg: whole operations per rank, whole SRS (raw + limb form on two contexts) on every rank
+        mine_, load_ = poly_parallel_assignment(S)
+        worst = max(sum(1 for o in ops_ if o[0] == "commit") * n * 32 + sum(1 for o in ops_ if o[0] == "coset_fft_8n") * (n + 3) * 32
+                    + sum(1 for o in ops_ if o[0] == "intt_n") * 2 * n * 32 + (2 * m * 32 if ("coset_ifft_8n", 0) in ops_ else 0) for ops_ in mine_)
+        pp = {"operations_per_rank": [{k_: sum(1 for o in ops_ if o[0] == k_) for k_ in POLY_OP_COST} for ops_ in mine_],
+              "modelled_load_ms_per_rank_at_2p24": [round(x, 1) for x in load_],
+              "approx_hbm_GiB_per_rank": round((worst + n * q_bytes + 2 * n * limb_bytes + 3 * m * 32 + 2 * 3 * 4 * 15 * min(n, 1 << 26)) / GiB, 1)}
     return {"n": n, "m": m, "ranks": S, "scheme": args.scheme if S > 1 else "single", "transforms": sizes,
             "msm_points_per_rank": n // S, "class_points_per_rank": m // S, "approx_hbm_GiB_per_rank_headline": round(hbm / GiB, 1),
-            "problems": problems, "ok": not problems}
+            "polynomial_parallel": pp, "problems": problems, "ok": not problems}
 
 
 class ResultLine:
