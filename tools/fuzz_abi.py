@@ -169,6 +169,50 @@ class Fuzz:
         return (self.affine_eq(jac, self.O.msm(self.cid, self.bases[start:start + n], sc, inf=self.inf[start:start + n], threads=4)),
                 dict(n=n, start=start, window=window, persist=persist, grid=grid))
 
+    def op_msm_table(self):
+        """The fixed-base window table forced on (msm_precompute = 2) with a random window width and bucket sets per scalar, a fresh SRS with
+        repeated / infinite bases: a sub-range MSM and a batched round of ragged commitments against the oracle; the table is switched off again."""
+        from distributed_plonk_amd._ffi import MsmWorkload
+        n_b = int(self.rs.randint(2, 1 << min(self.max_log, 11)) + 1)
+        unique = n_b if self.rs.rand() < 0.5 else int(self.rs.randint(1, min(n_b, 64) + 1))
+        bases = self.O.gen_bases(self.cid, self.seed(), unique, n_b)
+        inf = np.zeros(n_b, dtype=np.uint8)
+        if self.rs.rand() < 0.5:
+            i = int(self.rs.randint(0, n_b))
+            bases[i] = 0
+            inf[i] = 1
+        tc = int(self.rs.choice([0, 0, 4, 7, 9, 12]))
+        ts = int(self.rs.choice([0, 1, 2, 3])) if tc else 0
+        info = dict(n_bases=n_b, unique=unique, table_c=tc, table_sets=ts)
+        try:
+            self.w.set_option("msm_precompute", 2)
+            self.w.set_option("msm_table_c", tc)
+            self.w.set_option("msm_table_sets", ts)
+            self.w.init(bases, 0, 0)
+            lo = int(self.rs.randint(0, n_b))
+            hi = int(self.rs.randint(lo, n_b)) + 1
+            sc = self.scalars(hi - lo)
+            ok = self.affine_eq(self.w.var_msm(MsmWorkload(lo, hi), sc), self.O.msm(self.cid, bases[lo:hi], sc, inf=inf[lo:hi], threads=4))
+            info.update(range=(lo, hi))
+            if ok:
+                K = int(self.rs.randint(1, 5))
+                lens = [int(self.rs.randint(0, n_b + 1)) for _ in range(K)]
+                polys = [self.fr(ln) for ln in lens]
+                bufs = [self.up(p_) for p_ in polys]
+                jacs = self.w.commit_many_dev([(b.ptr, ln) for b, ln in zip(bufs, lens)])
+                for j, (p_, ln) in enumerate(zip(polys, lens)):
+                    want = self.O.commit_polynomial(self.cid, bases[:max(ln, 1)], p_ if ln else self.f.vec_to_limbs([0]), inf=inf[:max(ln, 1)], threads=4)
+                    ok = ok and self.affine_eq(jacs[j], want)
+                for b in bufs:
+                    b.free()
+                info.update(lens=lens)
+        finally:
+            self.w.set_option("msm_precompute", 0)
+            self.w.set_option("msm_table_c", 0)
+            self.w.set_option("msm_table_sets", 0)
+            self.n_bases = 0                                          # the next MSM operation installs a plain SRS
+        return ok, info
+
     def op_commit_many(self):
         K = int(self.rs.randint(1, 7))
         n = int(self.rs.randint(1, 1 << min(self.max_log, 11)) + 1)
@@ -476,7 +520,7 @@ class Fuzz:
             buf.free(); out.free()
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove"]
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove", "msm_table"]
 
     def close(self):
         self.w.close()
