@@ -80,3 +80,32 @@ def test_polynomial_parallel_assignment_covers_the_step_once_and_balances():
     # the n-domain-only step (configs[4]) has no 8n transform
     mine, _ = bench.poly_parallel_assignment(4, nbig=0)
     assert sorted(op for ops in mine for op in ops) == sorted([("commit", i) for i in range(13)] + [("intt_n", i) for i in range(7)])
+
+
+def test_pmc_numbers_are_quoted_only_for_the_code_they_were_collected_from(tmp_path):
+    """bench.load_pmc: the committed PMC collection is quoted for its own workload only, for all kernels when the kernel sources are the
+    collection's, and otherwise kernel by kernel when the machine-code hash recorded with the collection equals the built library's."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from distributed_plonk_amd import build
+    pmc, note = bench.load_pmc("2^20@bn254@1")
+    assert pmc == {} and "not this workload" in note
+    assert bench.load_pmc("2^24@bn254@1", dense_coset=True)[0] == {}
+    assert bench.load_pmc("2^24@bn254@1", path=str(tmp_path / "missing.json")) == ({}, bench.load_pmc("2^24@bn254@1", path=str(tmp_path / "missing.json"))[1])
+    kern = {"ntt_pass_kernel": {"traffic_bytes": 1}, "ntt_pass_kernel<8, 4, true, true>": {"traffic_bytes": 2}, "msm_accumulate_kernel": {"traffic_bytes": 3}}
+    # same sources: everything
+    f1 = tmp_path / "same.json"
+    f1.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": build.source_hash(), "kernels": kern}))
+    assert bench.load_pmc("2^24@bn254@1", path=str(f1)) == (kern, None)
+    # other sources: only kernels whose recorded machine-code hash is the library's
+    now = build.code_hashes()
+    if not now:
+        return                                   # the library has not been built in this tree: nothing more to compare
+    f2 = tmp_path / "other.json"
+    f2.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": "0" * 16, "kernels": kern,
+                              "code_hashes": {"ntt_pass_kernel": now["ntt_pass_kernel"], "msm_accumulate_kernel": "f" * 16}}))
+    pmc, note = bench.load_pmc("2^24@bn254@1", path=str(f2))
+    assert sorted(pmc) == ["ntt_pass_kernel", "ntt_pass_kernel<8, 4, true, true>"] and "byte-identical" in note and "ntt_pass_kernel" in note
+    f3 = tmp_path / "nohashes.json"
+    f3.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": "0" * 16, "kernels": kern}))
+    assert bench.load_pmc("2^24@bn254@1", path=str(f3))[0] == {}
