@@ -222,7 +222,8 @@ int plonk_poly_div_linear_dev(plonk_ctx* ctx, const void* d_poly, size_t len, co
  * trimming of from_coefficients_vec — the WrongQuotientPolyDegree check of :511-518 without a host copy.  Synchronises. */
 int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t len, int64_t* degree);
 /* d_poly (n + k coefficients, the top k already valid, normally zero) += (sum_{i<k} blinders[i] X^i) * (X^n - 1):
- * DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly (:311-312 k = 2, :347-348 k = 3).  k <= 4. */
+ * DensePolynomial::rand(k-1).mul_by_vanishing_poly(domain) + poly (:311-312 k = 2, :347-348 k = 3).  k <= 4, any n >= 1 (a domain smaller
+ * than the mask included). */
 int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k);
 
 /* ---- evaluation on / interpolation from an ARBITRARY coset (building block of coset-class parallelism) ------
