@@ -920,6 +920,11 @@ def main():
         arm(None, 0)
         if rank == 0:
             out["polynomial_parallel"] = pp
+            if not sim:
+                # the three ways to spread the step over the ranks, side by side (`value` is always the first: the reference's scheme)
+                out["schemes_ms_per_step"] = {scheme: out.get("ms_per_step"),
+                                              **({other_scheme["scheme"]: other_scheme.get("ms_per_step")} if other_scheme and "scheme" in other_scheme else {}),
+                                              "polynomial_parallel": pp.get("ms_per_step")}
 
     # ---- N > 1 (and --multi-path): the distributed code path that was just timed, checked on every rank against a single-rank
     # recomputation with the whole-vector path (which tests/ and the N = 1 run check against the oracle): one size-n inverse transform

@@ -10,8 +10,8 @@ R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_zz_bench_program.py -m gpu -q -x -p no:cacheprovider \
-    -k "grid_reduction or circuit_shaped or world_of_one or busiest_rank" 2>&1 | tail -5 | tee $O/r4open_new_tests.txt
+timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_quotient.py tests/test_gpu_polyops.py tests/test_gpu_zz_bench_program.py -m gpu -q -x -p no:cacheprovider \
+    -k "grid_reduction or circuit_shaped or tiny_domain or lincomb_and_blind or world_of_one or busiest_rank" 2>&1 | tail -5 | tee $O/r4open_new_tests.txt
 timeout 700 bash tools/ab_reduce_grid.sh 2>&1 | tail -40 | tee $O/r4open_ab_grid.txt
 B="python bench.py --no-cpu-baseline --no-next-rows --no-other-configs --no-class-prover --steps 3 --warmup 1"
 for S in 2 4 8; do
