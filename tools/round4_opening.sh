@@ -12,6 +12,8 @@ mkdir -p $O
 cd $R
 timeout 900 python -m pytest tests/test_gpu_msm.py tests/test_gpu_quotient.py tests/test_gpu_polyops.py tests/test_gpu_zz_bench_program.py -m gpu -q -x -p no:cacheprovider \
     -k "grid_reduction or circuit_shaped or tiny_domain or lincomb_and_blind or world_of_one or busiest_rank" 2>&1 | tail -5 | tee $O/r4open_new_tests.txt
+#   1b. the differential fuzzer on the real library for the first time (15 operations, odd shapes, ~3 min); promote a slice of it to a -m gpu test once green
+timeout 400 python tools/fuzz_abi.py --seconds 180 --seed 2026 --max-log 13 2>&1 | tail -3 | tee $O/r4open_fuzz.txt
 timeout 700 bash tools/ab_reduce_grid.sh 2>&1 | tail -40 | tee $O/r4open_ab_grid.txt
 B="python bench.py --no-cpu-baseline --no-next-rows --no-other-configs --no-class-prover --steps 3 --warmup 1"
 for S in 2 4 8; do
