@@ -41,6 +41,9 @@ struct dim3 {
 namespace hipemu {
 struct Idx3 { uint32_t x, y, z; };
 void launch(dim3 grid, dim3 block, size_t shmem, const std::function<void()>& thread_body);
+// the dynamic-LDS rule of the real runtime: a launch asking for more than 64 KiB must have raised the kernel's limit with
+// hipFuncSetAttribute(hipFuncAttributeMaxDynamicSharedMemorySize) ON THE DEVICE IT RUNS ON first (a launch that skips it fails on the GPU)
+void check_dynamic_lds(const void* kernel, size_t shmem, const char* name);
 void barrier_block();
 int shfl(int v, int src_lane);
 void* dyn_smem();
@@ -132,13 +135,16 @@ hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
 hipError_t hipEventSynchronize(hipEvent_t e);
 hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 hipError_t hipFuncSetAttribute(const void* fn, hipFuncAttribute attr, int value);
-template <typename F> static inline hipError_t hipFuncSetAttribute(F fn, hipFuncAttribute attr, int value) { (void)fn; (void)attr; (void)value; return hipSuccess; }
+template <typename F> static inline hipError_t hipFuncSetAttribute(F fn, hipFuncAttribute attr, int value) {
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(fn), attr, value);
+}
 
 // The arguments are evaluated ONCE (as a real launch does) and every emulated thread calls the kernel with them.
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...)                                                              \
     do {                                                                                                                         \
         auto _hipemu_args = std::make_tuple(__VA_ARGS__);                                                                        \
         (void)(stream);                                                                                                          \
+        hipemu::check_dynamic_lds(reinterpret_cast<const void*>(&kernel), (size_t)(shmem), #kernel);                             \
         hipemu::launch(dim3(grid), dim3(block), (size_t)(shmem),                                                                 \
                        [&]() { std::apply([](auto&... _a) { kernel(_a...); }, _hipemu_args); });                                 \
     } while (0)

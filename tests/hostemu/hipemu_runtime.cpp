@@ -13,6 +13,7 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -390,7 +391,30 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
     *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
     return hipSuccess;
 }
-hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+namespace {
+std::mutex g_attr_mutex;
+std::map<std::pair<int, const void*>, size_t> g_max_dyn_lds;          // (device, kernel) -> raised limit
+}
+hipError_t hipFuncSetAttribute(const void* fn, hipFuncAttribute attr, int value) {
+    if (attr == hipFuncAttributeMaxDynamicSharedMemorySize) {
+        if (value < 0 || (size_t)value > SMEM_BYTES) return hipErrorInvalidValue;
+        std::lock_guard<std::mutex> g(g_attr_mutex);
+        g_max_dyn_lds[{tl_device, fn}] = (size_t)value;
+    }
+    return hipSuccess;
+}
+namespace hipemu {
+void check_dynamic_lds(const void* kernel, size_t shmem, const char* name) {
+    if (shmem <= (64u << 10)) return;
+    std::lock_guard<std::mutex> g(g_attr_mutex);
+    auto it = g_max_dyn_lds.find({tl_device, kernel});
+    if (it == g_max_dyn_lds.end() || it->second < shmem) {
+        fprintf(stderr, "hipemu: %s launched with %zu bytes of dynamic LDS on device %d without hipFuncSetAttribute(MaxDynamicSharedMemorySize) >= that "
+                        "on this device (limit in force: %zu) - the launch fails on a GPU\n", name, shmem, tl_device, it == g_max_dyn_lds.end() ? (size_t)(64u << 10) : it->second);
+        abort();
+    }
+}
+}  // namespace hipemu
 
 // marks the library as the emulation: distributed_plonk_amd/_ffi.py refuses to load it unless the test harness opted in
 extern "C" int plonk_hostemu_marker() { return 1; }

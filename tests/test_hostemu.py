@@ -161,3 +161,30 @@ def test_differential_fuzz_slice(emu_env):
     r = subprocess.run([sys.executable, "tools/fuzz_abi.py", "--seconds", "500", "--max-ops", "100", "--seed", "5", "--max-log", "10"], cwd=ROOT, env=emu_env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz ok: 100 operations" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_second_device_of_one_process_raises_its_own_lds_limits(emu_env):
+    """The emulation enforces the runtime's dynamic-LDS rule per (device, kernel): a launch above 64 KiB aborts unless
+    hipFuncSetAttribute(MaxDynamicSharedMemorySize) was called for that kernel ON THAT DEVICE.  A second worker on another device of the
+    same process therefore only works because the library's guards are per device (plonk_internal.hpp: DeviceOnce) — a process-wide
+    `static bool` would launch the NTT passes and the MSM sort of device 1 with device 0's raised limit only."""
+    code = r"""
+import numpy as np
+from distributed_plonk_amd.worker import PlonkWorker
+from distributed_plonk_amd._ffi import MsmWorkload
+from oracle import oracle as O
+for dev in (0, 1, 3):
+    w = PlonkWorker(me=0, device=dev, curve="bn254")
+    v = O.rand_fr(O.BN254, 5 + dev, 1 << 12)
+    assert np.array_equal(w.ntt(v, False, True), O.ntt(O.BN254, v, False, True))
+    bases = O.gen_bases(O.BN254, 7, 64, 1 << 11)
+    sc = O.from_mont(O.BN254, O.rand_fr(O.BN254, 9, 1 << 11))
+    w.init(bases, 1 << 11, 1 << 14)
+    xy, inf = w.g1_to_affine(w.var_msm(MsmWorkload(0, 1 << 11), sc))
+    oxy, oinf = O.jac_to_affine(O.BN254, O.msm(O.BN254, bases, sc, threads=4))
+    assert inf == oinf and np.array_equal(xy, oxy)
+    w.close()
+print("devices ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=emu_env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "devices ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
