@@ -38,6 +38,18 @@ template <int NQ> static const FpParams<NQ>& fq_params(int curve);
 template <> const FpParams<8>& fq_params<8>(int) { return BN254_FQ_PARAMS; }
 template <> const FpParams<12>& fq_params<12>(int) { return BLS12_381_FQ_PARAMS; }
 
+// Wave priority of everything in an MSM that is NOT the bucket accumulation (build flag -DMSM_SIDE_PRIO=1..3; default 0 = no instruction): a SIMD's
+// arbiter issues the highest-priority ready wave first and the oldest among equals, so beside another stream's accumulation (four long-lived
+// VALU-bound waves per SIMD) the short memory- / latency-bound phases of the next MSM otherwise queue behind it for every instruction.
+#ifndef MSM_SIDE_PRIO
+#define MSM_SIDE_PRIO 0
+#endif
+#if MSM_SIDE_PRIO > 0
+#define MSM_SIDE_PRIO_ENTER() __builtin_amdgcn_s_setprio(MSM_SIDE_PRIO)
+#else
+#define MSM_SIDE_PRIO_ENTER() ((void)0)
+#endif
+
 // ---------------------------------------------------------------------------------------------- helpers
 template <typename T> __device__ __forceinline__ T load16(const T* p) {
     static_assert(sizeof(T) % 16 == 0, "16-byte multiple");
@@ -73,6 +85,7 @@ __device__ __forceinline__ uint32_t scalar_raw_digit(const uint32_t* s, int bit0
 // `len` <= n scalars are valid; positions len .. n-1 get zero digits (a batch of commitments pads its shorter polynomials).
 __global__ void __launch_bounds__(256) msm_digits_kernel(const uint32_t* __restrict__ scalars, uint64_t n, uint64_t len, int c, int W,
                                                          uint32_t* __restrict__ dig, int scalars_mont, const FpParams<8> FR) {
+    MSM_SIDE_PRIO_ENTER();
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     if (i >= len) {
@@ -133,6 +146,7 @@ struct SortGeom {
 };
 
 __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restrict__ dig, SortGeom g, uint32_t* __restrict__ blk_hist) {
+    MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t h[];
     const uint32_t np = (1u << g.lp) + 1;
     for (uint32_t k = threadIdx.x; k < np; k += blockDim.x) h[k] = 0;
@@ -159,6 +173,7 @@ __global__ void __launch_bounds__(256) sort_hist_kernel(const uint32_t* __restri
 #define SCATTER_THREADS 1024     // 16 waves on a ~74 KiB LDS footprint: two workgroups = eight waves per SIMD hide the LDS-atomic and HBM latency
 __global__ void __launch_bounds__(SCATTER_THREADS) sort_scatter_kernel(const uint32_t* __restrict__ dig, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                                        uint32_t* __restrict__ tmp) {
+    MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t sm[];
     const uint32_t np = (1u << g.lp) + 1;                 // last bin: zero digits (dropped)
     uint32_t* cnt = sm;                                   // [np]   counts, then running cursors
@@ -233,6 +248,7 @@ __global__ void __launch_bounds__(SCATTER_THREADS) sort_scatter_kernel(const uin
 // one workgroup per real partition: final order + bucket offsets
 __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                              uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+    MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t lds[];
     const uint32_t nlow = 1u << g.low_bits;
     uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors
@@ -291,6 +307,7 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
 #define STAGE_MAX_CHUNKS 8u
 __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
                                                                               uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+    MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t lds[];
     const uint32_t nlow = 1u << g.low_bits;
     uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors (relative to the partition start)
@@ -395,6 +412,7 @@ __device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint32_t s
     return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
 }
 __global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g, uint32_t* __restrict__ ghist) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t h[SIZE_BINS];
     h[threadIdx.x] = 0;
     __syncthreads();
@@ -404,6 +422,7 @@ __global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* _
     if (h[threadIdx.x]) atomicAdd(&ghist[threadIdx.x], h[threadIdx.x]);
 }
 __global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint32_t* __restrict__ ghist, uint32_t* __restrict__ bin_cursor) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t buf[SIZE_BINS];
     const uint32_t v = ghist[threadIdx.x];
     buf[threadIdx.x] = v;
@@ -418,6 +437,7 @@ __global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint3
 }
 __global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g,
                                                                 uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t h[SIZE_BINS];
     __shared__ uint32_t base[SIZE_BINS];
     h[threadIdx.x] = 0;
@@ -437,6 +457,7 @@ __global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* 
 #define SCAN_CHUNK (SCAN_ITEMS * SCAN_THREADS)
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const uint32_t* __restrict__ in, uint64_t n, uint32_t* __restrict__ block_sums) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t red[SCAN_THREADS];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t s = 0;
@@ -451,6 +472,7 @@ __global__ void __launch_bounds__(SCAN_THREADS) scan_block_sums_kernel(const uin
 }
 
 __global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t* __restrict__ block_sums, uint64_t nblocks, uint32_t* __restrict__ total_out) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t buf[1024];
     __shared__ uint32_t carry;
     if (threadIdx.x == 0) carry = 0;
@@ -477,6 +499,7 @@ __global__ void __launch_bounds__(1024) scan_top_kernel(uint32_t* __restrict__ b
 
 __global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t* __restrict__ in, uint64_t n, const uint32_t* __restrict__ block_offsets,
                                                                   uint32_t* __restrict__ out) {
+    MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t buf[SCAN_THREADS];
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_CHUNK + (uint64_t)threadIdx.x * SCAN_ITEMS;
     uint32_t v[SCAN_ITEMS];
@@ -621,6 +644,7 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>:
                                                         const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
                                                         XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
                                                         const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
@@ -660,6 +684,7 @@ __global__ void __launch_bounds__(64) msm_heavy_finish_kernel(const uint32_t* __
                                                               const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ partial,
                                                               XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets,
                                                               const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint32_t total = *heavy_count;
     for (uint32_t h = blockIdx.x * blockDim.x + threadIdx.x; h < total; h += gridDim.x * blockDim.x) {
@@ -676,6 +701,7 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
                                                                  XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
                                                                  const uint32_t* __restrict__ redo_list,
                                                                  const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint32_t total = *redo_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -719,6 +745,7 @@ __global__ void __launch_bounds__(256) msm_reduce_level_kernel(const XyzzL<LimbG
                                                                XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_s,
                                                                uint32_t* __restrict__ redo_count, uint32_t* __restrict__ redo_list,
                                                                const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= total) return;
@@ -745,6 +772,7 @@ __global__ void __launch_bounds__(64) msm_reduce_level_redo_kernel(const XyzzL<L
                                                                    XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_s,
                                                                    const uint32_t* __restrict__ redo_count, const uint32_t* __restrict__ redo_list,
                                                                    const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint32_t total = *redo_count;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
@@ -774,6 +802,7 @@ template <int NQ, bool RAW = false>
 __global__ void __launch_bounds__(256) msm_points_sum_kernel(SumJobs jobs, XyzzPt<NQ>* __restrict__ out, uint32_t nlevels, uint32_t nsplit,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
                                                              XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_raw = nullptr) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
@@ -816,6 +845,7 @@ __global__ void __launch_bounds__(256) msm_grid_sums_kernel(const XyzzL<LimbGeom
                                                             XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_r,
                                                             XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out_c,
                                                             const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
@@ -855,6 +885,7 @@ template <int NQ>
 __global__ void __launch_bounds__(256) msm_bit_sums_kernel(const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ r_sums,
                                                            const XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ c_sums, uint32_t logL, uint32_t logH,
                                                            XyzzPt<NQ>* __restrict__ out, const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
+    MSM_SIDE_PRIO_ENTER();
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     XyzzL<NL, B>* sh = reinterpret_cast<XyzzL<NL, B>*>(smem_raw);
@@ -1243,13 +1274,16 @@ static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d
     uint32_t* work = nullptr;
     uint32_t acc_grid = (uint32_t)((nbuckets + 255) / 256);
     if (ws.acc_persist != 0) {
-        static int n_cu = 0;
+        // CU count of the CURRENT device, cached per device (a process may drive several GPUs from several threads)
+        static int cu_of_dev[64];
+        int dev = 0;
+        HIP_TRY(hipGetDevice(&dev));
+        int n_cu = dev >= 0 && dev < 64 ? __atomic_load_n(&cu_of_dev[dev], __ATOMIC_ACQUIRE) : 0;
         if (!n_cu) {
-            int dev = 0;
             hipDeviceProp_t prop;
-            HIP_TRY(hipGetDevice(&dev));
             HIP_TRY(hipGetDeviceProperties(&prop, dev));
             n_cu = std::max(prop.multiProcessorCount, 1);
+            if (dev >= 0 && dev < 64) __atomic_store_n(&cu_of_dev[dev], n_cu, __ATOMIC_RELEASE);
         }
         const uint32_t pgrid = ws.acc_persist > 0 ? (uint32_t)n_cu * (uint32_t)ws.acc_persist : (uint32_t)(-ws.acc_persist);   // < 0: absolute grid (tests)
         if (pgrid < acc_grid) {                                   // small problems keep the plain grid

@@ -27,6 +27,7 @@
 #define __shared__ thread_local                     // block scope: implicitly static; a workgroup never leaves its OS thread
 #define HIP_KERNEL_NAME(...) __VA_ARGS__
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 
 struct uint2 { uint32_t x, y; };
 struct alignas(16) uint4 { uint32_t x, y, z, w; };

@@ -70,6 +70,20 @@ KERNEL16(k_mad_u32_u16, TWICE(REP8(OP_MADU16)), DECL32, C32)
 #define OP_LSHLADD64(r) "v_lshl_add_u64 " #r ", " #r ", 0, %10\n\t"
 KERNEL16(k_mad64, TWICE(REP8(OP_MAD64)), DECL32, C32)
 KERNEL16(k_lshladd64, TWICE(REP8(OP_LSHLADD64)), DECL32, C32)
+// dependent chains on the 64-bit accumulator (the multiplier's product scanning adds nine limb products into ONE accumulator per column):
+// 16 mads per iteration on 1, 2 or 4 accumulators -> issue-to-dependent-issue latency of v_mad_u64_u32
+#define OP16_DEP1 OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0) OP_MAD64(%0)
+#define OP16_DEP2 OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%0) OP_MAD64(%1)
+#define OP16_DEP4 OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%2) OP_MAD64(%3) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%2) OP_MAD64(%3) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%2) OP_MAD64(%3) OP_MAD64(%0) OP_MAD64(%1) OP_MAD64(%2) OP_MAD64(%3)
+KERNEL16(k_mad64_dep1, OP16_DEP1, DECL32, C32)
+KERNEL16(k_mad64_dep2, OP16_DEP2, DECL32, C32)
+KERNEL16(k_mad64_dep4, OP16_DEP4, DECL32, C32)
+// a dependent mad chain with the column hand-over of the multiplier: 8 mads, then acc >>= 29 (v_lshrrev_b64), repeated
+#define OP_SHR64(r) "v_lshrrev_b64 " #r ", 29, " #r "\n\t"
+#define OP8_COL(r) OP_MAD64(r) OP_MAD64(r) OP_MAD64(r) OP_MAD64(r) OP_MAD64(r) OP_MAD64(r) OP_MAD64(r) OP_SHR64(r)
+KERNEL16(k_mad64_col1, OP8_COL(%0) OP8_COL(%0), DECL32, C32)
+#define OP8_COL2(r, q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_SHR64(r) OP_SHR64(q)
+KERNEL16(k_mad64_col2, OP8_COL2(%0, %1), DECL32, C32)
 // mad64 with an SGPR multiplier operand (modulus limb)
 #undef C32
 #define C32 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "s"(seed), "v"(c64) : "vcc"
@@ -93,7 +107,7 @@ struct Entry { const char* name; kern_t k; };
 int main() {
     Entry tests[] = {{"v_add_u32", k_add}, {"v_mov_b32", k_mov}, {"v_add_co_u32", k_addco}, {"v_addc_co_u32", k_addc},
                      {"v_add3_u32", k_add3}, {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi},
-                     {"v_mad_u64_u32", k_mad64}, {"v_mad_u64_u32(sgpr)", k_mad64_sgpr}, {"v_lshl_add_u64", k_lshladd64},
+                     {"v_mad_u64_u32", k_mad64}, {"v_mad_u64_u32(sgpr)", k_mad64_sgpr}, {"mad64 chain x1", k_mad64_dep1}, {"mad64 chain x2", k_mad64_dep2}, {"mad64 chain x4", k_mad64_dep4}, {"mad64 col x1 (7+shr)", k_mad64_col1}, {"mad64 col x2 (7+shr)", k_mad64_col2}, {"v_lshl_add_u64", k_lshladd64},
                      {"v_mad_u32_u24", k_mad24}, {"v_mul_u32_u24", k_mul24}, {"v_mul_hi_u32_u24", k_mulhi24},
                      {"v_mad_u32_u16", k_mad_u32_u16}, {"v_fma_f64", k_fma64}, {"v_add_f64", k_addf64}};
     uint32_t* out; uint64_t* cyc;
@@ -102,7 +116,7 @@ int main() {
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     printf("%-22s %8s %8s | %10s %12s\n", "instruction", "waves/SIMD", "ms", "clk/instr/wave", "Ginstr/s(lane)");
     for (auto& t : tests) {
-        for (int waves_per_simd : {1, 2, 4}) {
+        for (int waves_per_simd : {1, 2, 3, 4}) {
             const int blocks = 256 * waves_per_simd;     // 256 threads = 4 waves = 1 per SIMD
             hipLaunchKernelGGL(t.k, dim3(blocks), dim3(256), 0, 0, out, 3u, cyc);   // warm
             hipEventRecord(e0);
