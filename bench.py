@@ -9,7 +9,8 @@ the reference prover issues per proof (/root/reference/src/dispatcher2.rs:294-69
     1  coset-iNTT of size 8n       (quotient)
     13 KZG commitments             (into_repr + n-point MSM each)
 
-metric = constraints/sec = n / (time of one step); ms_per_step is the proof-equivalent hot-path time.
+metric = constraints/sec = n / (time of one step); ms_per_step is the proof-equivalent hot-path time.  `proof_ms` beside it is a REAL
+proof of a satisfied 2^log_n-gate circuit (the five rounds of dispatcher2.rs:296-712), accepted by a verifier.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 24] [--curve bn254]
 
@@ -20,1437 +21,123 @@ N  > 1: launched by torchrun, one rank per GPU.  Same n (strong scaling): every 
         index-sharded with a 96-byte all-gather + host add.
         Reported beside `value`, never part of it: `other_scheme` (rank-local coset classes, 2 collectives per step) and
         `polynomial_parallel` (SURVEY §8e's alternative: whole operations per rank, whole SRS on every rank, no data-path collective).
-Only rank 0 prints, one JSON line.  The CPU baseline leg (rank 0, N == 1) times the oracle (a C
-restatement of the reference's arkworks algorithms) on a bounded sample; it is a reported baseline.
+Only rank 0 prints, one JSON line.  The parts live in benchlib/ (one function per leg; every leg after the headline runs in its own
+try/except and under a watchdog, so a failure there costs that leg's fields, never the line).
 """
-import argparse
-import json
 import os
 import sys
-import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL / multi-process)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
-N_NTT_SMALL, N_NTT_BIG, N_MSM = 7, 26, 13
+from benchlib import HBM_PEAK_GBS, N_MSM, N_NTT_BIG, N_NTT_SMALL, POLY_OP_COST, ResultLine, load_pmc, poly_parallel_assignment, run_leg  # noqa: E402,F401
+from benchlib.cli import parse, plan  # noqa: E402
 
 
-# ---- polynomial-level parallelism (SURVEY.md §8e, NTT row: "Alternative for N that fits one GPU: polynomial-level parallelism (25 independent
-# coset-FFTs -> GPUs), zero communication - report both").  The 46 operations of a step are independent objects; a rank takes WHOLE operations.
-# Relative costs measured on one MI355X at n = 2^24 (profiles/r03_bench_2p24_final.json: 8n zero-padded coset FFT 15.2 ms, dense 8n coset iFFT
-# ~19 ms, size-n iNTT 1.9 ms, commitment 21.5 ms); the longest-processing-time rule needs ratios, not absolute times.
-POLY_OP_COST = {"commit": 21.5, "coset_ifft_8n": 19.0, "coset_fft_8n": 15.2, "intt_n": 1.9}
+def _single_gpu_legs(b, out, args):
+    """rank 0, N == 1, after the headline: checks against the oracle, the next rows, the verified proof"""
+    from benchlib import legs_single as L
+    if not args.no_verify:
+        ver = run_leg(None, "verify", None, lambda: L.verify_single(b))       # a failed check must be visible, never fatal to the measurement
+        out["verification"] = ver
+        out["verified"] = "error" not in ver and all(ver.values())
+    next_rows = {}
+    if args.next_rows == "all":
+        next_rows.update(run_leg(None, "quotient_row", None, lambda: L.quotient_row(b), error=lambda ex: {"error": str(ex)}))
+    if args.next_rows in ("all", "proof"):
+        full = args.next_rows == "all"
+        res = run_leg(None, "prover_rounds", None, lambda: L.prover_rounds(b, with_small_rows=full, with_variants=full), error=lambda ex: ({}, {"error": repr(ex)}))
+        next_rows.update(res[0])
+        next_rows["prover_rounds"] = res[1]
+    return next_rows or None
 
 
-def poly_parallel_assignment(n_ranks, nbig=N_NTT_BIG, n_small=N_NTT_SMALL, n_msm=N_MSM, cost=None):
-    """-> (ops_of_rank, load_of_rank): every operation of one step on exactly one rank.  An operation is (kind, index): index = the
-    commitment / polynomial / vector number of the single-GPU step, so the union over ranks is the single-GPU step on the same inputs.
-    Longest-processing-time-first: operations by descending cost, each to the least loaded rank (ties: the lowest rank)."""
-    cost = cost or POLY_OP_COST
-    ops = [("commit", i) for i in range(n_msm)]
-    if nbig:
-        ops += [("coset_ifft_8n", 0)] + [("coset_fft_8n", i) for i in range(nbig - 1)]
-    ops += [("intt_n", i) for i in range(n_small)]
-    ops.sort(key=lambda o: -cost[o[0]])                      # stable: equal-cost operations keep their index order
-    mine = [[] for _ in range(n_ranks)]
-    load = [0.0] * n_ranks
-    for o in ops:
-        g = min(range(n_ranks), key=lambda r: (load[r], r))
-        mine[g].append(o)
-        load[g] += cost[o[0]]
-    return mine, load
-
-
-def load_pmc(config, dense_coset=False, path=None):
-    """-> (per-kernel PMC numbers bench.py may quote for this run, note or None).  profiles/pmc_current.json (tools/pmc_collect.py) is quoted
-    when it holds this workload and was collected from the kernel sources the loaded library was built from (build.source_hash) — or,
-    kernel by kernel, when the sources differ but that kernel's gfx950 MACHINE CODE (every instantiation, hashed from the objects:
-    distributed_plonk_amd/codehash.py) is byte-identical to what the counters ran: an edit elsewhere (an error path of the C ABI, a new
-    kernel beside it) does not touch it.  Otherwise nothing is quoted and the note says why."""
-    try:
-        from distributed_plonk_amd.build import code_hashes, source_hash
-        with open(path or os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
-            db = json.load(f)
-        if db.get("config") != config or dense_coset:
-            return {}, f"profiles/pmc_current.json holds {db.get('config')} (padded coset inputs): not this workload"
-        if db.get("source_hash") == source_hash():
-            return db["kernels"], None
-        now, then = code_hashes(), db.get("code_hashes") or {}
-        same = sorted(k_ for k_ in then if now.get(k_) == then[k_])
-        pmc = {k_: v_ for k_, v_ in db["kernels"].items() if k_.split("<")[0] in same}
-        return pmc, (f"profiles/pmc_current.json was collected from other kernel sources ({db.get('source_hash')} != {source_hash()}); quoted only for "
-                     f"kernels whose gfx950 machine code is byte-identical to the collection's: {', '.join(k_ for k_ in same if k_ in db['kernels']) or 'none'}")
-    except Exception as ex:     # noqa: BLE001 - a missing or unreadable profile costs the PMC fields, never the run
-        return {}, f"no PMC profile: {ex!r}"
-
-
-def parse():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-n", type=int, default=int(os.environ.get("PLONK_BENCH_LOG_N", "24")))
-    ap.add_argument("--curve", default="bn254", choices=["bn254", "bls12_381"])
-    ap.add_argument("--bases", default="distinct", choices=["distinct", "tiled"])
-    ap.add_argument("--dense-coset", action="store_true",
-                    help="feed the 25 forward coset transforms dense random 8n-point inputs through plonk_ntt_dev (the round-1 bench line) "
-                         "instead of the n+3 coefficients the prover actually has (zero-padded to 8n by the reference, dispatcher2.rs:746)")
-    ap.add_argument("--n-domain-only", action="store_true",
-                    help="BASELINE.json configs[4] (2^28-gate BN254: 'HBM-resident witness' sizing stress): the 8n quotient domain of such a circuit "
-                         "does not exist on BN254 (two-adicity 28), so only the n-domain part of the step runs - 7 iNTT(n) + 13 commitments(n)")
-    ap.add_argument("--no-verify", action="store_true", help="skip the post-run result checks (`verified` becomes null)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-next-rows", action="store_true", help="skip the SURVEY §8f rows measured after the headline (quotient kernel, prover rounds)")
-    ap.add_argument("--no-other-configs", action="store_true",
-                    help="default run only: skip the compact re-runs at BASELINE.json's configs[1] (2^20 BN254) and configs[3] (2^22 BLS12-381)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=20)
-    ap.add_argument("--no-poly-parallel", action="store_true",
-                    help="N > 1: skip the polynomial-level-parallel leg (whole operations per rank, no data-path collective; SURVEY §8e's alternative)")
-    ap.add_argument("--simulate-ranks", type=int, default=0,
-                    help="diagnostic: run rank 0's share of an S-rank job on ONE GPU with a no-op exchange (results are garbage, "
-                         "timings are one rank's compute without communication)")
-    ap.add_argument("--class-prover", action="store_true",
-                    help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
-                         "on by default for N > 1, reported under next_rows, never part of `value`")
-    ap.add_argument("--no-class-prover", action="store_true", help="N > 1: skip the coset-class prover leg")
-    ap.add_argument("--scheme", default="reference2d", choices=["classes", "reference2d"],
-                    help="N > 1: how the step's transforms are distributed.  'classes': rank s evaluates every polynomial on ITS coset "
-                         "class (the points j = s mod N of the 8n-point coset) with a local zero-padding-aware (8n/N)-point transform - no "
-                         "exchange for the 25 forward coset FFTs; the quotient's coset iFFT is one class-local inverse transform + ONE all-to-all "
-                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs run on every rank.  'reference2d' (default): every one "
-                         "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass), the 25 forward "
-                         "coset FFTs from zero-padded rows (plonk_fft1_dev_compact), two lanes so that exchanges overlap the next transform's passes.  "
-                         "The other scheme is timed after the headline and reported as `other_scheme`")
-    ap.add_argument("--dry-run", action="store_true",
-                    help="no GPU: validate the arguments for this --gpus (divisibility of r and n, class count, buffer sizes per rank) and print the plan")
-    ap.add_argument("--multi-path", action="store_true",
-                    help="diagnostic: run the N > 1 code path (communicators, collectives, class scheme) on a world of ONE rank")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
-                    help="N > 1 data path: 'rccl' = the communicator inside libplonk_hip.so (plonk_comm_init; grouped ncclSend/ncclRecv on the "
-                         "library's stream, no Python in the exchange), 'torch' = torch.distributed.all_to_all_single through the callback")
-    return ap.parse_args()
-
-
-def plan(args, S):
-    """Everything that can be decided without a GPU: used by --dry-run (tools/preflight_multi.sh) and checked again at start-up."""
-    n, m = 1 << args.log_n, 8 << args.log_n
-    two_adicity = 28 if args.curve == "bn254" else 32
-    problems = []
-    if args.n_domain_only:
-        if args.log_n > two_adicity:
-            problems.append(f"the domain 2^{args.log_n} exceeds the field's two-adicity {two_adicity} (DomainCreationError)")
-    elif args.log_n + 3 > two_adicity:
-        problems.append(f"the quotient domain 2^{args.log_n + 3} exceeds the field's two-adicity {two_adicity} (DomainCreationError); "
-                        f"--n-domain-only runs the n-domain part of the step")
-    if S & (S - 1):
-        problems.append(f"{S} ranks: the row / column / class partitions need a power of two")
-    sizes = {}
-    for name, N_ in ((("n", n),) if args.n_domain_only else (("n", n), ("8n", m))):
-        log = N_.bit_length() - 1
-        r_, c_ = 1 << (log >> 1), 1 << (log - (log >> 1))
-        if r_ % S or c_ % S:
-            problems.append(f"{S} ranks do not divide r = {r_} / c = {c_} of the 2^{log}-point 2-D transform")
-        sizes[name] = {"r": r_, "c": c_, "rows_per_rank": r_ // max(S, 1), "cols_per_rank": c_ // max(S, 1),
-                       "bytes_per_pair_per_exchange": (r_ // S) * (c_ // S) * 32 if S > 1 else 0}
-    if S > 8:
-        problems.append(f"{S} ranks: the coset-class scheme needs N <= 8n/n = 8 classes")
-    GiB = float(1 << 30)
-    q_bytes = 64 if args.curve == "bn254" else 96
-    limb_bytes = 72 if args.curve == "bn254" else 112
-    me_ = 0 if args.n_domain_only else m
-    msm_ws = 3 * 4 * 15 * min(n // S, 1 << 26)                          # digit / sorted-index arrays of one MSM slice
-    if S == 1:
-        hbm = 2 * n * 32 + 2 * me_ * 32 + (n + 3) * 32 + me_ * 32 + 2 * (n * limb_bytes) + n * q_bytes + 2 * me_ * 32 + 2 * msm_ws + n * 32   # buffers + scratch + SRS (two contexts) + planes
-    else:
-        hbm = (2 * 2 * (n // S) * 32 + 2 * 2 * (me_ // S) * 32           # reference2d lanes
-               + (2 * n * 32 + (n + 3) * 32 + 2 * (me_ // S) * 32 + 3 * me_ * 32 if me_ else 0)     # classes: bn, poly, out/mine, contrib/recv/quot
-               + 2 * (n // S) * limb_bytes + (n // S) * q_bytes + (me_ // S) * 32 * 2 + 2 * msm_ws + 3 * (n // S) * 32)
-    pp = None
-    if S > 1 and not args.n_domain_only:
-        # the polynomial-level-parallel leg: whole operations per rank, whole SRS (raw + limb form on two contexts) on every rank
-        mine_, load_ = poly_parallel_assignment(S)
-        worst = max(sum(1 for o in ops_ if o[0] == "commit") * n * 32 + sum(1 for o in ops_ if o[0] == "coset_fft_8n") * (n + 3) * 32
-                    + sum(1 for o in ops_ if o[0] == "intt_n") * 2 * n * 32 + (2 * m * 32 if ("coset_ifft_8n", 0) in ops_ else 0) for ops_ in mine_)
-        pp = {"operations_per_rank": [{k_: sum(1 for o in ops_ if o[0] == k_) for k_ in POLY_OP_COST} for ops_ in mine_],
-              "modelled_load_ms_per_rank_at_2p24": [round(x, 1) for x in load_],
-              "approx_hbm_GiB_per_rank": round((worst + n * q_bytes + 2 * n * limb_bytes + 3 * m * 32 + 2 * 3 * 4 * 15 * min(n, 1 << 26)) / GiB, 1)}
-    return {"n": n, "m": m, "ranks": S, "scheme": args.scheme if S > 1 else "single", "transforms": sizes,
-            "msm_points_per_rank": n // S, "class_points_per_rank": m // S, "approx_hbm_GiB_per_rank_headline": round(hbm / GiB, 1),
-            "polynomial_parallel": pp, "problems": problems, "ok": not problems}
-
-
-class ResultLine:
-    """The one JSON line of a run and the watchdog that protects it.  The line exists (`out`) as soon as the headline is measured;
-    the optional legs that follow only add fields.  With the watchdog started, a leg that exceeds the budget it was armed with — a
-    collective that never completes on an N > 1 run — costs that leg, not the line: rank 0 prints what it has, with
-    `aborted_optional_leg` naming the leg, and every rank leaves with exit code 0 (os._exit: the hung thread cannot be joined)."""
-
-    def __init__(self, fd, rank, out):
-        import threading
-        self.fd, self.rank, self.out = fd, rank, out
-        self._emitted = threading.Event()
-        self._lock = threading.Lock()
-        self._leg = (None, None)                 # (name, deadline on time.monotonic())
-
-    @staticmethod
-    def _scrub(x):
-        """an emulated dry run carries no timing of anything: drop every clock-derived field, keep the verdicts"""
-        if isinstance(x, dict):
-            return {k: ResultLine._scrub(v) for k, v in x.items()
-                    if not (k == "ms" or k.endswith("_ms") or k.startswith("ms_") or "_ms_" in k or "constraints_per_s" in k or k.startswith("proof_ms"))}
-        if isinstance(x, list):
-            return [ResultLine._scrub(v) for v in x]
-        return x
-
-    def emit(self):
-        with self._lock:
-            if self.rank == 0 and not self._emitted.is_set():
-                line = self._scrub(self.out) if isinstance(self.out, dict) and self.out.get("emulated") else self.out
-                os.write(self.fd, (json.dumps(line) + "\n").encode())
-            self._emitted.set()
-
-    def arm(self, name, seconds):
-        """Start (or, with name None, stop) the watchdog clock of one optional leg."""
-        self._leg = (name, time.monotonic() + seconds) if name else (None, None)
-
-    def start_watchdog(self, poll_s=1.0):
-        import threading
-
-        def run():
-            while True:                              # daemon thread: ends with the process
-                time.sleep(poll_s)
-                name, deadline = self._leg
-                if deadline is not None and time.monotonic() > deadline:
-                    if self.out is None and name == "headline":
-                        # the timed region itself never finished (a collective that hangs on an N > 1 run): there is no measurement to
-                        # print — say so on rank 0 and leave with a failure code instead of hanging until the driver's own limit
-                        if self.rank == 0:
-                            os.write(self.fd, (json.dumps({"error": "the warm-up / timed steps exceeded the headline watchdog budget "
-                                                                    "(a collective that never completed?); nothing was measured"}) + "\n").encode())
-                        os._exit(4)
-                    if self.rank == 0:
-                        self.out["aborted_optional_leg"] = {"leg": name, "note": "the leg exceeded its watchdog budget (a collective that never "
-                                                            "completed?); the headline above was measured before it started and is unaffected"}
-                    self.emit()
-                    os._exit(0)
-
-        threading.Thread(target=run, daemon=True).start()
+def _proof_fields(out, next_rows, class_row):
+    """the REAL proof at top level (BASELINE's metric is "proof-gen ms"): the five rounds of dispatcher2.rs:296-712 on the 8n route
+    with the proving key NOT resident — the reference's work — on the satisfied synthetic circuit, verified; `value` stays on
+    the SURVEY §8d op mix for continuity with rounds 1-3.  Same-proof variants beside it, labelled."""
+    pr = (next_rows or {}).get("prover_rounds") or {}
+    if "ms" in pr:
+        out["proof_ms"] = pr["ms"]
+        out["proof_constraints_per_s"] = pr["constraints_per_s"]
+        out["prover_verified"] = pr.get("prover_verified")
+        names = {"resident_key_cosets": "8n_route_key_coset_vectors_resident_in_HBM", "six_cosets": "six_coset_quotient_key_not_resident",
+                 "six_cosets_resident_key": "six_coset_quotient_key_resident"}
+        out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms)": pr["ms"]},
+                                        **{names[k_]: v_.get("ms") for k_, v_ in (pr.get("variants") or {}).items()})
+    if class_row and "ms" in class_row:
+        out["proof_ms_class_prover_all_ranks"] = class_row["ms"]
 
 
 def main():
     args = parse()
     if args.dry_run:
         p_ = plan(args, max(args.gpus, args.simulate_ranks, 1))
-        print(json.dumps(p_))
+        print(__import__("json").dumps(p_))
         raise SystemExit(0 if p_["ok"] else 2)
     # stdout carries exactly ONE JSON line: libraries that print there (RCCL's version banner at the first collective) are
     # sent to stderr by pointing fd 1 at fd 2 for the duration of the run; the result goes out through the saved descriptor
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    import numpy as np
-    import torch
-    import torch.distributed as dist
+    from benchlib import headline, legs_multi as M
+    from benchlib.run import Bench
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    # tests/test_hostemu.py only: a DRY RUN of this program's control flow (the N > 1 legs above all) against the host emulation of the
-    # library — rank processes under gloo, no GPU, tiny sizes.  Its JSON line says `emulated` and carries no value.
-    emulated = os.environ.get("PLONK_ALLOW_HOSTEMU") == "1"
-    if emulated:
-        args.no_cpu_baseline = args.no_other_configs = True
-        if args.transport != "rccl":
-            raise SystemExit("bench.py under the host emulation: only the default in-library transport has a stand-in (tests/hostemu/comm_local.cpp)")
-    elif not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: no HIP device visible (the product path has no CPU fallback)")
-    if not emulated:
-        torch.cuda.set_device(local_rank)
-    pg_kwargs = dict(backend="gloo") if emulated else dict(backend="nccl", device_id=torch.device("cuda", local_rank))
-
-    def dev_sync():
-        if not emulated:
-            torch.cuda.synchronize()
-
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(**pg_kwargs)
-
-    from distributed_plonk_amd.dispatcher import RankProver, gather_points, split_rc
-    from distributed_plonk_amd.worker import PlonkWorker
-
-    n = 1 << args.log_n
-    m = 8 * n
-    nbig = 0 if args.n_domain_only else N_NTT_BIG          # size-8n transforms per step
-    if args.n_domain_only:
-        args.scheme, args.no_class_prover, args.no_next_rows, args.no_other_configs, args.no_cpu_baseline = "reference2d", True, True, True, True
-    S = world
-    sim = args.simulate_ranks if (world == 1 and args.simulate_ranks > 1) else 0
-    if sim:
-        S = sim
-    pl = plan(args, S)
-    if not pl["ok"]:
-        raise SystemExit("bench.py: " + "; ".join(pl["problems"]))
-    dev = torch.device("cpu") if emulated else torch.device("cuda", local_rank)
-    # N > 1: two contexts (two HIP streams) per rank, so that the all-to-all of one transform overlaps the
-    # row / column passes of the next (the 26 size-8n transforms of a proof are independent polynomials)
-    multi = S > 1 or args.multi_path
-    n_lanes = 2 if multi else 1
-    # always two contexts for the commitments: the 13 MSMs of a proof are independent, and a second stream fills the sort /
-    # reduction phases and the wave tail of one MSM with the bucket accumulation of the next (measured: 29.3 -> 26.8 ms per
-    # 2^24-point commit, 4.9 -> 4.0 ms at the 2^21 points of an 8-rank shard; tools/msm_overlap.py)
-    n_commit_lanes = max(2, int(os.environ.get("PLONK_BENCH_COMMIT_LANES", "2")))      # experiment knob; 2 is the measured choice
-    workers = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(n_commit_lanes)]
-    w = workers[0]
-    q64 = w.q64
-    if os.environ.get("PLONK_BENCH_MSM_WINDOW"):                 # experiment knob: force the Pippenger window (0 / unset: the library's cost model)
-        for x in workers:
-            x.set_option("msm_window", int(os.environ["PLONK_BENCH_MSM_WINDOW"]))
-    if os.environ.get("PLONK_BENCH_ACC_PERSIST") is not None:    # experiment knob: workgroups per CU of the persistent accumulation (0 = plain grid)
-        for x in workers:
-            x.set_option("msm_acc_persist", int(os.environ["PLONK_BENCH_ACC_PERSIST"]))
-    experiment_opts = {}
-    for kv in filter(None, os.environ.get("PLONK_BENCH_OPTS", "").split(",")):   # experiment knob: "key=value,..." through plonk_set_option on every context
-        k_, v_ = kv.split("=")                                                    # (e.g. msm_reduce_grid=1); recorded in config.experiment_opts
-        experiment_opts[k_.strip()] = int(v_)
-        for x in workers:
-            x.set_option(k_.strip(), int(v_))
-    noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if sim else None
-    transport = args.transport if (world > 1 or args.multi_path) else "torch"
-    rccl_info = None
-    if args.multi_path and world == 1 and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29655")
-        dist.init_process_group(rank=0, world_size=1, **pg_kwargs)
-    if (world > 1 or args.multi_path) and transport == "rccl" and not sim:
-        # one RCCL communicator per context (two streams -> two communicators), created in the same order on every rank; the
-        # 128-byte ids travel once through the launcher's rendezvous — nothing else of the data path touches torch
-        ids = [PlonkWorker.comm_unique_id() for _ in workers] if rank == 0 else [None] * len(workers)
-        dist.broadcast_object_list(ids, src=0)
-        for x, uid in zip(workers, ids):
-            x.comm_init(uid, rank, world)
-        r_, w_, v_ = w.comm_info()
-        rccl_info = {"rank0_reports_world": w_, "rccl_version": v_, "communicators_per_rank": len(workers)}
-    provers = [RankProver(x, rank, S, exchange=noop_exchange, transport=transport) for x in workers[:n_lanes]]
-
-    # ---- resident synthetic inputs (seeded; the reference uses thread_rng)
-    n_loc, m_loc = n // S, (m // S if nbig else 8)
-    # Every operation of a step has its OWN input (VERDICT r2: committing one scalar vector 13 times and transforming one polynomial
-    # 25 times cannot show a data-dependent defect): 7 vectors for the size-n iNTTs, 25 coefficient vectors for the forward coset
-    # FFTs, 13 scalar vectors for the commitments — 26 GiB at n = 2^24.  Above 2^26 (configs[4]: 8 GiB per vector) they are shared.
-    distinct_inputs = args.log_n <= 26
-    n_small_bufs = N_NTT_SMALL if distinct_inputs else n_lanes
-    buf_n = [[w.alloc(n_loc * 32), w.alloc(n_loc * 32)] for _ in range(max(n_small_bufs, n_lanes))]
-    buf_m = [[w.alloc(m_loc * 32), w.alloc(m_loc * 32)] for _ in range(n_lanes)]
-    for i, pair in enumerate(buf_n):
-        w.synth_fr(0xD15EA5E + 64 * rank + i, pair[0].ptr, n_loc)
-    for lane in range(n_lanes):
-        w.synth_fr(0xBADC0DE + 16 * rank + lane, buf_m[lane][0].ptr, m_loc)
-    n_scal = N_MSM if distinct_inputs else 2
-    scal = [w.alloc(n_loc * 32) for _ in range(n_scal)]          # commit_polynomial takes Montgomery coefficients (into_repr inside)
-    for i, b in enumerate(scal):
-        w.synth_fr(0x5CA1A5 + 64 * rank + i, b.ptr, n_loc)
-    # the coefficient vectors the 25 forward coset transforms start from: n + 3 coefficients (the blinded permutation polynomial's
-    # length; wires have n + 2, selectors n), which the reference zero-pads to 8n (dispatcher2.rs:746)
-    padded = (S == 1) and not multi and not args.dense_coset and nbig > 0
-    poly_len = n + 3
-    gen_limbs = None
-    polys = []
-    n_polys = (N_NTT_BIG - 1) if distinct_inputs else 1
-    if padded:
-        from distributed_plonk_amd import fr as _fr
-        gen_limbs = _fr.FIELDS[args.curve].to_limbs(_fr.FIELDS[args.curve].generator)
-        polys = [w.alloc(poly_len * 32) for _ in range(n_polys)]
-        for i, b in enumerate(polys):
-            w.synth_fr(0xC0EFF + i, b.ptr, poly_len)
-    bases = w.alloc(n_loc * 16 * q64)
-    # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
-    w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, bases.ptr)
-    for x in workers:
-        x.init_dev(bases.ptr, n_loc, n, m if nbig else 0)      # both contexts hold the SRS shard in the resident limb form
-        x.sync()
-
-    def ntt(lane, bufs, size, inv, coset, is_quot):
-        """one whole-vector / distributed transform; the pair ping-pongs (the next step transforms this step's output)"""
-        if S == 1:
-            w.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
-        else:
-            provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
-        bufs[0], bufs[1] = bufs[1], bufs[0]
-
-    # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
-    # c/8 + 1 coefficients can be non-zero (dispatcher2.rs:746, 754) — plonk_fft1_dev_compact
-    rows_compact, row_len_m = [], 0
-    if multi and not args.dense_coset and nbig:
-        r_m, c_m = split_rc(m)
-        row_len_m = (poly_len + r_m - 1) // r_m
-        rows_compact = [w.alloc((r_m // S) * row_len_m * 32) for _ in range(n_polys)]
-        for i, b in enumerate(rows_compact):
-            w.synth_fr(0xC0EFF + 64 * rank + i, b.ptr, (r_m // S) * row_len_m)
-
-    def coset_fft_8n(lane, i):
-        """quot_domain.coset_fft of polynomial i of the step (dispatcher2.rs:387-424)."""
-        if padded:
-            w.coset_eval_dev(polys[i % len(polys)].ptr, poly_len, m, gen_limbs, buf_m[lane][0].ptr)
-        elif rows_compact:
-            provers[lane].fft_dev(rows_compact[i % len(rows_compact)].ptr, buf_m[lane][1].ptr, m, True, False, True, out_layout=1, row_len=row_len_m)
-            buf_m[lane][0], buf_m[lane][1] = buf_m[lane][1], buf_m[lane][0]
-        else:
-            ntt(lane, buf_m[lane], m, False, True, True)
-
-    import threading
-
-    cworkers = workers
-
-    # The 13 commitments of a proof come in rounds (dispatcher2.rs:313-321 five wires, :352-358 the permutation product, :519-531
-    # five quotient parts, :690-697 two openings); the commitments of one round are independent and go through
-    # plonk_commit_many_dev as ONE Pippenger problem, split over the commit lanes.  PLONK_BENCH_COMMIT_BATCH=0: one MSM at a time.
-    commit_batch = os.environ.get("PLONK_BENCH_COMMIT_BATCH", "1") != "0"
-    use_lanes = min(n_commit_lanes, max(1, int(os.environ.get("PLONK_BENCH_COMMIT_USE_LANES", str(n_commit_lanes)))))
-    ROUNDS = (5, 1, 5, 2)
-
-    def commit_groups(count):
-        groups, at = [], 0
-        while at < count:
-            for r in ROUNDS:
-                r = min(r, count - at)
-                if r:
-                    groups.append((at, r))
-                    at += r
-        return groups
-
-    def commits_start(count):
-        """commitment i of the step takes scalar vector i"""
-        src = [scal[i % len(scal)].ptr for i in range(count)]
-        parts = [None] * count
-        errs = []
-
-        def run(lane):
-            try:
-                if commit_batch:
-                    for gi, (at, r) in enumerate(commit_groups(count)):
-                        # the odd polynomial of a round goes to another context every round (5 -> 3 + 2, then 1 -> 0 + 1, 5 -> 2 + 3, ...):
-                        # 7 + 6 commitments per step instead of 8 + 5, so neither context runs a long tail alone
-                        mine = list(range(at + (lane + gi) % use_lanes, at + r, use_lanes))
-                        if mine:
-                            pts = cworkers[lane].commit_many_dev([(src[i], n_loc) for i in mine])
-                            for j, i in enumerate(mine):
-                                parts[i] = pts[j]
-                    return
-                for i in range(lane, count, use_lanes):
-                    parts[i] = cworkers[lane].commit_dev(src[i], n_loc)
-            except BaseException as ex:     # noqa: BLE001 - re-raised on the main thread
-                errs.append(ex)
-
-        th = [threading.Thread(target=run, args=(lane,)) for lane in range(use_lanes)]
-        for t_ in th:
-            t_.start()
-        return th, parts, errs
-
-    def commits_finish(handle, all_parts=False):
-        th, parts, errs = handle
-        count = len(parts)
-        for t_ in th:
-            t_.join()
-        if errs:
-            raise errs[0]
-        if not multi or sim:
-            return parts if all_parts else parts[-1]
-        flat = np.concatenate(parts)                                         # one collective for all partial points
-        gathered = list(w.comm_allgather_host(flat, world)) if transport == "rccl" else gather_points(flat, None, dev)
-        acc = [None] * count
-        for p in gathered:                                                   # reduce(a + b) per commitment, on the host
-            for i in range(count):
-                pt = p[i * 3 * q64:(i + 1) * 3 * q64]
-                acc[i] = pt if acc[i] is None else w.g1_add(acc[i], pt)
-        return acc[-1]
-
-    phase = {"ntt": 0.0, "msm": 0.0}              # host-clock split of the step at its one internal sync point (this rank)
-
-    def step():
-        t_in = time.perf_counter()
-        for i in range(N_NTT_SMALL):
-            ntt(i % n_lanes, buf_n[i % len(buf_n)], n, True, False, False)
-        for i in range(nbig - 1):
-            coset_fft_8n(i % n_lanes, i)
-        if nbig:
-            ntt(0, buf_m[0], m, True, True, True)
-        for x in workers:
-            x.sync()
-        # (running the commitments concurrently with the transforms instead was measured: 977 vs 987 ms per step, not worth
-        #  distorting the per-launch NTT timings the roofline is computed from)
-        t_mid = time.perf_counter()
-        res = commits_finish(commits_start(N_MSM))
-        phase["ntt"] += t_mid - t_in
-        phase["msm"] += time.perf_counter() - t_mid
-        return res
-
-    # ---- N > 1, scheme "classes": the step with the coset-class decomposition (DESIGN.md §7).  Every rank holds the coefficient
-    # vectors (the size-n iNTTs that produce them run on every rank: 2.6 ms each, cheaper than gathering them), evaluates all 25
-    # polynomials on its OWN class of the 8n-point coset with a local zero-padding-aware (8n/N)-point transform, and the quotient's
-    # coset iFFT is the class-local inverse + one all-to-all (sum) + one all-gather.  Same work as the reference's 33 distributed
-    # transforms, two data-path collectives instead of 33.
-    cls = None
-    if multi and nbig:
-        from distributed_plonk_amd import fr as _fr
-        f_ = _fr.FIELDS[args.curve]
-        G = S
-        mL = m // G
-        cls = dict(
-            bn=[[w.alloc(n * 32), w.alloc(n * 32)] for _ in range(n_small_bufs)], polys=[w.alloc(poly_len * 32) for _ in range(n_polys)], out=w.alloc(mL * 32),
-            contrib=w.alloc(m * 32), recv=w.alloc(m * 32), mine=w.alloc(mL * 32), quot=w.alloc(m * 32),
-            shift=f_.to_limbs(f_.generator * pow(f_.root_of_unity(m), rank, f_.p) % f_.p), inv_g=f_.to_limbs(pow(G, -1, f_.p)),
-            ones=np.tile(f_.to_limbs(1), (G, 1)))
-        for i, pair in enumerate(cls["bn"]):                     # the same vectors on every rank
-            w.synth_fr(0xD15EA5E + i, pair[0].ptr, n)
-        for i, b in enumerate(cls["polys"]):
-            w.synth_fr(0xC0EFF + i, b.ptr, poly_len)
-        w.synth_fr(0x5EC7, cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
-
-    def step_classes():
-        t_in = time.perf_counter()
-        c = cls
-        for i in range(N_NTT_SMALL):
-            pair = c["bn"][i % len(c["bn"])]
-            w.ntt_dev(pair[0].ptr, pair[1].ptr, n, True, False)
-            pair[0], pair[1] = pair[1], pair[0]
-        for i in range(N_NTT_BIG - 1):
-            w.coset_eval_dev(c["polys"][i % len(c["polys"])].ptr, poly_len, mL, c["shift"], c["out"].ptr)
-        # quotient coefficients: this class's additive share of every coefficient, summed across ranks, then replicated
-        w.coset_interp_dev(c["out"].ptr, mL, c["shift"], c["inv_g"], 0, m, c["contrib"].ptr)
-        if not sim:
-            if transport == "rccl":
-                w.comm_alltoall_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
-            else:
-                torch_comm.all_to_all_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
-        w.poly_lincomb_dev([(c["recv"].ptr + p_ * mL * 32, mL) for p_ in range(G)], c["ones"], c["mine"].ptr, mL)
-        if not sim:
-            if transport == "rccl":
-                w.comm_allgather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
-            else:
-                torch_comm.all_gather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
-        for x in workers:
-            x.sync()
-        t_mid = time.perf_counter()
-        res = commits_finish(commits_start(N_MSM))
-        phase["ntt"] += t_mid - t_in
-        phase["msm"] += time.perf_counter() - t_mid
-        return res
-
-    torch_comm = None
-    if multi and transport == "torch" and not sim:
-        from distributed_plonk_amd.class_prover import TorchComm
-        torch_comm = TorchComm(w, None if emulated else dev)
-    scheme = args.scheme if multi else "single"
-    step_ref2d = step
-    if scheme == "classes":
-        step = step_classes
-
-    def full_sync():
-        for x in set(workers) | set(cworkers):
-            x.sync()
-        dev_sync()
-        if world > 1:
-            dist.barrier()
-
-    # N > 1: the warm-up and the timed steps run under a watchdog too (a hung collective must not hang the driver): generous budget
-    guard = ResultLine(json_fd, rank, None)
-    if world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
-        guard.start_watchdog()
-        guard.arm("headline", float(os.environ.get("PLONK_BENCH_HEADLINE_BUDGET_S", "900")))
-    for _ in range(args.warmup):
-        step()
-    full_sync()
-    w.profile_reset()
-    w.profile_enable(True)
-    phase["ntt"] = phase["msm"] = 0.0
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    full_sync()
-    dt = time.perf_counter() - t0
-    phases_ms = {"transforms": round(phase["ntt"] / args.steps * 1e3, 3), "commitments": round(phase["msm"] / args.steps * 1e3, 3),
-                 "note": "rank 0's host clock, split at the step's internal sync: the 33 transforms (with their exchanges), then the 13 commitments"}
-    w.profile_enable(False)
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    ms_per_step = dt / args.steps * 1e3
-    value = n / (dt / args.steps)
-
-    # ---- roofline of the dominant kernel (HIP events recorded around every launch in the timed region)
-    kernels = {}
-    for name in ["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order",
-                 "msm_accumulate_redo_kernel", "msm_heavy", "msm_reduce", "rccl_alltoall", "rccl_allgather"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)]:
-        ms, cnt = w.profile_get(name)
-        if cnt:
-            kernels[name] = {"total_ms": ms, "launches": int(cnt), "avg_ms": ms / cnt}
-    aff_bytes = 16 * q64
-    # algorithmic bytes (BASELINE.md §4): NTT(N) = 2*N*32 per transform, spread over its pass launches;
-    # MSM(n) = n*(sizeof(affine)+32) per MSM, attributed to the bucket-accumulation launch.
-    if scheme == "classes":      # per rank: the 7 size-n iNTTs in full (they run on every rank), its class (8n/N points) of the 26 big ones
-        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n + nbig * m_loc)
-    else:
-        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + nbig * m_loc)
-    msm_alg_total = args.steps * N_MSM * n_loc * (aff_bytes + 32.0)
-    # The 25 forward coset FFTs read n+3 coefficients, not 8n (the zeros the reference appends are never materialised): the least any
-    # implementation must move for them is (n+3 + 8n)*32 B, 9/16 of §8d's 2*8n*32.  `achieved`/`frac` keep §8d's definition (what the
-    # judge recomputes, comparable with rounds 1-2); `achieved_min_bytes`/`frac_min_bytes` price the same launches with this lower figure.
-    ntt_min_total = None
-    if (padded or rows_compact) and scheme != "classes" and nbig:
-        ntt_min_total = args.steps * 32.0 * (2 * N_NTT_SMALL * n_loc + (nbig - 1) * (poly_len / S + m_loc) + 2 * m_loc)
-    roof = {}
-    if "ntt_pass_kernel" in kernels:
-        k = kernels["ntt_pass_kernel"]
-        roof["ntt_pass_kernel"] = {"bytes_per_launch": ntt_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"],
-                                   "min_bytes_per_launch": ntt_min_total / k["launches"] if ntt_min_total else None}
-    if "msm_accumulate_kernel" in kernels:
-        k = kernels["msm_accumulate_kernel"]
-        roof["msm_accumulate_kernel"] = {"bytes_per_launch": msm_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"]}
-    # PMC-derived numbers (HBM traffic, VALU instruction counts) come from separate rocprofv3 counter runs of this same command,
-    # committed as profiles/pmc_current.json (tools/pmc_collect.py).  They are quoted ONLY when that file was collected from the
-    # kernel sources this library was built from (source hash) — or, per kernel, from byte-identical machine code — and for this
-    # workload; otherwise the fields stay null.
-    pmc, pmc_note = load_pmc(f"2^{args.log_n}@{args.curve}@{world}", args.dense_coset)
-
-    def valu_entry(name, avg_ms):
-        """The roofline that actually binds these kernels: VALU issue.  insts = SQ_INSTS_VALU per launch; issue_ms = insts * 4.5 clk /
-        (1024 SIMDs * 2.4 GHz), 4.5 clk being the measured issue interval of v_mad_u64_u32 and the VOP3 carry ops
-        (profiles/r01_valu_microbench.txt) and 2.4 GHz the peak clock (a lower sustained clock raises the fraction — rocm-smi beside the
-        running step shows 2.06-2.27 GHz at 1.25-1.36 kW, profiles/r02_clock_samples.txt; plain VOP2 issues faster, which lowers it)."""
-        ent = pmc.get(name)
-        if not ent or "SQ_INSTS_VALU" not in ent:
-            return None
-        insts = ent["SQ_INSTS_VALU"]
-        issue_ms = insts * 4.5 / (1024 * 2.4e9) * 1e3
-        return {"insts_per_launch": round(insts), "issue_ms_at_4.5clk": round(issue_ms, 3), "frac_of_launch": round(issue_ms / avg_ms, 3),
-                "source": "profiles/pmc_current.json (source- or machine-code-hash checked), profiles/r01_valu_microbench.txt"}
-
-    def roofline_entry(name):
-        r = roof[name]
-        achieved = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
-        tr = (pmc.get(name) or {}).get("traffic_bytes")
-        extra = {}
-        if r.get("min_bytes_per_launch"):
-            a_min = r["min_bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
-            extra = {"achieved_min_bytes": round(a_min, 2), "frac_min_bytes": round(a_min / HBM_PEAK_GBS, 5),
-                     "min_bytes_note": "the zero-padded coset FFTs priced at the (n+3 + 8n)*32 B they must move instead of SURVEY §8d's 2*8n*32 B"}
-        return {**extra, "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr, "traffic_note": pmc_note,
-                "algorithmic_bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": round(r["avg_ms"], 4),
-                "share_of_step": round(r["total_ms"] / (ms_per_step * args.steps), 3),
-                "valu_issue": valu_entry(name, r["avg_ms"])}
-
-    dominant = max(roof, key=lambda k: roof[k]["total_ms"]) if roof else None
-
-    # ---- the result line exists from here on: the headline is measured, everything below only ADDS fields to it.  N > 1 has never
-    # run on more than one real GPU (gpurun grants one), so the optional legs that follow run under a watchdog: should one of them
-    # hang in a collective, rank 0 still prints the headline (with `aborted_optional_leg` naming the leg) and every rank exits 0.
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "constraints/sec (proof-equivalent MSM+NTT hot path; BN254 PLONK)" if args.curve == "bn254"
-                      else "constraints/sec (proof-equivalent MSM+NTT hot path; BLS12-381 PLONK)",
-            "value": round(value, 1), "unit": "constraints/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 3), "phases_ms": phases_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if args.curve == "bn254" else "u32x8 Fr / u32x12 Fq Montgomery",
-            "data": "synthetic",
-            "config": {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if nbig else
-                                    f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
-                       "log_n": args.log_n, "curve": args.curve, "bases": args.bases,
-                       "scheme": scheme,
-                       "parallelism": (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
-                                       ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}")) if world == 1
-                                      else (f"{world} ranks, scheme {scheme}: " +
-                                            ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local "
-                                             "inverse + 1 all-to-all + 1 all-gather" if scheme == "classes" else "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs")) +
-                                            f"; index-sharded MSM + 1 point all-gather; transport {'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}"),
-                       "coset_inputs": ("n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if padded else
-                                        "n+3 coefficients on every rank, class-local zero-padding-aware transforms (plonk_coset_eval_dev)" if scheme == "classes" and multi else
-                                        "zero-padded decimated rows, ceil((n+3)/r) leading coefficients each (plonk_fft1_dev_compact)" if rows_compact else
-                                        "dense 8n (plonk_ntt_dev / distributed 2-D transform)"),
-                       "commit_batching": "plonk_commit_many_dev per prover round (5, 1, 5, 2), split over two contexts" if commit_batch else "one MSM per commitment",
-                       "rccl": rccl_info, **({"experiment_opts": experiment_opts} if experiment_opts else {})},
-            "roofline": roofline_entry(dominant) if dominant else None,
-            "roofline_other": [roofline_entry(k) for k in roof if k != dominant],
-            "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)}
-                        for k, v in sorted(kernels.items())},
-            "cpu_baseline": None, "other_scheme": None, "verified": None, "verification": None, "next_rows": None,
-        }
-        if multi and transport == "rccl":
-            # the exchanges of the timed region as rank 0's streams saw them (HIP events around each collective, waiting for the peers
-            # included).  Two lanes overlap a collective with the other lane's passes, so: exposed communication per step ~=
-            # phases_ms.transforms - (ntt_pass_kernel.total_ms / steps), bounded above by exchange.ms_per_step.
-            ex = {k_: kernels.get(k_) for k_ in ("rccl_alltoall", "rccl_allgather")}
-            tot = sum(v_["total_ms"] for v_ in ex.values() if v_)
-            ntt_ms = kernels.get("ntt_pass_kernel", {}).get("total_ms", 0.0) / args.steps
-            out["exchange"] = {"collectives": {k_: ({"launches_per_step": v_["launches"] / args.steps, "avg_ms": round(v_["avg_ms"], 4)} if v_ else None)
-                                               for k_, v_ in ex.items()},
-                               "ms_per_step_on_stream": round(tot / args.steps, 3),
-                               "transform_kernels_ms_per_step": round(ntt_ms, 3),
-                               "exposed_in_transform_phase_ms_per_step": round(max(phases_ms["transforms"] - ntt_ms, 0.0), 3),
-                               "note": "rank 0; HIP events on the issuing stream around each RCCL call; a collective's time includes waiting for "
-                                       "the slowest peer; exposed = host-clock transform phase minus the pass kernels' own time"}
-    if out is not None and emulated:
-        # a dry run of the control flow on the host emulation: whatever the clock said is not a measurement of anything
-        out.update(metric="EMULATED DRY RUN of bench.py's control flow (tests/hostemu, no GPU): NOT a measurement", value=None, ms_per_step=None,
-                   phases_ms=None, roofline=None, roofline_other=None, kernels=None, emulated=True)
-        out.pop("exchange", None)
+    b = Bench(args)
+    guard = ResultLine(json_fd, b.rank, None)
+    dt, phases_ms = headline.timed_steps(b, guard)
+    # ---- the result line exists from here on: the headline is measured, everything below only ADDS fields to it, each leg in its own
+    # try/except; on N > 1 (never run on more than one real GPU: gpurun grants one) also under a watchdog: should a leg hang in a
+    # collective, rank 0 still prints the headline (with `aborted_optional_leg` naming the leg) and every rank exits 0.
+    out = headline.result_line(b, dt, phases_ms)
     guard.arm(None, 0)
     guard.out = out
-    emit, arm = guard.emit, guard.arm
-    LEG_BUDGET_S = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
+    rank0 = b.rank == 0
+    LEG = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
+    multi, sim, nbig = b.multi, b.sim, b.nbig
 
-    # ---- N > 1: the OTHER scheme, two steps after one warm-up, outside `value` (both are always visible in one SCALE run)
-    other_scheme = None
+    other = None
     if multi and not sim and nbig:
-        arm("other_scheme", LEG_BUDGET_S)
-        try:
-            other = step_ref2d if scheme == "classes" else step_classes
-            other()
-            full_sync()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                other()
-            full_sync()
-            dt2 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dt2], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt2 = float(t.item())
-            other_scheme = {"scheme": "reference2d" if scheme == "classes" else "classes", "steps": 2, "ms_per_step": round(dt2 / 2 * 1e3, 3),
-                            "constraints_per_s": round(n / (dt2 / 2), 1),
-                            "note": "reference2d = all 33 transforms as the reference's 2-D distributed transform (33 RCCL all-to-alls per step; the 25 "
-                                    "forward coset FFTs take zero-padded rows, plonk_fft1_dev_compact, unless --dense-coset); classes = rank-local "
-                                    "coset classes, 2 data-path collectives per step"}
-        except Exception as ex:
-            other_scheme = {"error": repr(ex)}
-        arm(None, 0)
-        if rank == 0:
-            out["other_scheme"] = other_scheme
-
-
-    # ---- N > 1: polynomial-level parallelism (SURVEY.md §8e: "Alternative for N that fits one GPU: polynomial-level parallelism ... zero
-    # communication - report both"), two steps after one warm-up, outside `value`.  The 46 operations of a step are independent objects:
-    # every rank holds the whole SRS (1 GiB at 2^24; the reference replicates it too, dispatcher.rs:213-216) and takes WHOLE operations of
-    # the single-GPU step (poly_parallel_assignment: longest-processing-time-first) on the single-GPU step's own inputs, so the union over
-    # the ranks IS the single-GPU step.  No data-path collective; the 13 commitments reach rank 0 in one 1.2 KiB all-gather (the varMsm
-    # replies).  --simulate-ranks S: the most loaded rank's share on one GPU (compute only, nothing to simulate away but that gather).
+        other = run_leg(guard, "other_scheme", LEG, lambda: M.other_scheme(b))
+        if rank0:
+            out["other_scheme"] = other
     if multi and nbig and not args.no_poly_parallel:
-        arm("polynomial_parallel", LEG_BUDGET_S)
-        pp, pbufs, pw = {}, [], []
-        try:
-            from distributed_plonk_amd import fr as _frp
-            fp_ = _frp.FIELDS[args.curve]
-            mine_all, load = poly_parallel_assignment(S, nbig)
-            me_p = max(range(S), key=lambda r_: load[r_]) if sim else rank
-            my_ops = mine_all[me_p]
-            owner = {op: r_ for r_, ops_ in enumerate(mine_all) for op in ops_}
-            c_idx = [i for k_, i in my_ops if k_ == "commit"]
-            f_idx = [i for k_, i in my_ops if k_ == "coset_fft_8n"]
-            s_idx = [i for k_, i in my_ops if k_ == "intt_n"]
-            has_inv = ("coset_ifft_8n", 0) in my_ops
-            pw = [PlonkWorker(me=rank, device=local_rank, curve=args.curve) for _ in range(2)]
-            for k_, v_ in experiment_opts.items():
-                for x in pw:
-                    x.set_option(k_, v_)
-
-            def palloc(nbytes):
-                pbufs.append(pw[0].alloc(nbytes))
-                return pbufs[-1]
-
-            gen_p = fp_.to_limbs(fp_.generator)
-            tiled = 0 if args.bases == "distinct" else min(n, 1 << 11)
-            bases_full = palloc(n * 16 * q64)
-            pw[0].synth_bases(0x5EED, tiled, n, bases_full.ptr)                 # the single-GPU run's SRS, on every rank
-            for x in pw:
-                x.init_dev(bases_full.ptr, n, n, m)
-                x.sync()
-            p_scal, p_poly, p_small = {}, {}, {}
-            for i in c_idx:
-                p_scal[i] = palloc(n * 32)
-                pw[0].synth_fr(0x5CA1A5 + i, p_scal[i].ptr, n)
-            for i in f_idx:
-                p_poly[i] = palloc(poly_len * 32)
-                pw[0].synth_fr(0xC0EFF + i, p_poly[i].ptr, poly_len)
-            for i in s_idx:
-                p_small[i] = [palloc(n * 32), palloc(n * 32)]
-                pw[0].synth_fr(0xD15EA5E + i, p_small[i][0].ptr, n)
-            out_m = palloc(m * 32) if f_idx else None
-            inv_m = [palloc(m * 32), palloc(m * 32)] if has_inv else None
-            if has_inv:
-                pw[0].synth_fr(0xBADC0DE, inv_m[0].ptr, m)
-            pw[0].sync()
-
-            def pstep():
-                for i in s_idx:
-                    pair = p_small[i]
-                    pw[0].ntt_dev(pair[0].ptr, pair[1].ptr, n, True, False)
-                    pair[0], pair[1] = pair[1], pair[0]
-                for i in f_idx:
-                    pw[0].coset_eval_dev(p_poly[i].ptr, poly_len, m, gen_p, out_m.ptr)
-                if has_inv:
-                    pw[0].ntt_dev(inv_m[0].ptr, inv_m[1].ptr, m, True, True)
-                    inv_m[0], inv_m[1] = inv_m[1], inv_m[0]
-                pw[0].sync()
-                parts, errs = {}, []
-
-                def run(lane):
-                    try:
-                        mine_c = c_idx[lane::2]
-                        if mine_c:
-                            pts = pw[lane].commit_many_dev([(p_scal[i].ptr, n) for i in mine_c])
-                            for j, i in enumerate(mine_c):
-                                parts[i] = pts[j]
-                    except BaseException as ex_:     # noqa: BLE001 - re-raised below
-                        errs.append(ex_)
-
-                th = [threading.Thread(target=run, args=(lane,)) for lane in range(2)]
-                for t_ in th:
-                    t_.start()
-                for t_ in th:
-                    t_.join()
-                if errs:
-                    raise errs[0]
-                table = np.zeros((N_MSM, 3 * q64), dtype=np.uint64)
-                for i, pt in parts.items():
-                    table[i] = pt
-                if sim:
-                    return table
-                flat = table.reshape(-1)
-                gathered = list(w.comm_allgather_host(flat, world)) if transport == "rccl" else gather_points(flat, None, dev)
-                return np.stack([np.asarray(gathered[owner[("commit", i)]]).reshape(N_MSM, 3 * q64)[i] for i in range(N_MSM)])
-
-            def psync():
-                for x in pw:
-                    x.sync()
-                dev_sync()
-                if world > 1:
-                    dist.barrier()
-
-            pstep()
-            psync()
-            t1 = time.perf_counter()
-            for _ in range(2):
-                commits_tab = pstep()
-            psync()
-            dt3 = time.perf_counter() - t1
-            if world > 1:
-                t = torch.tensor([dt3], dtype=torch.float64, device=dev)
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                dt3 = float(t.item())
-
-            def every_rank(flag):
-                if world == 1:
-                    return bool(flag)
-                t_ = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(t_, op=dist.ReduceOp.MIN)
-                return bool(t_.item())
-
-            pv_ = {}
-            if not args.no_verify:
-                # (a) a forward coset FFT of this rank: sampled outputs against Horner evaluations by an unrelated kernel
-                ok = True
-                if f_idx:
-                    i0 = f_idx[0]
-                    w_m_ = fp_.root_of_unity(m)
-                    pw[0].coset_eval_dev(p_poly[i0].ptr, poly_len, m, gen_p, out_m.ptr)
-                    for k2 in (0, 1, 9, (12345 + i0) % m, m - 1):
-                        x_ = fp_.to_limbs(fp_.generator * pow(w_m_, k2, fp_.p) % fp_.p)
-                        ok &= bool(np.array_equal(out_m.download((1, 4), byte_offset=k2 * 32)[0], pw[0].poly_eval_dev(p_poly[i0].ptr, poly_len, x_)))
-                pv_["coset_fft_samples_vs_poly_eval_on_every_rank"] = every_rank(ok)
-                # (b) a commitment of this rank: the batched launch set against the single-MSM path on the other context
-                ok = True
-                if c_idx:
-                    a_, ai = pw[0].g1_to_affine(commits_tab[c_idx[0]])
-                    b_, bi = pw[1].g1_to_affine(pw[1].commit_dev(p_scal[c_idx[0]].ptr, n))
-                    ok = bool(ai == bi and np.array_equal(a_, b_))
-                pv_["commitment_batched_vs_single_msm_on_every_rank"] = every_rank(ok)
-                # (c) rank 0 recomputes a commitment that ANOTHER rank produced and compares it with what the gather delivered
-                ok = ok_exact = True
-                if not sim and world > 1 and rank == 0:
-                    j = next(i for i in range(N_MSM - 1, -1, -1) if owner[("commit", i)] != 0)
-                    tmp = palloc(n * 32)
-                    pw[0].synth_fr(0x5CA1A5 + j, tmp.ptr, n)
-                    a_, ai = pw[0].g1_to_affine(commits_tab[j])
-                    b_, bi = pw[0].g1_to_affine(pw[0].commit_dev(tmp.ptr, n))
-                    ok = bool(ai == bi and np.array_equal(a_, b_))
-                    # ... and against the exact expected point from the CPU oracle (small MSMs of the aggregated scalars, oracle/checks.py)
-                    from oracle import checks as _chk, oracle as _O
-                    cid_ = _O.CURVE_IDS[args.curve]
-                    sc_ = _O.from_mont(cid_, tmp.download((n, 4)))
-                    want_ = _chk.msm_expected_distinct(cid_, 0x5EED, sc_) if args.bases == "distinct" else _chk.msm_expected_tiled(cid_, 0x5EED, tiled, sc_)
-                    e_, ei = _O.jac_to_affine(cid_, want_)
-                    ok_exact = bool(ai == ei and np.array_equal(a_, e_))
-                    del sc_
-                if not sim and world > 1:
-                    pv_["gathered_commitment_of_another_rank_vs_recomputation_on_rank_0"] = every_rank(ok)
-                    pv_["gathered_commitment_of_another_rank_vs_oracle_exact"] = every_rank(ok_exact)
-            pp = {"scheme": "polynomial_parallel", "steps": 2, "ms_per_step": round(dt3 / 2 * 1e3, 3), "constraints_per_s": round(n / (dt3 / 2), 1),
-                  "ranks": S, "operations_per_rank": [{k_: sum(1 for o in ops_ if o[0] == k_) for k_ in POLY_OP_COST} for ops_ in mine_all],
-                  "modelled_load_ms_per_rank": [round(x, 1) for x in load],
-                  "data_path_collectives_per_step": 0, "result_collectives_per_step": 0 if sim else 1,
-                  "verified": (bool(pv_) and all(pv_.values())) if not args.no_verify else None, "verification": pv_ or None,
-                  "note": "whole operations per rank (longest-processing-time-first over the step's 13 commitments, 25 zero-padded 8n coset FFTs, "
-                          "the 8n coset iFFT and 7 size-n iNTTs), the whole SRS on every rank, the single-GPU step's inputs; the only collective "
-                          "is the 1.2 KiB all-gather that brings the 13 commitments to rank 0"
-                          + (f"; SIMULATED: the most loaded rank ({me_p}) of {S} on one GPU" if sim else "")}
-            if emulated:
-                pp.update(ms_per_step=None, constraints_per_s=None, modelled_load_ms_per_rank=None)
-        except Exception as ex:
-            pp = {"scheme": "polynomial_parallel", "error": repr(ex)}
-        finally:
-            for b in pbufs:
-                try:
-                    b.free()
-                except Exception:       # noqa: BLE001 - best-effort release of a diagnostic leg's buffers
-                    pass
-            for x in pw:
-                try:
-                    x.close()
-                except Exception:       # noqa: BLE001
-                    pass
-        arm(None, 0)
-        if rank == 0:
+        pp = run_leg(guard, "polynomial_parallel", LEG, lambda: M.polynomial_parallel(b), error=lambda ex: {"scheme": "polynomial_parallel", "error": repr(ex)})
+        if rank0:
             out["polynomial_parallel"] = pp
             if not sim:
                 # the three ways to spread the step over the ranks, side by side (`value` is always the first: the reference's scheme)
-                out["schemes_ms_per_step"] = {scheme: out.get("ms_per_step"),
-                                              **({other_scheme["scheme"]: other_scheme.get("ms_per_step")} if other_scheme and "scheme" in other_scheme else {}),
+                out["schemes_ms_per_step"] = {b.scheme: out.get("ms_per_step"), **({other["scheme"]: other.get("ms_per_step")} if other and "scheme" in other else {}),
                                               "polynomial_parallel": pp.get("ms_per_step")}
-
-    # ---- N > 1 (and --multi-path): the distributed code path that was just timed, checked on every rank against a single-rank
-    # recomputation with the whole-vector path (which tests/ and the N = 1 run check against the oracle): one size-n inverse transform
-    # and one zero-padded 8n coset FFT through row pass -> RCCL all-to-all -> column pass, and a sharded commitment through the point
-    # all-gather.  Outside the timed region, under the watchdog.
     if multi and not sim and not args.no_verify:
-        arm("verify_multi", LEG_BUDGET_S)
-        mv = {}
-        try:
-            from distributed_plonk_amd.dispatcher import _DevPtr
-            from distributed_plonk_amd import fr as _fr2
-
-            def dev_i64(ptr, nbytes):
-                if emulated:                      # "device" memory of the emulation is host memory
-                    import ctypes
-                    return torch.frombuffer((ctypes.c_char * nbytes).from_address(ptr), dtype=torch.int64)
-                return torch.as_tensor(_DevPtr(ptr, nbytes), device=dev)
-
-            def all_ranks(flag):
-                if world == 1:
-                    return bool(flag)
-                t_ = torch.tensor([1 if flag else 0], dtype=torch.int32, device=dev)
-                dist.all_reduce(t_, op=dist.ReduceOp.MIN)
-                return bool(t_.item())
-
-            tmp_bufs = []
-
-            def talloc(nbytes):
-                tmp_bufs.append(w.alloc(nbytes))
-                return tmp_bufs[-1]
-
-            # (a) iNTT of size n: X[j*r + b] -> this rank's decimated rows are rows of the transposed [c][r] matrix
-            r_n, c_n = split_rc(n)
-            full, ref, rowsT, outn = talloc(n * 32), talloc(n * 32), talloc(n * 32), talloc(n_loc * 32)
-            w.synth_fr(0x7E57, full.ptr, n)                                   # the same whole vector on every rank
-            w.transpose_dev(full.ptr, rowsT.ptr, c_n, r_n)
-            provers[0].fft_dev(rowsT.ptr + rank * (r_n // S) * c_n * 32, outn.ptr, n, False, True, False, out_layout=1)
-            w.ntt_dev(full.ptr, ref.ptr, n, True, False)
-            w.sync()
-            dev_sync()
-            got = dev_i64(outn.ptr, n_loc * 32).view(r_n, c_n // S, 4)
-            want = dev_i64(ref.ptr, n * 32).view(r_n, c_n, 4)[:, rank * (c_n // S):(rank + 1) * (c_n // S), :]
-            mv["distributed_intt_n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
-            if nbig:
-                # (b) the zero-padded 8n coset FFT from compact rows (plonk_fft1_dev_compact) vs plonk_coset_eval_dev of the whole polynomial
-                f2 = _fr2.FIELDS[args.curve]
-                r_m, c_m = split_rc(m)
-                L = (poly_len + r_m - 1) // r_m
-                p_pad, rows_m, refm = talloc(r_m * L * 32), talloc(r_m * L * 32), talloc(m * 32)
-                w.memset_dev(p_pad.ptr, 0, r_m * L * 32)
-                w.synth_fr(0x7E58, p_pad.ptr, poly_len)
-                w.transpose_dev(p_pad.ptr, rows_m.ptr, L, r_m)                # [L][r_m] -> [r_m][L]: row b = coefficients b, b + r_m, ...
-                outm = buf_m[0][1]
-                provers[0].fft_dev(rows_m.ptr + rank * (r_m // S) * L * 32, outm.ptr, m, True, False, True, out_layout=1, row_len=L)
-                w.coset_eval_dev(p_pad.ptr, poly_len, m, f2.to_limbs(f2.generator), refm.ptr)
-                w.sync()
-                dev_sync()
-                got = dev_i64(outm.ptr, m_loc * 32).view(r_m, c_m // S, 4)
-                want = dev_i64(refm.ptr, m * 32).view(r_m, c_m, 4)[:, rank * (c_m // S):(rank + 1) * (c_m // S), :]
-                mv["distributed_zero_padded_coset_fft_8n_vs_single_rank_every_element"] = all_ranks(torch.equal(got, want))
-            # (c) a round of two sharded commitments through the point all-gather vs every shard recomputed on THIS rank
-            got_pt = w.g1_to_affine(commits_finish(commits_start(2)))
-            chk = PlonkWorker(me=rank, device=local_rank, curve=args.curve)
-            try:
-                tb, ts = talloc(n_loc * 16 * q64), talloc(n_loc * 32)
-                acc = None
-                for r_ in range(world):
-                    chk.synth_bases(0x5EED + r_, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, tb.ptr)
-                    chk.init_dev(tb.ptr, n_loc, 0, 0)
-                    chk.synth_fr(0x5CA1A5 + 64 * r_ + (1 % len(scal)), ts.ptr, n_loc)
-                    part = chk.commit_dev(ts.ptr, n_loc)
-                    acc = part if acc is None else chk.g1_add(acc, part)
-                want_pt = chk.g1_to_affine(acc)
-            finally:
-                chk.close()
-            mv["sharded_commitment_vs_all_shards_on_one_rank"] = all_ranks(want_pt[1] == got_pt[1] and np.array_equal(want_pt[0], got_pt[0]))
-            for b in tmp_bufs:
-                b.free()
-        except Exception as ex:
-            mv["error"] = repr(ex)
-        arm(None, 0)
-        if rank == 0:
+        mv = run_leg(guard, "verify_multi", LEG, lambda: M.verify_multi(b))
+        if rank0:
             out["verification"] = mv
             out["verified"] = bool(mv) and "error" not in mv and all(mv.values())
 
-    # ---- result checks, after and outside the timed region (rank 0, N == 1): the oracle as CHECKER of what was just timed
-    verified, verification = None, None
-    if rank == 0 and world == 1 and not multi and not sim and not args.no_verify:
-        verification = {}
-        try:
-            from oracle import checks, oracle as O
-            cid = O.CURVE_IDS[args.curve]
-            f_ = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-            # (1) a whole ROUND of five commitments of the timed configuration (same bases, the step's first five DISTINCT scalar vectors,
-            #     same two-lane code path: both contexts run a BATCHED problem, three and two vectors, at full size), each against
-            #     the exact expected point from small oracle MSMs of its aggregated scalars (oracle/checks.py)
-            got5 = commits_finish(commits_start(5), all_parts=True)
-            ok = True
-            for j, got in enumerate(got5):
-                sc = O.from_mont(cid, scal[j % len(scal)].download((n, 4)))
-                want = (checks.msm_expected_distinct(cid, 0x5EED, sc) if args.bases == "distinct"
-                        else checks.msm_expected_tiled(cid, 0x5EED, min(n, 1 << 11), sc))
-                e_, ei = O.jac_to_affine(cid, want)
-                g_, gi = w.g1_to_affine(got)
-                ok &= bool(gi == ei and np.array_equal(g_, e_))
-                del sc
-            verification["commit_round_of_5_distinct_vectors_vs_oracle_exact"] = ok
-            # (2) 8n coset FFTs as timed, three different polynomials of the step: sampled outputs against Horner evaluations by an
-            #     unrelated kernel (plonk_poly_eval_dev, itself oracle-checked in tests/); for the last one the coset iFFT must also
-            #     return the zero-padded coefficients everywhere
-            CH = 1 << 22
-            if not nbig:
-                pass                                   # --n-domain-only: there is no 8n transform to check
-            elif padded:
-                w_m = f_.root_of_unity(m)
-                ok = True
-                picks = sorted({0, len(polys) // 2, len(polys) - 1})
-                for pi_ in picks:
-                    buf_p = polys[pi_]
-                    w.coset_eval_dev(buf_p.ptr, poly_len, m, gen_limbs, buf_m[0][0].ptr)
-                    for k_ in (0, 1, 8, 9, (12345 + pi_) % m, (5 * n + 3) % m, m - 1):
-                        x_ = f_.to_limbs(f_.generator * pow(w_m, k_, f_.p) % f_.p)
-                        ok &= bool(np.array_equal(buf_m[0][0].download((1, 4), byte_offset=k_ * 32)[0], w.poly_eval_dev(buf_p.ptr, poly_len, x_)))
-                verification["coset_fft_samples_vs_poly_eval_3_polys"] = ok
-                w.ntt_dev(buf_m[0][0].ptr, buf_m[0][1].ptr, m, True, True)
-                back = buf_m[0][1]
-                ok = bool(np.array_equal(back.download((poly_len, 4)), buf_p.download((poly_len, 4))))
-                for off in range(poly_len * 32, m * 32, CH * 32):
-                    nb = min(CH * 32, m * 32 - off)
-                    ok &= not back.download((nb // 8,), byte_offset=off).any()
-                verification["coset_fft_round_trip_every_element"] = ok
-            else:
-                w.synth_fr(0xBADC0DE, buf_m[0][0].ptr, m)
-                keep = w.alloc(m * 32)
-                w.memcpy_d2d(keep.ptr, buf_m[0][0].ptr, m * 32)
-                w.ntt_dev(buf_m[0][0].ptr, buf_m[0][1].ptr, m, False, True)
-                w.ntt_dev(buf_m[0][1].ptr, buf_m[0][0].ptr, m, True, True)
-                ok = True
-                for off in range(0, m, CH):
-                    cnt = min(CH, m - off)
-                    ok &= bool(np.array_equal(buf_m[0][0].download((cnt, 4), byte_offset=off * 32), keep.download((cnt, 4), byte_offset=off * 32)))
-                keep.free()
-                verification["coset_fft_round_trip_every_element"] = ok
-            # (3) a size-n iNTT as timed: NTT(iNTT(x)) == x everywhere (and against the oracle itself when n is small enough)
-            w.synth_fr(0xD15EA5E, buf_n[0][0].ptr, n)
-            ref = buf_n[0][0].download((n, 4))
-            w.ntt_dev(buf_n[0][0].ptr, buf_n[0][1].ptr, n, True, False)
-            w.ntt_dev(buf_n[0][1].ptr, buf_n[0][0].ptr, n, False, False)
-            verification["intt_n_round_trip_every_element"] = bool(np.array_equal(buf_n[0][0].download((n, 4)), ref))
-            if n <= (1 << 20):                     # small enough for the oracle to transform directly
-                buf_n[0][0].upload(ref)
-                w.ntt_dev(buf_n[0][0].ptr, buf_n[0][1].ptr, n, True, False)
-                verification["intt_n_vs_oracle"] = bool(np.array_equal(buf_n[0][1].download((n, 4)), O.ntt(cid, ref, True, False, threads=O.max_threads())))
-            verified = all(verification.values())
-        except Exception as ex:                     # a failed check must be visible, never fatal to the measurement
-            verification["error"] = repr(ex)
-            verified = False
-        out["verified"], out["verification"] = verified, verification
-
-    # ---- next row (SURVEY §8f rank 1), measured on its own, NOT part of `value`: quotient coset evaluations over 8n points
-    next_rows = None
-    if rank == 0 and world == 1 and not multi and not sim and not args.no_next_rows:
-        try:
-            vecs = [w.alloc(m * 32) for _ in range(25)]
-            for j, b in enumerate(vecs):
-                w.synth_fr(0xABC + j, b.ptr, m)
-            ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 3
-            ptr = [b.ptr for b in vecs]
-            w.profile_enable(True)
-            for it in range(2):
-                w.profile_reset()
-                w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], buf_m[0][1].ptr)
-                w.sync()
-            qms, _ = w.profile_get("quotient_evals_kernel")
-            w.profile_enable(False)
-            alg = 27.0 * 32 * m                     # 26 vector reads (z twice) + 1 write per point
-            next_rows = {"quotient_evals_kernel": {"points": m, "ms": round(qms, 3), "bound": "hbm", "achieved": round(alg / qms / 1e6, 1),
-                                                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(alg / qms / 1e6 / HBM_PEAK_GBS, 4),
-                                                   "algorithmic_bytes": alg, "reference": "dispatcher2.rs:435-504"}}
-            for b in vecs:
-                b.free()
-        except Exception as ex:                     # the extra row must never break the headline measurement
-            next_rows = {"error": str(ex)}
-        # ---- next rows (ranks 2-3) + everything above chained as the reference's five prover rounds (dispatcher2.rs:296-712) on a
-        # SATISFIED synthetic circuit generated in HBM, with the merlin transcript, the quotient-degree check ON, and the finished
-        # proof handed to a verifier — the reference's own end-to-end test (dispatcher2.rs:1273-1295) at BASELINE's size.
-        # Reported under next_rows and as top-level proof_ms; NOT part of `value`.
-        try:
-            from distributed_plonk_amd.prover import Prover
-            from distributed_plonk_amd.synthetic import SyntheticInstance
-            from distributed_plonk_amd.transcript import PlonkTranscript
-            fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-            TAU = 0x2F0D5EED0C0FFEE0123456789ABCDEF0FEDCBA98765432100F1E2D3C4B5A697 % fld.p      # the trapdoor this run publishes
-            t0 = time.perf_counter()
-            inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, helpers=workers[1:2])
-            for x in workers[:2]:
-                x.sync()
-            t_gen = (time.perf_counter() - t0) * 1e3
-            consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-            bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-            pv = Prover(w, args.log_n, commit_helper=workers[1])
-            pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-            pub = inst.public_inputs()
-            t0 = time.perf_counter()
-            vk = pv.verifying_key()                                           # preprocess: 18 commitments, once per key
-            t_vk = (time.perf_counter() - t0) * 1e3
-            proof = None
-            for it in range(2):
-                fs = pv.fiat_shamir(pub)
-                t0 = time.perf_counter()
-                proof = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=True)
-                t_prove = (time.perf_counter() - t0) * 1e3
-            rounds = {k_: round(v_, 2) for k_, v_ in pv.timings.items()}
-            # ---- the proof just timed, checked: (a) accepted by the pairing-free verifier for the trapdoor SRS (oracle/verifier_ref.py:
-            # pure-Python integers, its own Fiat-Shamir) — every one of the 13 + 18 commitments, the 10 evaluations and both openings
-            # enter that equation; (b) three of the proof's commitments re-derived as f(tau)*G and three evaluations re-derived by the
-            # CPU oracle's Horner from the polynomials the prover holds; (c) a flipped evaluation must be rejected.
-            pver = {}
-            if not args.no_verify:
-                try:
-                    from oracle import bigint_ref as B_, oracle as O, verifier_ref as V_
-                    cid = O.CURVE_IDS[args.curve]
-                    cv = B_.CURVES[args.curve]
-                    t0 = time.perf_counter()
-                    res = V_.verify(cv, vk, pub, proof, TAU, transcript=PlonkTranscript(args.curve))
-                    pver["accepted_by_verifier"] = True
-                    pver["verifier_and_prover_drew_the_same_challenges"] = all(np.array_equal(res["challenges"][k_], fs.drawn[k_]) for k_ in fs.drawn)
-                    bad = [x.copy() for x in proof["wires_evals"]]
-                    bad[1][0] ^= np.uint64(1)
-                    try:
-                        V_.verify(cv, vk, pub, dict(proof, wires_evals=bad), TAU, transcript=PlonkTranscript(args.curve))
-                        pver["flipped_evaluation_rejected"] = False
-                    except V_.VerificationError:
-                        pver["flipped_evaluation_rejected"] = True
-                    tau_l, zeta_l = fld.to_limbs(TAU), fs.drawn["zeta"]
-                    zeta_w = fld.to_limbs(fld.from_limbs(zeta_l) * fld.root_of_unity(n) % fld.p)
-                    lp = pv.last_polys
-                    ok_c = ok_e = True
-                    for (ptr, ln), comm, ev_pt, ev_want in ((lp["wire_polys"][2], proof["wires_poly_comms"][2], zeta_l, proof["wires_evals"][2]),
-                                                            (lp["perm_poly"], proof["prod_perm_poly_comm"], zeta_w, proof["perm_next_eval"]),
-                                                            (lp["split_quot_polys"][4], proof["split_quot_poly_comms"][4], None, None),
-                                                            ((inst.sig_ptrs[1], n), vk["sigma_comms"][1], zeta_l, proof["wire_sigma_evals"][1])):
-                        poly = pv._download(ptr, ln)
-                        f_tau = O.from_mont(cid, O.poly_eval(cid, poly, tau_l).reshape(1, 4))[0]
-                        want = O.jac_to_affine(cid, O.scalar_mul(cid, O.generator(cid), f_tau))
-                        ok_c &= bool(want[1] == comm[1] and np.array_equal(want[0], comm[0]))
-                        if ev_pt is not None:
-                            ok_e &= bool(np.array_equal(O.poly_eval(cid, poly, ev_pt), ev_want))
-                        del poly
-                    pver["commitments_equal_f_of_tau_times_G_by_cpu_horner_4_checked"] = ok_c
-                    pver["evaluations_equal_cpu_horner_3_checked"] = ok_e
-                    pver["check_s"] = round(time.perf_counter() - t0, 1)
-                except Exception as ex:
-                    pver["error"] = repr(ex)
-            prover_verified = (bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s")) if not args.no_verify else None
-            # the O(n) rows on their own (HIP events inside the library), with their algorithmic HBM bytes
-            ch = {k_: fs.drawn[k_] for k_ in ("beta", "gamma", "alpha", "zeta", "v")}
-            w.profile_enable(True)
-            w.profile_reset()
-            out_n = w.alloc((n + 3) * 32)
-            w.perm_product_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, ch["beta"], ch["gamma"], n, out_n.ptr)
-            w.poly_eval_dev(inst.wev[0], n, ch["zeta"])
-            w.poly_lincomb_dev([(ptr_, n) for ptr_ in inst.sel_ptrs + inst.sig_ptrs] + [(inst.wev[0], n), (inst.wev[1], n)],
-                               np.tile(consts[:4], (5, 1)), out_n.ptr, n)
-            w.poly_div_linear_dev(inst.wev[0], n, ch["zeta"], out_n.ptr)
-            w.sync()
-
-            def row(names, alg_bytes, ref):
-                ms = sum(w.profile_get(k_)[0] for k_ in names)
-                return {"ms": round(ms, 3), "bound": "hbm", "achieved": round(alg_bytes / ms / 1e6, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(alg_bytes / ms / 1e6 / HBM_PEAK_GBS, 4), "algorithmic_bytes": alg_bytes, "reference": ref}
-
-            small = {
-                "perm_product": row(["perm_terms_kernel", "perm_scan_num", "perm_scan_den_final"], n * (16 * 32 + 5 * 8.0), "dispatcher2.rs:329-344"),
-                "poly_eval": row(["poly_eval_kernel"], n * 32.0, "dispatcher2.rs:545-555"),
-                "poly_lincomb_20_terms": row(["poly_lincomb_kernel"], n * 21 * 32.0, "dispatcher2.rs:566-633"),
-                "poly_div_linear": row(["poly_scale_kernel", "poly_div_scan"], n * 64.0, "dispatcher2.rs:651-666"),
-            }
-            w.profile_enable(False)
-            out_n.free()
-            pv.close()
-            # variants of the same rounds (identical proofs): the quotient from 6 cosets of H_n instead of the 8n-point domain,
-            # and/or the 18 proving-key evaluation vectors kept resident across proofs (72 / 54 GiB at 2^24)
-            variants = {}
-            same_as_headline_proof = lambda pr: bool(all(np.array_equal(pr[k_][0], proof[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof"))
-                                                     and np.array_equal(np.stack(pr["wires_evals"]), np.stack(proof["wires_evals"])))
-            for vname, kw in (("resident_key_cosets", dict(cache_key_cosets=True)),
-                              ("six_cosets", dict(quotient_mode="classes6")),
-                              ("six_cosets_resident_key", dict(quotient_mode="classes6", cache_key_cosets=True))):
-                try:
-                    pvc = Prover(w, args.log_n, commit_helper=workers[1], **kw)
-                    pvc.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-                    pvc._key["vk"] = vk                                          # same key: the 18 commitments are not repeated
-                    t_v = pr = None
-                    for it in range(2):
-                        fsv = pvc.fiat_shamir(pub)
-                        t0 = time.perf_counter()
-                        pr = pvc.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fsv, check_degree=True)
-                        t_v = (time.perf_counter() - t0) * 1e3
-                    variants[vname] = {"ms": round(t_v, 2), "constraints_per_s": round(n / t_v * 1e3, 1),
-                                       "rounds_ms": {k_: round(v_, 2) for k_, v_ in pvc.timings.items()},
-                                       "same_proof_as_the_verified_one": same_as_headline_proof(pr)}
-                    pvc.close()
-                except Exception as ex:
-                    variants[vname] = {"error": str(ex)}
-            next_rows = dict(next_rows or {})
-            next_rows.update(small)
-            next_rows["prover_rounds"] = {
-                "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
-                "rounds_ms": rounds,
-                "prover_verified": prover_verified, "prover_verification": pver,
-                "setup_ms": {"circuit_key_and_trapdoor_srs_generation": round(t_gen, 1), "verifying_key_18_commitments": round(t_vk, 1)},
-                "variants": variants,
-                "reference": "dispatcher2.rs:296-712 (rounds 1-5: 13 commitments, 7 NTT(n), 26 NTT(8n), permutation product, quotient, "
-                             "10 evaluations, linearisation, 2 openings), end-to-end test dispatcher2.rs:1273-1295",
-                "note": "a random SATISFIED TurboPlonk circuit generated in HBM (plonk_synth_circuit: uniform witness and selectors, q_c solved per "
-                        "gate, copy constraints = n cycles of length 5 between pseudo-random gates), commit key tau^i*G with a published trapdoor "
-                        "(plonk_synth_srs), challenges from the merlin transcript (host Python, ~7 ms inside the timed proof), "
-                        "WrongQuotientPolyDegree check ON.  Variants produce the same proof: resident_key_cosets skips the 18 selector/sigma coset "
-                        "NTTs per proof (proving-key data); six_cosets interpolates the degree-(5n+7) quotient from 6n evaluations"}
-            inst.close()
-        except Exception as ex:
-            next_rows = dict(next_rows or {})
-            next_rows["prover_rounds"] = {"error": repr(ex)}
-
-    # ---- the five prover rounds on ALL ranks with the coset-class decomposition (class_prover.py): the same satisfied synthetic
-    # instance on every rank (generated in HBM from the seed), the commit key sharded over the ranks (dispatcher2.rs:260-266), real
-    # transcript on every rank, degree check on; rank 0 hands the proof to the trapdoor verifier.  Default for N > 1.
-    # --simulate-ranks S: rank 0's share of an S-rank proof on ONE GPU with no-op collectives (garbage proof, compute time only).
-    def release_step_buffers():
-        """the op-mix step's vectors (tens of GiB at 2^24) are not needed after the legs above; the class prover wants the room"""
-        for pair in buf_n + buf_m:
-            for b in pair:
-                b.free()
-        for b in polys + rows_compact + scal:
-            b.free()
-        if cls is not None:
-            for k_ in ("out", "contrib", "recv", "mine", "quot"):
-                if cls[k_] is not None:
-                    cls[k_].free()
-            for b in cls["polys"] + [x for pair in cls["bn"] for x in pair]:
-                b.free()
-            cls["polys"], cls["bn"] = [], []
-            for k_ in ("out", "contrib", "recv", "mine", "quot"):
-                cls[k_] = None
-        del buf_n[:], buf_m[:], polys[:], rows_compact[:], scal[:]
-
+    single = rank0 and b.world == 1 and not multi and not sim
+    next_rows = _single_gpu_legs(b, out, args) if single else None
     class_row = None
     if (args.class_prover or multi or sim) and not args.no_class_prover and nbig:
-        arm("class_prover", 2 * LEG_BUDGET_S)
-        try:
-            release_step_buffers()
-            from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
-            from distributed_plonk_amd.synthetic import SyntheticInstance
-            from distributed_plonk_amd.transcript import PlonkTranscript
-            if world == 1 and not dist.is_initialized() and not sim:
-                os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-                os.environ.setdefault("MASTER_PORT", "29653")
-                dist.init_process_group(rank=0, world_size=1, **pg_kwargs)
-            fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-            TAU = 0x2F0D5EED0C0FFEE0123456789ABCDEF0FEDCBA98765432100F1E2D3C4B5A697 % fld.p
-            G_, r_ = (sim, 0) if sim else (world, rank)
-            inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, init_worker=False)
-            klo, khi = key_shard_range(inst.key_size, r_, G_)                                     # a rank KEEPS only its slice of the key
-            for x in workers[:2]:
-                x.init_dev(inst.d_ck.ptr + klo * 16 * q64, khi - klo, n, m)
-            consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-            bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-
-            class SimComm:
-                """rank 0 of `size` ranks with nobody else there: collectives return at once (diagnostic timing only)"""
-                rank, size = 0, G_
-
-                def all_gather_host(self, obj):
-                    return [obj] * self.size
-
-                def all_to_all_dev(self, d_send, d_recv, nbytes):
-                    pass
-
-                def all_gather_dev(self, d_send, d_recv, nbytes):
-                    pass
-
-            if sim:
-                comm = SimComm()
-            elif transport == "rccl" and multi:
-                def _boot(obj):
-                    out_ = [None] * world
-                    dist.all_gather_object(out_, obj)
-                    return out_
-                comm = LibComm(w, bootstrap=_boot)
-            else:
-                comm = TorchComm(w, None if emulated else dev)
-            cp = ClassProver(w, args.log_n, comm, commit_helper=workers[1], key_range=(klo, khi))
-            cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-            pub = inst.public_inputs()
-            vk = cp.verifying_key()                                                               # 18 sharded commitments, once per key
-            t_cls, proof_c = None, None
-            for it in range(2):
-                fs = cp.fiat_shamir(pub)
-                full_sync()
-                t0 = time.perf_counter()
-                proof_c = cp.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=not sim)
-                full_sync()
-                t_cls = (time.perf_counter() - t0) * 1e3
-            if world > 1:
-                tt = torch.tensor([t_cls], dtype=torch.float64, device=dev)
-                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-                t_cls = float(tt.item())
-            cverified = None
-            if rank == 0 and not sim and not args.no_verify:
-                try:
-                    from oracle import bigint_ref as B_, verifier_ref as V_
-                    V_.verify(B_.CURVES[args.curve], vk, pub, proof_c, TAU, transcript=PlonkTranscript(args.curve))
-                    cverified = True
-                except Exception as ex:
-                    cverified = f"REJECTED: {ex!r}"
-            class_row = {"n": n, "ranks": G_, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
-                         "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
-                         "accepted_by_verifier": cverified,
-                         "simulated": bool(sim),
-                         "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round), "
-                                                  "4 all-gathers of 32-byte partials (evaluations, degree, two openings)",
-                         "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
-            cp.close()
-            inst.close()
-        except Exception as ex:        # every rank raises or none does (same sizes everywhere); the headline must survive either way
-            class_row = {"error": repr(ex)}
-        arm(None, 0)
-
-    # ---- CPU baseline (oracle = C restatement of the reference's arkworks path), bounded sample.  The reference builds ark-poly
-    # WITHOUT its "parallel" feature and ark-ec WITH it (Cargo.toml:31-34): its NTTs are single-threaded, its MSM runs its
-    # windows on the rayon pool.  `value` is that configuration; the all-threads OpenMP NTT of the oracle is reported beside it.
+        class_row = run_leg(guard, "class_prover", 2 * LEG, lambda: M.class_prover(b))   # every rank raises or none does (same sizes everywhere)
     cpu = None
-    if rank == 0 and world == 1 and not multi and not sim and not args.no_cpu_baseline:
-        from oracle import oracle as O
-        cid = O.CURVE_IDS[args.curve]
-        ls = min(args.cpu_sample_log_n, args.log_n)
-        ns = 1 << ls
-        thr = O.max_threads()
-        v = O.rand_fr(cid, 1, ns)
-        vb = O.rand_fr(cid, 2, 8 * ns)
-        hb = np.empty((ns, 2 * q64), dtype=np.uint64)
-        import ctypes as C
-        from distributed_plonk_amd._ffi import check
-        check(w.lib.plonk_memcpy_d2h(w.ctx, hb.ctypes.data_as(C.c_void_p), bases.ptr, hb.nbytes))
-
-        def timed(fn):
-            t = time.perf_counter()
-            fn()
-            return time.perf_counter() - t
-
-        t_ntt_par = timed(lambda: O.ntt(cid, v, True, False, threads=thr))
-        t_ntt8_par = timed(lambda: O.ntt(cid, vb, False, True, threads=thr))
-        t_ntt_1 = timed(lambda: O.ntt(cid, v, True, False, threads=1))
-        t_ntt8_1 = timed(lambda: O.ntt(cid, vb, False, True, threads=1))
-        t_msm = timed(lambda: O.commit_polynomial(cid, hb, v, threads=thr))
-        t_step = N_NTT_SMALL * t_ntt_1 + N_NTT_BIG * t_ntt8_1 + N_MSM * t_msm
-        t_step_par = N_NTT_SMALL * t_ntt_par + N_NTT_BIG * t_ntt8_par + N_MSM * t_msm
-        cpu = {"value": round(ns / t_step, 1), "unit": "constraints/s", "cores": thr, "kind": "port",
-               "sample": f"oracle (C restatement of ark-poly/ark-ec 0.3.0) at n=2^{ls}, each op of the step run ONCE in full and combined "
-                         f"with the per-proof op mix 7/26/13: iNTT(n) {t_ntt_1*1e3:.0f} ms and coset-NTT(8n) {t_ntt8_1*1e3:.0f} ms on 1 thread "
-                         f"(the reference's ark-poly has no `parallel` feature, Cargo.toml:31), commit(n) {t_msm*1e3:.0f} ms on {thr} threads "
-                         f"(ark-ec `parallel`: windows on the rayon pool).  `value` is this 2^{ls} measurement; the estimate for the GPU line's "
-                         f"size is in extrapolated_to_bench_size",
-               "all_threads_ntt": {"value": round(ns / t_step_par, 1), "iNTT_n_ms": round(t_ntt_par * 1e3, 1), "coset_NTT_8n_ms": round(t_ntt8_par * 1e3, 1),
-                                   "note": "the oracle's OpenMP NTT on every host thread - faster than the reference's build would be"},
-               "host_cores_online": os.cpu_count()}
-        if args.log_n > ls:
-            # labelled extrapolation to the GPU line's size (BASELINE.md §3 allows it): radix-2 NTT cost per element grows with log2 of
-            # the size ((log n + 3) / (ls + 3) for the 8n transforms, log n / ls for the n ones); Pippenger's cost per point is taken as
-            # constant (it falls slightly with n: larger windows).  An estimate, not a measurement.
-            up = 1 << (args.log_n - ls)
-            t_ext = up * (N_NTT_SMALL * t_ntt_1 * args.log_n / ls + N_NTT_BIG * t_ntt8_1 * (args.log_n + 3) / (ls + 3) + N_MSM * t_msm)
-            cpu["extrapolated_to_bench_size"] = {"log_n": args.log_n, "value": round(n / t_ext, 1), "unit": "constraints/s", "s_per_step": round(t_ext, 1),
-                                                 "note": f"EXTRAPOLATED from the 2^{ls} sample above with the operation counts of radix-2 NTT (n log n) and "
-                                                         f"Pippenger (linear in n at a fixed window): not measured at 2^{args.log_n}"}
-
-    if rank == 0:
+    if single and not args.no_cpu_baseline:
+        from benchlib.cpu_baseline import cpu_baseline
+        cpu = run_leg(None, "cpu_baseline", None, lambda: cpu_baseline(b))
+    if rank0:
         out["cpu_baseline"] = cpu
         out["next_rows"] = dict(next_rows or {}, class_prover=class_row) if class_row else next_rows
-        # the REAL proof at top level (BASELINE's metric is "proof-gen ms"): the five rounds of dispatcher2.rs:296-712 on the 8n route
-        # with the proving key NOT resident — the reference's work — on the satisfied synthetic circuit, verified; `value` stays on
-        # the SURVEY §8d op mix for continuity with rounds 1-2.  Same-proof variants beside it, labelled.
-        pr = (next_rows or {}).get("prover_rounds") or {}
-        if "ms" in pr:
-            out["proof_ms"] = pr["ms"]
-            out["proof_constraints_per_s"] = pr["constraints_per_s"]
-            out["prover_verified"] = pr.get("prover_verified")
-            out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms)": pr["ms"]},
-                                            **{{"resident_key_cosets": "8n_route_key_coset_vectors_resident_in_HBM",
-                                                "six_cosets": "six_coset_quotient_key_not_resident",
-                                                "six_cosets_resident_key": "six_coset_quotient_key_resident"}[k_]: v_.get("ms")
-                                               for k_, v_ in (pr.get("variants") or {}).items()})
-        if class_row and "ms" in class_row:
-            out["proof_ms_class_prover_all_ranks"] = class_row["ms"]
-    if world > 1:
-        emit()                                   # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
-        arm("teardown", 120.0)
-    if buf_n or buf_m:
-        release_step_buffers()
-    bases.free()
-    for x in workers:
-        x.close()
-    if dist.is_initialized():
-        dist.destroy_process_group()
-    if rank == 0:
-        # ---- BASELINE.json's other single-GPU configurations, each as its own short run of this script AFTER the headline
-        # measurement has released the GPU (never part of `value`): configs[1] and configs[3]
-        if world == 1 and not multi and not sim and not args.no_other_configs and args.log_n == 24 and args.curve == "bn254" and not args.dense_coset:
-            import subprocess
-            other = []
-            for label, extra in (("configs[1]: 2^20-gate BN254, 1 GPU", ["--log-n", "20", "--curve", "bn254"]),
-                                 ("configs[3]: 2^22-gate BLS12-381, 1 GPU", ["--log-n", "22", "--curve", "bls12_381"])):
-                cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", args.bases,
-                       "--no-cpu-baseline", "--no-next-rows", "--no-other-configs"] + extra
-                try:
-                    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
-                    d_ = json.loads(res.stdout.decode().strip().splitlines()[-1])
-                    rf = d_.get("roofline") or {}
-                    other.append({"config": label, "ms_per_step": d_["ms_per_step"], "constraints_per_s": d_["value"], "steps": d_["steps"],
-                                  "dominant_kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_ms": rf.get("avg_launch_ms"),
-                                  "verified": d_.get("verified"), "verification": d_.get("verification")})
-                except Exception as ex:             # the extra lines must never break the headline
-                    other.append({"config": label, "error": repr(ex)})
-            out["other_configs"] = other
-    emit()
+        _proof_fields(out, next_rows, class_row)
+    if b.world > 1:
+        guard.emit()                             # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
+        guard.arm("teardown", 120.0)
+    b.close()
+    if single and not args.no_other_configs and args.log_n == 24 and args.curve == "bn254" and not args.dense_coset:
+        from benchlib.other_configs import other_configs
+        out["other_configs"] = run_leg(None, "other_configs", None, lambda: other_configs(args), error=lambda ex: [{"error": repr(ex)}])
+    guard.emit()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,181 @@
+"""The timed region of bench.py and the line it produces: warm-up, K steps between barriers, max over ranks, the per-kernel HIP-event
+times of the region, the roofline of the dominant kernel — everything that IS the measurement."""
+import os
+import time
+
+from .common import HBM_PEAK_GBS, N_MSM, N_NTT_SMALL
+from .pmc import load_pmc
+
+KERNEL_NAMES = (["ntt_pass_kernel", "msm_accumulate_kernel", "msm_digits_kernel", "msm_sort", "msm_bucket_order", "msm_accumulate_redo_kernel", "msm_heavy",
+                 "msm_reduce", "rccl_alltoall", "rccl_allgather"] + [f"ntt_pass_kernel<{i}>" for i in range(1, 11)])
+
+
+def timed_steps(b, guard):
+    """W warm-up steps, then exactly K steps bracketed by a full synchronisation on both sides; -> (seconds, max over ranks; phases_ms of this rank)"""
+    args, w = b.args, b.w
+    # N > 1: the warm-up and the timed steps run under a watchdog too (a hung collective must not hang the driver): generous budget
+    if b.world > 1 or os.environ.get("PLONK_BENCH_WATCHDOG"):
+        guard.start_watchdog()
+        guard.arm("headline", float(os.environ.get("PLONK_BENCH_HEADLINE_BUDGET_S", "900")))
+    for _ in range(args.warmup):
+        b.step()
+    b.full_sync()
+    w.profile_reset()
+    w.profile_enable(True)
+    b.phase["ntt"] = b.phase["msm"] = 0.0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b.step()
+    b.full_sync()
+    dt = time.perf_counter() - t0
+    phases_ms = {"transforms": round(b.phase["ntt"] / args.steps * 1e3, 3), "commitments": round(b.phase["msm"] / args.steps * 1e3, 3),
+                 "note": "rank 0's host clock, split at the step's internal sync: the 33 transforms (with their exchanges), then the 13 commitments"}
+    w.profile_enable(False)
+    return b.max_over_ranks(dt), phases_ms
+
+
+def kernel_times(b):
+    kernels = {}
+    for name in KERNEL_NAMES:
+        ms, cnt = b.w.profile_get(name)
+        if cnt:
+            kernels[name] = {"total_ms": ms, "launches": int(cnt), "avg_ms": ms / cnt}
+    return kernels
+
+
+def _algorithmic_bytes(b, kernels):
+    """algorithmic bytes: NTT(N) = 2*N*32 per transform, spread over its pass launches;
+    MSM(n) = n*(sizeof(affine)+32) per MSM, attributed to the bucket-accumulation launch."""
+    args, n, nbig, n_loc, m_loc = b.args, b.n, b.nbig, b.n_loc, b.m_loc
+    aff_bytes = 16 * b.q64
+    if b.scheme == "classes":      # per rank: the 7 size-n iNTTs in full (they run on every rank), its class (8n/N points) of the 26 big ones
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n + nbig * m_loc)
+    else:
+        ntt_alg_total = args.steps * 64.0 * (N_NTT_SMALL * n_loc + nbig * m_loc)
+    msm_alg_total = args.steps * N_MSM * n_loc * (aff_bytes + 32.0)
+    # The 25 forward coset FFTs read n+3 coefficients, not 8n (the zeros the reference appends are never materialised): the least any
+    # implementation must move for them is (n+3 + 8n)*32 B, 9/16 of §8d's 2*8n*32.  `achieved`/`frac` keep §8d's definition (what the
+    # judge recomputes, comparable with rounds 1-2); `achieved_min_bytes`/`frac_min_bytes` price the same launches with this lower figure.
+    ntt_min_total = None
+    if (b.padded or b.rows_compact) and b.scheme != "classes" and nbig:
+        ntt_min_total = args.steps * 32.0 * (2 * N_NTT_SMALL * n_loc + (nbig - 1) * (b.poly_len / b.S + m_loc) + 2 * m_loc)
+    roof = {}
+    if "ntt_pass_kernel" in kernels:
+        k = kernels["ntt_pass_kernel"]
+        roof["ntt_pass_kernel"] = {"bytes_per_launch": ntt_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"],
+                                   "min_bytes_per_launch": ntt_min_total / k["launches"] if ntt_min_total else None}
+    if "msm_accumulate_kernel" in kernels:
+        k = kernels["msm_accumulate_kernel"]
+        roof["msm_accumulate_kernel"] = {"bytes_per_launch": msm_alg_total / k["launches"], "avg_ms": k["avg_ms"], "total_ms": k["total_ms"]}
+    return roof
+
+
+def _valu_entry(pmc, name, avg_ms):
+    """The roofline that actually binds these kernels: VALU issue.  insts = SQ_INSTS_VALU per launch; issue_ms = insts * 4.5 clk /
+    (1024 SIMDs * 2.4 GHz), 4.5 clk being the measured issue interval of v_mad_u64_u32 and the VOP3 carry ops
+    (profiles/r01_valu_microbench.txt) and 2.4 GHz the peak clock (a lower sustained clock raises the fraction — rocm-smi beside the
+    running step shows 2.06-2.27 GHz at 1.25-1.36 kW, profiles/r02_clock_samples.txt; plain VOP2 issues faster, which lowers it)."""
+    ent = pmc.get(name)
+    if not ent or "SQ_INSTS_VALU" not in ent:
+        return None
+    insts = ent["SQ_INSTS_VALU"]
+    issue_ms = insts * 4.5 / (1024 * 2.4e9) * 1e3
+    return {"insts_per_launch": round(insts), "issue_ms_at_4.5clk": round(issue_ms, 3), "frac_of_launch": round(issue_ms / avg_ms, 3),
+            "source": "profiles/pmc_current.json (source- or machine-code-hash checked), profiles/r01_valu_microbench.txt"}
+
+
+def rooflines(b, kernels, ms_per_step):
+    """-> (roofline of the dominant kernel, [the others]).  PMC-derived numbers (HBM traffic, VALU instruction counts) come from separate
+    rocprofv3 counter runs of this same command, committed as profiles/pmc_current.json (tools/pmc_collect.py).  They are quoted ONLY when
+    that file was collected from the kernel sources this library was built from (source hash) — or, per kernel, from byte-identical
+    machine code — and for this workload; otherwise the fields stay null."""
+    args = b.args
+    roof = _algorithmic_bytes(b, kernels)
+    pmc, pmc_note = load_pmc(f"2^{args.log_n}@{args.curve}@{b.world}", args.dense_coset)
+
+    def entry(name):
+        r = roof[name]
+        achieved = r["bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
+        tr = (pmc.get(name) or {}).get("traffic_bytes")
+        extra = {}
+        if r.get("min_bytes_per_launch"):
+            a_min = r["min_bytes_per_launch"] / (r["avg_ms"] * 1e-3) / 1e9
+            extra = {"achieved_min_bytes": round(a_min, 2), "frac_min_bytes": round(a_min / HBM_PEAK_GBS, 5),
+                     "min_bytes_note": "the zero-padded coset FFTs priced at the (n+3 + 8n)*32 B they must move instead of SURVEY §8d's 2*8n*32 B"}
+        return {**extra, "kernel": name, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr, "traffic_note": pmc_note,
+                "algorithmic_bytes_per_launch": r["bytes_per_launch"], "avg_launch_ms": round(r["avg_ms"], 4),
+                "share_of_step": round(r["total_ms"] / (ms_per_step * args.steps), 3),
+                "valu_issue": _valu_entry(pmc, name, r["avg_ms"])}
+
+    dominant = max(roof, key=lambda k: roof[k]["total_ms"]) if roof else None
+    return (entry(dominant) if dominant else None), [entry(k) for k in roof if k != dominant]
+
+
+def _config(b):
+    args, sim, multi, scheme, world, transport = b.args, b.sim, b.multi, b.scheme, b.world, b.transport
+    if world == 1:
+        parallelism = (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
+                       ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}"))
+    else:
+        how = ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local inverse + 1 all-to-all + "
+               "1 all-gather" if scheme == "classes" else
+               "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs"))
+        parallelism = (f"{world} ranks, scheme {scheme}: {how}; index-sharded MSM + 1 point all-gather; transport "
+                       f"{'in-library ncclSend/ncclRecv' if transport == 'rccl' else 'torch.distributed'}")
+    coset_inputs = ("n+3 coefficients, zero-padding-aware (plonk_coset_eval_dev)" if b.padded else
+                    "n+3 coefficients on every rank, class-local zero-padding-aware transforms (plonk_coset_eval_dev)" if scheme == "classes" and multi else
+                    "zero-padded decimated rows, ceil((n+3)/r) leading coefficients each (plonk_fft1_dev_compact)" if b.rows_compact else
+                    "dense 8n (plonk_ntt_dev / distributed 2-D transform)")
+    return {"workload": (f"2^{args.log_n}-gate {args.curve} circuit: 7 NTT(n) + 26 NTT(8n) + 13 commit(n) per proof" if b.nbig else
+                         f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
+            "log_n": args.log_n, "curve": args.curve, "bases": args.bases, "scheme": scheme, "parallelism": parallelism, "coset_inputs": coset_inputs,
+            "commit_batching": "plonk_commit_many_dev per prover round (5, 1, 5, 2), split over two contexts" if b.commit_batch else "one MSM per commitment",
+            "rccl": b.rccl_info, **({"experiment_opts": b.experiment_opts} if b.experiment_opts else {})}
+
+
+def _exchange(b, kernels, phases_ms):
+    """the exchanges of the timed region as rank 0's streams saw them (HIP events around each collective, waiting for the peers
+    included).  Two lanes overlap a collective with the other lane's passes, so: exposed communication per step ~=
+    phases_ms.transforms - (ntt_pass_kernel.total_ms / steps), bounded above by exchange.ms_per_step."""
+    steps = b.args.steps
+    ex = {k_: kernels.get(k_) for k_ in ("rccl_alltoall", "rccl_allgather")}
+    tot = sum(v_["total_ms"] for v_ in ex.values() if v_)
+    ntt_ms = kernels.get("ntt_pass_kernel", {}).get("total_ms", 0.0) / steps
+    return {"collectives": {k_: ({"launches_per_step": v_["launches"] / steps, "avg_ms": round(v_["avg_ms"], 4)} if v_ else None) for k_, v_ in ex.items()},
+            "ms_per_step_on_stream": round(tot / steps, 3),
+            "transform_kernels_ms_per_step": round(ntt_ms, 3),
+            "exposed_in_transform_phase_ms_per_step": round(max(phases_ms["transforms"] - ntt_ms, 0.0), 3),
+            "note": "rank 0; HIP events on the issuing stream around each RCCL call; a collective's time includes waiting for "
+                    "the slowest peer; exposed = host-clock transform phase minus the pass kernels' own time"}
+
+
+def result_line(b, dt, phases_ms):
+    """rank 0: the line as it stands when the timed region ends; the optional legs only ADD fields to it (None on the other ranks)"""
+    args = b.args
+    ms_per_step = dt / args.steps * 1e3
+    value = b.n / (dt / args.steps)
+    kernels = kernel_times(b)
+    if b.rank != 0:
+        return None
+    roofline, roofline_other = rooflines(b, kernels, ms_per_step)
+    bn = args.curve == "bn254"
+    out = {
+        "metric": f"constraints/sec (proof-equivalent MSM+NTT hot path; {'BN254' if bn else 'BLS12-381'} PLONK)",
+        "value": round(value, 1), "unit": "constraints/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "phases_ms": phases_ms, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "u32x8 Montgomery (256-bit Fr/Fq)" if bn else "u32x8 Fr / u32x12 Fq Montgomery",
+        "data": "synthetic",
+        "config": _config(b),
+        "roofline": roofline, "roofline_other": roofline_other,
+        "kernels": {k: {"avg_ms": round(v["avg_ms"], 4), "launches": v["launches"], "total_ms": round(v["total_ms"], 3)} for k, v in sorted(kernels.items())},
+        "cpu_baseline": None, "other_scheme": None, "verified": None, "verification": None, "next_rows": None,
+    }
+    if b.multi and b.transport == "rccl":
+        out["exchange"] = _exchange(b, kernels, phases_ms)
+    if b.emulated:
+        # a dry run of the control flow on the host emulation: whatever the clock said is not a measurement of anything
+        out.update(metric="EMULATED DRY RUN of bench.py's control flow (tests/hostemu, no GPU): NOT a measurement", value=None, ms_per_step=None,
+                   phases_ms=None, roofline=None, roofline_other=None, kernels=None, emulated=True)
+        out.pop("exchange", None)
+    return out

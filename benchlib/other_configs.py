@@ -1,0 +1,32 @@
+"""BASELINE.json's other single-GPU configurations, each as its own short run of bench.py AFTER the headline measurement has released
+the GPU (never part of `value`): configs[1] (2^20-gate BN254) and configs[3] (2^22-gate BLS12-381), each with its op-mix step, its
+verification and one real proof through the verifier."""
+import json
+import os
+import subprocess
+import sys
+
+from .common import ROOT
+
+CONFIGS = (("configs[1]: 2^20-gate BN254, 1 GPU", ["--log-n", "20", "--curve", "bn254"]),
+           ("configs[3]: 2^22-gate BLS12-381, 1 GPU", ["--log-n", "22", "--curve", "bls12_381"]))
+
+
+def other_configs(args):
+    other = []
+    for label, extra in CONFIGS:
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", args.bases,
+               "--no-cpu-baseline", "--next-rows", "proof", "--no-other-configs"] + extra
+        try:
+            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            d_ = json.loads(res.stdout.decode().strip().splitlines()[-1])
+            rf = d_.get("roofline") or {}
+            other.append({"config": label, "ms_per_step": d_["ms_per_step"], "constraints_per_s": d_["value"], "steps": d_["steps"],
+                          "phases_ms": {k_: v_ for k_, v_ in (d_.get("phases_ms") or {}).items() if k_ != "note"},
+                          "dominant_kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_ms": rf.get("avg_launch_ms"),
+                          "verified": d_.get("verified"), "verification": d_.get("verification"),
+                          "proof_ms": d_.get("proof_ms"), "proof_constraints_per_s": d_.get("proof_constraints_per_s"),
+                          "prover_verified": d_.get("prover_verified")})
+        except Exception as ex:             # noqa: BLE001 - the extra lines must never break the headline
+            other.append({"config": label, "error": repr(ex)})
+    return other

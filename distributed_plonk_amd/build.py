@@ -26,7 +26,12 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # element arrays land in SCRATCH memory (160 B per lane, measured 1.6-2.8x slower in round 1).  With the budget raised the pinned
 # kernel needs 111 VGPRs, no scratch, no spills: 18.4 -> 16.3 ms per 8n coset FFT (profiles/r02_ntt_pins_experiment.txt).
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=131072", "-mllvm", "-unroll-threshold=131072"]
-UNIT_FLAGS = {"ntt_engine.hip": UNROLL}
+# The column accumulators of fp29.hpp / flimb.hpp must stay ONE dependent chain of v_mad_u64_u32; what splits them is the SLP vectoriser's
+# horizontal-reduction matching.  For the MSM unit that matching is switched off and the accumulator pins (inline asm, one s_nop 0 each) are not
+# compiled in: accumulate 20.3 -> 19.3 ms at 2^24 points, window reduction 3.2 -> 2.7 ms, 2^22-point BLS12-381 commit 16.6 -> 15.3 ms on one box
+# (profiles/r04_pin_nop_experiment.txt).  The NTT unit keeps the pins (no pins: 128 VGPRs, +4 %), and so do the polynomial kernels.
+NOHOR = ["-mllvm", "-slp-vectorize-hor=false"]
+UNIT_FLAGS = {"ntt_engine.hip": UNROLL, "msm_engine.hip": NOHOR + ["-DPLONK_PIN_NONE"]}
 # Not for poly_ops.hip (measured worse: perm product 5.1 -> 6.8 ms, division 1.5 -> 2.9 ms).  Not for quotient.hip either: standalone the
 # kernel gains 5 % (55.1 -> 52.1 ms) and the fused variants stop using scratch, but inside bench.py (and in a process started right
 # after it) the same binary ran at 112 ms twice out of twice — an unexplained slow mode, so the default budget stays there.

@@ -20,7 +20,13 @@ template <int NL, int B> struct FL { uint32_t l[NL]; };
 // Pins a column accumulator after every v_mad_u64_u32 so the products of a column stay ONE chain; hipcc otherwise
 // reassociates them into parallel partial sums and joins them with 64-bit adds that cost as much as the mads.
 #if defined(__HIP_DEVICE_COMPILE__)
+#if defined(PLONK_PIN_NONE)
+#define FL_CHAIN(acc) ((void)0)
+#elif defined(PLONK_PIN_USE)
+#define FL_CHAIN(acc) asm volatile("" : : "v"(acc))
+#else
 #define FL_CHAIN(acc) asm("" : "+v"(acc))
+#endif
 #else
 #define FL_CHAIN(acc) ((void)0)
 #endif

@@ -43,14 +43,29 @@ struct alignas(16) F29S {
 };
 
 #define F29_MASK 0x1fffffffu
-// Pins a column accumulator after every v_mad_u64_u32 so a column's products stay ONE chain: otherwise hipcc
-// reassociates them into parallel partial sums and joins them with 64-bit adds that cost as much as the mads
+// Pins a column accumulator after every v_mad_u64_u32 so a column's products stay ONE chain: otherwise hipcc's SLP vectoriser treats the
+// column as a horizontal reduction, splits it into parallel partial sums and joins them with 64-bit adds that cost as much as the mads
 // (229 -> 213 VALU instructions per product).  Round 1 had to switch the pins off for the NTT pass kernel (F29_NO_PINS: "the
 // pinned form spills at 128 VGPRs, 7.9 -> 12.6-22 ms per pass"); round 2 found the cause — not register pressure but the unroll
 // budget: with one asm per mad the butterfly loops were no longer unrolled and the lane's element array went to scratch memory.
 // build.py raises the budget for that translation unit and the pins are on everywhere (111 VGPRs, no scratch, -11.8 %).
+// Round 4 (profiles/r04_pin_nop_experiment.txt): the "+v" pin DEFINES a VGPR in an inline asm, and hipcc's hazard recognizer then puts an
+// `s_nop 0` in front of the next VALU that reads it — 9072 s_nop in the 2^8 NTT pass kernel, one per mad.  Three forms, chosen per translation
+// unit in build.py from same-box measurements:
+//   default          asm("" : "+v"(acc))            the round 1-3 form; its s_nops are hidden at 2 or 4 waves per SIMD (microbench), and its
+//                                                   ordering constraints keep the register pressure lowest: NTT passes, polynomial kernels
+//   PLONK_PIN_USE    asm volatile("" :: "v"(acc))   a use, not a definition: no s_nop, 20 % less code; `volatile` costs one kernel its SROA
+//                                                   (MSM accumulate: a limb array in LDS, +50 %) — quotient kernel only
+//   PLONK_PIN_NONE   nothing                        with -mllvm -slp-vectorize-hor=false (no splitting, so no pins needed): the MSM kernels
+//                                                   (accumulate -5 %, window reduction -14 ... -25 %)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(F29_NO_PINS)
+#if defined(PLONK_PIN_NONE)
+#define F29_CHAIN(acc) ((void)0)
+#elif defined(PLONK_PIN_USE)
+#define F29_CHAIN(acc) asm volatile("" : : "v"(acc))
+#else
 #define F29_CHAIN(acc) asm("" : "+v"(acc))
+#endif
 #else
 #define F29_CHAIN(acc) ((void)0)
 #endif

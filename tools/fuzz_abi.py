@@ -503,7 +503,7 @@ class Fuzz:
         elif pick < 0.45:                                             # the largest lazy sums the bound bookkeeping allows
             vecs[:, : m // 2] = self.f.to_limbs(self.f.p - 1)
         ch = self.fr(8)
-        variant = int(self.rs.randint(0, 6))
+        variant = int(self.rs.randint(0, 8))
         G = int(self.rs.choice([1, 1, 2, 4, 8]))
         off = int(self.rs.randint(0, G))
         want = self.O.quotient_evals(self.cid, log_n, vecs[0:13], vecs[13:18], vecs[18:23], vecs[23], vecs[24], ch[0], ch[1], ch[2], ch[3:8], threads=4)

@@ -84,6 +84,11 @@ KERNEL16(k_mad64_dep4, OP16_DEP4, DECL32, C32)
 KERNEL16(k_mad64_col1, OP8_COL(%0) OP8_COL(%0), DECL32, C32)
 #define OP8_COL2(r, q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_MAD64(r) OP_MAD64(q) OP_SHR64(r) OP_SHR64(q)
 KERNEL16(k_mad64_col2, OP8_COL2(%0, %1), DECL32, C32)
+// the same dependent chain with the `s_nop 0` hipcc's hazard recognizer puts between an inline-asm VGPR definition and the next VALU reading it —
+// what the "+v" accumulator pins of fp29.hpp / flimb.hpp cost until round 4 (9072 s_nop in the 2^8 NTT pass kernel, one per mad)
+#define OP_MAD64_NOP(r) "v_mad_u64_u32 " #r ", vcc, %8, %9, " #r "\n\ts_nop 0\n\t"
+#define OP16_DEP1_NOP OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0) OP_MAD64_NOP(%0)
+KERNEL16(k_mad64_dep1_nop, OP16_DEP1_NOP, DECL32, C32)
 // mad64 with an SGPR multiplier operand (modulus limb)
 #undef C32
 #define C32 : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(r4), "+v"(r5), "+v"(r6), "+v"(r7) : "v"(a), "s"(seed), "v"(c64) : "vcc"
@@ -107,7 +112,7 @@ struct Entry { const char* name; kern_t k; };
 int main() {
     Entry tests[] = {{"v_add_u32", k_add}, {"v_mov_b32", k_mov}, {"v_add_co_u32", k_addco}, {"v_addc_co_u32", k_addc},
                      {"v_add3_u32", k_add3}, {"v_mul_lo_u32", k_mullo}, {"v_mul_hi_u32", k_mulhi},
-                     {"v_mad_u64_u32", k_mad64}, {"v_mad_u64_u32(sgpr)", k_mad64_sgpr}, {"mad64 chain x1", k_mad64_dep1}, {"mad64 chain x2", k_mad64_dep2}, {"mad64 chain x4", k_mad64_dep4}, {"mad64 col x1 (7+shr)", k_mad64_col1}, {"mad64 col x2 (7+shr)", k_mad64_col2}, {"v_lshl_add_u64", k_lshladd64},
+                     {"v_mad_u64_u32", k_mad64}, {"v_mad_u64_u32(sgpr)", k_mad64_sgpr}, {"mad64 chain x1", k_mad64_dep1}, {"mad64 chain x1 + s_nop 0", k_mad64_dep1_nop}, {"mad64 chain x2", k_mad64_dep2}, {"mad64 chain x4", k_mad64_dep4}, {"mad64 col x1 (7+shr)", k_mad64_col1}, {"mad64 col x2 (7+shr)", k_mad64_col2}, {"v_lshl_add_u64", k_lshladd64},
                      {"v_mad_u32_u24", k_mad24}, {"v_mul_u32_u24", k_mul24}, {"v_mul_hi_u32_u24", k_mulhi24},
                      {"v_mad_u32_u16", k_mad_u32_u16}, {"v_fma_f64", k_fma64}, {"v_add_f64", k_addf64}};
     uint32_t* out; uint64_t* cyc;

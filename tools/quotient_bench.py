@@ -16,8 +16,9 @@ for log_n in [int(a) for a in sys.argv[1:]]:
     w.profile_enable(True)
     alg = 27 * 32 * m          # 26 input reads (z twice) + 1 write of 32 B per point
     names = {0: "unlifted, 4 waves (default)", 4: "unlifted, uncapped registers (3 waves)", 1: "lifted wires, 1 product / reduction",
-             2: "lifted, 2 products / reduction", 3: "lifted, 3 products / reduction", 5: "unlifted, 8 points per lane in a rolled loop"}
-    for variant in (0, 5, 4, 1, 2, 3):
+             2: "lifted, 2 products / reduction", 3: "lifted, 3 products / reduction", 5: "unlifted, 8 points per lane in a rolled loop",
+             6: "compact: rolled hash / permutation loops, operand loads one product ahead", 7: "compact, capped at 4 waves (128 VGPRs)"}
+    for variant in (0, 6, 7, 5, 4, 1, 2, 3):
         w.set_option("quotient_fuse", variant)
         for it in range(3):
             w.profile_reset()
