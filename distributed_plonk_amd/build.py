@@ -27,11 +27,13 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", 
 # kernel needs 111 VGPRs, no scratch, no spills: 18.4 -> 16.3 ms per 8n coset FFT (profiles/r02_ntt_pins_experiment.txt).
 UNROLL = ["-mllvm", "-pragma-unroll-threshold=131072", "-mllvm", "-unroll-threshold=131072"]
 # The column accumulators of fp29.hpp / flimb.hpp must stay ONE dependent chain of v_mad_u64_u32; what splits them is the SLP vectoriser's
-# horizontal-reduction matching.  For the MSM unit that matching is switched off and the accumulator pins (inline asm, one s_nop 0 each) are not
-# compiled in: accumulate 20.3 -> 19.3 ms at 2^24 points, window reduction 3.2 -> 2.7 ms, 2^22-point BLS12-381 commit 16.6 -> 15.3 ms on one box
-# (profiles/r04_pin_nop_experiment.txt).  The NTT unit keeps the pins (no pins: 128 VGPRs, +4 %), and so do the polynomial kernels.
+# horizontal-reduction matching.  Every unit keeps the round 1-3 remedy — the "+v" accumulator pin (fp29.hpp) — although it costs one
+# `s_nop 0` per mad.  Round 4 measured the alternatives (profiles/r04_pin_nop_experiment.txt): NOHOR + -DPLONK_PIN_NONE (no pins, the
+# matching switched off instead) makes the MSM kernels 5-25 % faster on one class of gpurun boxes and the bucket accumulation 46 % SLOWER on
+# another (16.3 -> 23.8 ms at 2^24 points; in the two-context step 276 -> 295 ms), -DPLONK_PIN_USE costs the accumulate kernel its SROA, and
+# the NTT pass kernel is indifferent.  The forms stay selectable per unit (build_variant) for whoever measures on a known machine.
 NOHOR = ["-mllvm", "-slp-vectorize-hor=false"]
-UNIT_FLAGS = {"ntt_engine.hip": UNROLL, "msm_engine.hip": NOHOR + ["-DPLONK_PIN_NONE"]}
+UNIT_FLAGS = {"ntt_engine.hip": UNROLL}
 # Not for poly_ops.hip (measured worse: perm product 5.1 -> 6.8 ms, division 1.5 -> 2.9 ms).  Not for quotient.hip either: standalone the
 # kernel gains 5 % (55.1 -> 52.1 ms) and the fused variants stop using scratch, but inside bench.py (and in a process started right
 # after it) the same binary ran at 112 ms twice out of twice — an unexplained slow mode, so the default budget stays there.

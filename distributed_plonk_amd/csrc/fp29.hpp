@@ -50,14 +50,14 @@ struct alignas(16) F29S {
 // budget: with one asm per mad the butterfly loops were no longer unrolled and the lane's element array went to scratch memory.
 // build.py raises the budget for that translation unit and the pins are on everywhere (111 VGPRs, no scratch, -11.8 %).
 // Round 4 (profiles/r04_pin_nop_experiment.txt): the "+v" pin DEFINES a VGPR in an inline asm, and hipcc's hazard recognizer then puts an
-// `s_nop 0` in front of the next VALU that reads it — 9072 s_nop in the 2^8 NTT pass kernel, one per mad.  Three forms, chosen per translation
-// unit in build.py from same-box measurements:
-//   default          asm("" : "+v"(acc))            the round 1-3 form; its s_nops are hidden at 2 or 4 waves per SIMD (microbench), and its
-//                                                   ordering constraints keep the register pressure lowest: NTT passes, polynomial kernels
-//   PLONK_PIN_USE    asm volatile("" :: "v"(acc))   a use, not a definition: no s_nop, 20 % less code; `volatile` costs one kernel its SROA
-//                                                   (MSM accumulate: a limb array in LDS, +50 %) — quotient kernel only
-//   PLONK_PIN_NONE   nothing                        with -mllvm -slp-vectorize-hor=false (no splitting, so no pins needed): the MSM kernels
-//                                                   (accumulate -5 %, window reduction -14 ... -25 %)
+// `s_nop 0` in front of the next VALU that reads it — 9072 s_nop in the 2^8 NTT pass kernel, one per mad.  Three forms were measured per
+// translation unit (build.py: build_variant); the default ships everywhere:
+//   default          asm("" : "+v"(acc))            the round 1-3 form; its s_nops are hidden at 2 or 4 waves per SIMD (tools/mb), its ordering
+//                                                   constraints keep the register pressure lowest, and it is the only form that is never slow
+//   PLONK_PIN_USE    asm volatile("" :: "v"(acc))   a use, not a definition: no s_nop, 20 % less code; NTT and quotient kernels within 2 % of the
+//                                                   default, but `volatile` costs the MSM accumulate kernel its SROA (a limb array in LDS, +50 %)
+//   PLONK_PIN_NONE   nothing                        with -mllvm -slp-vectorize-hor=false (no splitting, so no pins needed): MSM kernels 5-25 %
+//                                                   faster on one class of boxes, the accumulation 46 % slower on another; NTT +4 % (128 VGPRs)
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(F29_NO_PINS)
 #if defined(PLONK_PIN_NONE)
 #define F29_CHAIN(acc) ((void)0)

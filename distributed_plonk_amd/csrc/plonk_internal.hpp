@@ -108,7 +108,7 @@ struct NttTables {
     std::vector<std::string> pow_order;
     // per-context tuning knobs (plonk_set_option): tests and experiments only; a context is driven by one host thread at a time
     int max_log_r = 9;                      // "ntt_max_log_r": widest in-LDS transform of a pass (<= NTT_LOG_RMAX)
-    int quotient_fuse = 0;                  // "quotient_fuse": kernel-formulation experiments of quotient.hip (0 = the shipped kernel)
+    int quotient_fuse = 6;                  // "quotient_fuse": kernel formulations of quotient.hip (6 = the shipped compact kernel; 0 = the round 2-3 kernel; 1-5, 7: experiments)
     std::vector<Fr> h_pow2_inv;             // 2^-k in Montgomery form, k = 0..two_adicity
     Fr h_root[2];                           // w_Nmax, w_Nmax^-1 (Montgomery), Nmax = 2^(2*lt) clipped to two-adicity
 };

@@ -396,7 +396,7 @@ __device__ __forceinline__ void quotient_evals_body(const QuotParams& P) {
     store_fr(P.out + i, f29_to_sat(r));
 }
 
-// Variants: how many products share a reduction.  PLONK_QUOT_FUSE selects; the default is the measured best.
+// Variants behind plonk_set_option("quotient_fuse"); the default (6: quotient_evals_kernel_c) is the measured best on every box.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel(const QuotParams P) { quotient_evals_unlifted(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_u3(const QuotParams P) { quotient_evals_unlifted(P); }      // uncapped registers: 3 waves
 #define QUOT_LOOP_PTS 8
@@ -559,7 +559,7 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 7) ? T.quotient_fuse : 0;
+        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 7) ? T.quotient_fuse : 6;
         const dim3 grid((uint32_t)((m_local + 255) / 256));
         if (fuse == 1) hipLaunchKernelGGL(quotient_evals_kernel_f1, grid, dim3(256), 0, stream, q);
         else if (fuse == 2) hipLaunchKernelGGL(quotient_evals_kernel_f2, grid, dim3(256), 0, stream, q);

@@ -13,6 +13,8 @@ for log_n in [int(a) for a in sys.argv[1:]]:
     out = w.alloc(m * 32)
     ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 5
     ptr = [b.ptr for b in bufs]
+    if __import__('os').environ.get('QUOT_ALIAS'):      # diagnostic: all 25 input vectors are ONE buffer (1 stream instead of 26: compute + latency only)
+        ptr = [bufs[0].ptr] * 25
     w.profile_enable(True)
     alg = 27 * 32 * m          # 26 input reads (z twice) + 1 write of 32 B per point
     names = {0: "unlifted, 4 waves (default)", 4: "unlifted, uncapped registers (3 waves)", 1: "lifted wires, 1 product / reduction",
@@ -26,6 +28,6 @@ for log_n in [int(a) for a in sys.argv[1:]]:
             w.sync()
         ms, cnt = w.profile_get("quotient_evals_kernel")
         print(f"2^{log_n} quotient_fuse={variant} ({names[variant]}): {ms:.3f} ms, algorithmic {alg / ms / 1e6:.1f} GB/s = {alg / ms / 1e6 / 8000:.4f} of 8 TB/s", flush=True)
-    w.set_option("quotient_fuse", 0)
+    w.set_option("quotient_fuse", 6)                  # back to the shipped default
     for b in bufs + [out]:
         b.free()
