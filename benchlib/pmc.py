@@ -20,9 +20,15 @@ def load_pmc(config, dense_coset=False, path=None):
         if db.get("source_hash") == source_hash():
             return db["kernels"], None
         now, then = code_hashes(), db.get("code_hashes") or {}
-        same = sorted(k_ for k_ in then if now.get(k_) == then[k_])
+
+        def host_same(k_):      # the launch shape: the host code of the kernel's unit and of plonk_api (option defaults) must be unchanged too
+            u = now.get("unit_of:" + k_)
+            return (u is not None and then.get("unit_of:" + k_) == u and now.get("host:" + u) == then.get("host:" + u)
+                    and now.get("host:plonk_api") is not None and now.get("host:plonk_api") == then.get("host:plonk_api"))
+
+        same = sorted(k_ for k_ in then if ":" not in k_ and now.get(k_) == then[k_] and host_same(k_))
         pmc = {k_: v_ for k_, v_ in db["kernels"].items() if k_.split("<")[0] in same}
         return pmc, (f"profiles/pmc_current.json was collected from other kernel sources ({db.get('source_hash')} != {source_hash()}); quoted only for "
-                     f"kernels whose gfx950 machine code is byte-identical to the collection's: {', '.join(k_ for k_ in same if k_ in db['kernels']) or 'none'}")
+                     f"kernels whose gfx950 machine code AND launching host code are byte-identical to the collection's: {', '.join(k_ for k_ in same if k_ in db['kernels']) or 'none'}")
     except Exception as ex:     # noqa: BLE001 - a missing or unreadable profile costs the PMC fields, never the run
         return {}, f"no PMC profile: {ex!r}"

@@ -117,8 +117,37 @@ def kernel_code_hashes(obj_dir, arch="gfx950"):
     return out
 
 
+def host_code_hashes(obj_dir):
+    """{"host:<unit>": sha256[:16] of the HOST machine code (.text* sections) of each object} and {"unit_of:<kernel>": unit}.  A kernel's
+    counters depend on its launch shape as well as on its code — window widths, grids, pass plans are decided by the host code of the unit
+    that launches it and by the option defaults compiled into plonk_api.o — so bench.py quotes a kernel from a profile of other
+    sources only if these agree too."""
+    out = {}
+    for f in sorted(os.listdir(obj_dir)):
+        if not f.endswith(".o"):
+            continue
+        path = os.path.join(obj_dir, f)
+        with open(path, "rb") as fh:
+            data = fh.read()
+        secs, _, _ = _elf_sections(data)
+        h = hashlib.sha256()
+        for name in sorted(secs):
+            if name == ".text" or name.startswith(".text."):
+                off, size, _ = secs[name]
+                h.update(name.encode())
+                h.update(data[off:off + size])
+        unit = f[:-2]
+        out["host:" + unit] = h.hexdigest()[:16]
+        co = device_code_object(path)
+        if co is not None:
+            for name in kernel_symbols(co):
+                out["unit_of:" + base_name(name)] = unit
+    return out
+
+
 def write_hashes(obj_dir, out_path):
     hashes = kernel_code_hashes(obj_dir)
+    hashes.update(host_code_hashes(obj_dir))
     with open(out_path, "w") as f:
         json.dump(hashes, f, indent=0, sort_keys=True)
     return hashes

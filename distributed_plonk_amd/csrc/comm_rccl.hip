@@ -14,7 +14,9 @@
 #include <rccl/rccl.h>
 
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
+#include <thread>
 
 #include "plonk_internal.hpp"
 
@@ -80,6 +82,8 @@ struct PlonkComm {
         if (_r != ncclSuccess) return plonk_fail(PLONK_ERR_EXCHANGE, "%s:%d: %s -> %s", __FILE__, __LINE__, #expr, (api)->GetErrorString(_r)); \
     } while (0)
 
+static void comm_device_count(int dev, int delta);      // live communicators per device (the collective order below)
+
 int comm_unique_id(void* out128) {
     const RcclApi* api;
     int rc = rccl_api(&api);
@@ -96,6 +100,7 @@ int comm_create(PlonkComm** out, const void* id128, int rank, int world, int dev
     int rc = rccl_api(&api);
     if (rc) return rc;
     if (world < 1 || rank < 0 || rank >= world) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_init: rank %d of %d", rank, world);
+    if (device < 0 || device >= 64) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_init: device %d (0..63: the per-device collective order is a fixed table)", device);
     HIP_TRY(hipSetDevice(device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof id);
@@ -110,12 +115,14 @@ int comm_create(PlonkComm** out, const void* id128, int rank, int world, int dev
         delete c;
         return plonk_fail(PLONK_ERR_EXCHANGE, "RCCL reports rank %d of %d, expected %d of %d", ur, cnt, rank, world);
     }
+    comm_device_count(device, +1);
     *out = c;
     return PLONK_OK;
 }
 
 void comm_destroy(PlonkComm* c) {
     if (!c) return;
+    comm_device_count(c->device, -1);
     (void)hipSetDevice(c->device);
     if (c->d_stage) (void)hipFree(c->d_stage);
     if (c->comm && g_api.handle) (void)g_api.CommDestroy(c->comm);
@@ -142,24 +149,54 @@ namespace {
 struct CollectiveOrder {
     std::mutex mu;
     hipEvent_t last[64] = {};
+    std::thread::id owner[64];          // the host thread that issues this device's collectives (set by the first one)
+    bool owned[64] = {};
+    int comms[64] = {};                 // live communicators per device: the owner is forgotten with the last one
 };
 CollectiveOrder g_order;
 
-struct CollectiveScope {        // RAII: wait for the device's previous collective, issue, record
+// RAII: wait for the device's previous collective, issue, record.  The ordering only prevents the cross-communicator deadlock if every
+// rank issues its collectives in the SAME order, which two host threads racing for the mutex cannot promise: a device's collectives must
+// come from one thread (the first to issue one), anything else is refused (PLONK_ERR_STATE) instead of deadlocking with the peers.
+// PLONK_COMM_ANY_THREAD=1 lifts the check for callers that serialise their collectives some other way (an async runtime that migrates
+// one logical task between OS threads).
+struct CollectiveScope {
     std::unique_lock<std::mutex> lock;
     int device;
     hipStream_t stream;
-    bool ok = true;
-    CollectiveScope(int dev, hipStream_t s) : lock(g_order.mu), device(dev & 63), stream(s) {
-        hipEvent_t& e = g_order.last[device];
-        if (!e) ok = hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess;
-        else ok = hipStreamWaitEvent(stream, e, 0) == hipSuccess;
+    int rc = PLONK_OK;
+    const char* what = "";
+    CollectiveScope(int dev, hipStream_t s) : lock(g_order.mu), device(dev), stream(s) {
+        if (dev < 0 || dev >= 64) { rc = PLONK_ERR_ARG; what = "device index outside 0..63"; device = -1; return; }
+        static const bool any_thread = getenv("PLONK_COMM_ANY_THREAD") != nullptr;
+        const std::thread::id me = std::this_thread::get_id();
+        if (!g_order.owned[dev]) { g_order.owner[dev] = me; g_order.owned[dev] = true; }
+        else if (g_order.owner[dev] != me && !any_thread) {
+            rc = PLONK_ERR_STATE; what = "collectives of one device must be issued from one host thread (same order on every rank)"; device = -1; return;
+        }
+        hipEvent_t& e = g_order.last[dev];
+        hipError_t he = e ? hipStreamWaitEvent(stream, e, 0) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
+        if (he != hipSuccess) { rc = PLONK_ERR_HIP; what = "collective ordering event"; device = -1; }
+    }
+    // record the ordering point behind the collective; a failure here would silently drop the ordering, so it is reported
+    int finish() {
+        if (device < 0) return rc;
+        const hipError_t he = hipEventRecord(g_order.last[device], stream);
+        device = -1;
+        return he == hipSuccess ? PLONK_OK : plonk_fail(PLONK_ERR_HIP, "collective ordering event: %s", hipGetErrorString(he));
     }
     ~CollectiveScope() {
-        if (g_order.last[device]) (void)hipEventRecord(g_order.last[device], stream);
+        if (device >= 0) (void)hipEventRecord(g_order.last[device], stream);      // error exits: best effort, the error is already on its way
     }
 };
 }  // namespace
+
+static void comm_device_count(int dev, int delta) {
+    if (dev < 0 || dev >= 64) return;
+    std::lock_guard<std::mutex> g(g_order.mu);
+    g_order.comms[dev] += delta;
+    if (g_order.comms[dev] <= 0) { g_order.comms[dev] = 0; g_order.owned[dev] = false; }      // the next communicator's first collective picks the thread again
+}
 
 // block p of `send` -> rank p ; block p of `recv` <- rank p.  One group = one fused RCCL launch; per pair bytes_per_peer bytes,
 // each pair over its own xGMI link (the fabric is point-to-point: 7 links per GPU, no switch).
@@ -170,7 +207,7 @@ int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_p
     const char* s = (const char*)send;
     char* r = (char*)recv;
     CollectiveScope order(c->device, stream);
-    if (!order.ok) return plonk_fail(PLONK_ERR_HIP, "collective ordering event");
+    if (order.rc) return plonk_fail(order.rc, "plonk all-to-all: %s", order.what);
     ProfScope prof("rccl_alltoall", stream);          // HIP events on the stream: the exchange as the GPU saw it (incl. waiting for peers)
     NCCL_TRY(api, api->GroupStart());
     // at most 1 GiB per ncclSend / ncclRecv call: a single-rank world exchanges the WHOLE 4 GiB buffer of a 2^27-point transform with
@@ -185,7 +222,7 @@ int comm_alltoall(PlonkComm* c, const void* send, void* recv, size_t bytes_per_p
         }
     }
     NCCL_TRY(api, api->GroupEnd());
-    return PLONK_OK;
+    return order.finish();
 }
 
 int comm_allgather(PlonkComm* c, const void* send, void* recv, size_t bytes, hipStream_t stream) {
@@ -193,10 +230,10 @@ int comm_allgather(PlonkComm* c, const void* send, void* recv, size_t bytes, hip
     int rc = rccl_api(&api);
     if (rc) return rc;
     CollectiveScope order(c->device, stream);
-    if (!order.ok) return plonk_fail(PLONK_ERR_HIP, "collective ordering event");
+    if (order.rc) return plonk_fail(order.rc, "plonk all-gather: %s", order.what);
     ProfScope prof("rccl_allgather", stream);
     NCCL_TRY(api, api->AllGather(send, recv, bytes, ncclInt8, c->comm, stream));
-    return PLONK_OK;
+    return order.finish();
 }
 
 // host buffers through a device staging area: in (bytes) -> out (world * bytes); synchronises the stream

@@ -230,6 +230,11 @@ __device__ __forceinline__ void ntt_butterflies(F29 (&v)[1 << K], int s0, uint32
     }
 }
 
+// CONTRACT of the SHOUP path (f29_mul_shoup's second loop holds 9 * 2^31 * 2^29 + 9 * 2^58 + carry < 2^63.6 in its 64-bit accumulator only
+// while every limb of x stays below 2^31 and x below 2^261): an operand of a butterfly product has seen AT MOST ONE un-normalised f29_sub4p /
+// f29_add since the last f29_norm — ntt_butterflies normalises after ds == 1 and after the last stage of a step, so a product's operand is
+// either a tile value (normalised) or one lazy butterfly output (limbs < 2^29 + 2^31 ... checked on the host build of this code against Python
+// integers over the whole operand range: tests/test_fp29_host.py) — and the VALUE bound 1.4p + 4p per stage < 40p needs p < 2^254.7 (BN254).
 // SHOUP: the butterfly products use the precomputed-quotient multiplier with twiddles fetched from the 80-byte global table (five
 // 128-bit loads per product on the otherwise idle vector-memory pipe; the table is L1-resident) instead of Montgomery products
 // with twiddles from LDS: 143 limb products instead of 171 + 9.  Its result is < 3p, so butterflies subtract from 4p and bounds

@@ -207,7 +207,13 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
-    if (!strcmp(key, "msm_table_c")) { ctx->msm_table_c = (int)value; return PLONK_OK; }              // takes effect at the next init
+    if (!strcmp(key, "msm_table_c")) {                                                                // takes effect at the next init
+        // 0 = the plan's choice; a pinned width must be one the table plan considers (msm_engine.hip: MSM_TABLE_MAX_C = 21).  A width that is valid
+        // but unusable for the SRS at hand (top window nearly empty, sort geometry, budget) falls back to "no table" at init, also in mode 2.
+        if (value != 0 && (value < 4 || value > 21)) return plonk_fail(PLONK_ERR_ARG, "msm_table_c = %lld (0 or 4..21)", (long long)value);
+        ctx->msm_table_c = (int)value;
+        return PLONK_OK;
+    }
     if (!strcmp(key, "msm_table_sets")) { ctx->msm_table_sets = (int)value; return PLONK_OK; }        // takes effect at the next init
     if (!strcmp(key, "msm_table_budget_mib")) { ctx->msm_table_budget = (size_t)value << 20; return PLONK_OK; }
     // every knob lives in the context it was set on (another context, possibly driven from another host thread, is not affected)
@@ -217,6 +223,11 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_sort_stage_cap")) { ctx->msm_ws.sort_stage_cap = (int)std::max<int64_t>(0, value); return PLONK_OK; }   // tests: force the chunked level-2 sort
     if (!strcmp(key, "msm_acc_persist")) { ctx->msm_ws.acc_persist = (int)std::max<int64_t>(-65536, std::min<int64_t>(value, 8)); return PLONK_OK; }   // default 4; < 0: an absolute grid of -value workgroups (tests)
     if (!strcmp(key, "msm_reduce_grid")) { ctx->msm_ws.reduce_grid = value ? 1 : 0; return PLONK_OK; }   // experiment: grid reduction (msm_engine.hip, 5b); default 0
+    if (!strcmp(key, "ntt_shoup")) {              // precomputed-quotient butterflies (ntt_kernels.hpp); the environment variable PLONK_NTT_NO_SHOUP only sets the initial value
+        if (value && ctx->curve != PLONK_BN254) return plonk_fail(PLONK_ERR_ARG, "ntt_shoup: BN254 only (the 4p-per-stage bound needs 40p of headroom, BLS12-381's Fr leaves 23p)");
+        ctx->tables.use_shoup = value != 0;
+        return PLONK_OK;
+    }
     if (!strcmp(key, "quotient_fuse")) { ctx->tables.quotient_fuse = (int)value; return PLONK_OK; }   // experiments, see quotient.hip
     if (!strcmp(key, "msm_slice_log")) { ctx->msm_ws.slice_log = (int)value; return PLONK_OK; }       // MSMs above 2^value points are sliced (8..26)
     return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: unknown key %s", key);

@@ -243,9 +243,10 @@ static int synth_srs_t(int curve, const Fr& tau, size_t n, void* d_out, hipStrea
     hipLaunchKernelGGL(srs_points_kernel<NQ>, dim3((uint32_t)((n + 127) / 128)), dim3(128), 0, stream, table, tau, (uint64_t)n, (AffPt<NQ>*)d_out,
                        fr_params(curve), P);
     hipError_t e = hipGetLastError();
-    (void)hipStreamSynchronize(stream);
+    const hipError_t es = hipStreamSynchronize(stream);       // the table must outlive both kernels; a fault inside them surfaces here
     (void)hipFree(table);
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_srs launch: %s", hipGetErrorString(e));
+    if (es != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "synth_srs: %s", hipGetErrorString(es));
     return PLONK_OK;
 }
 

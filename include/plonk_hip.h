@@ -281,11 +281,14 @@ int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, c
  * computed slice by slice and the partial points added; default 26, for tests of the slicing path), "msm_batch_max"
  * (scalar vectors per launch set of plonk_commit_many_dev, default 32; 1 = one MSM at a time), "msm_acc_persist" (workgroups per CU of the
  * persistent bucket accumulation, default 4; 0 = one lane per bucket over the whole grid; < 0 = an absolute grid, for tests),
- * "msm_precompute" (fixed-base window table built at the next init: 0 off = default, 1 when the cost model predicts a gain, 2 always),
- * "msm_table_c" / "msm_table_sets" / "msm_table_budget_mib" (the table's window width, bucket sets per scalar and memory budget; 0 = the plan's
- * choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_reduce_grid" (experiment, default 0: the window
- * reduction as tree sums over the bucket grid instead of the running-sum pyramid), "msm_fused_y3", "quotient_fuse"
- * (kernel-formulation experiments).  INTEGRATION.md §6 has the table. */
+ * "msm_precompute" (fixed-base window table built at the next init: 0 off = default, 1 when the cost model predicts a gain, 2 whenever a usable
+ * shape exists — a pinned width that is unusable for the SRS at hand falls back to no table, never to an error),
+ * "msm_table_c" (0 or 4..21) / "msm_table_sets" / "msm_table_budget_mib" (the table's window width, bucket sets per scalar and memory budget;
+ * 0 = the plan's choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_reduce_grid" (default 0: the window
+ * reduction as tree sums over the bucket grid instead of the running-sum pyramid — faster for one small MSM alone, not beside another context's
+ * accumulation: profiles/r04_pin_nop_experiment.txt), "msm_fused_y3", "ntt_shoup" (BN254 only, default 1: precomputed-quotient butterflies in
+ * the NTT passes; 0 = Montgomery butterflies), "quotient_fuse" (6 = default: the compact kernel; 0-5, 7: other formulations).
+ * INTEGRATION.md §6 has the table. */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
 /* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP
  * events on the context's stream (milliseconds). */

@@ -102,10 +102,18 @@ def test_pmc_numbers_are_quoted_only_for_the_code_they_were_collected_from(tmp_p
     if not now:
         return                                   # the library has not been built in this tree: nothing more to compare
     f2 = tmp_path / "other.json"
+    host = {k_: v_ for k_, v_ in now.items() if k_.startswith(("host:", "unit_of:"))}
     f2.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": "0" * 16, "kernels": kern,
-                              "code_hashes": {"ntt_pass_kernel": now["ntt_pass_kernel"], "msm_accumulate_kernel": "f" * 16}}))
+                              "code_hashes": dict(host, ntt_pass_kernel=now["ntt_pass_kernel"], msm_accumulate_kernel="f" * 16)}))
     pmc, note = bench.load_pmc("2^24@bn254@1", path=str(f2))
     assert sorted(pmc) == ["ntt_pass_kernel", "ntt_pass_kernel<8, 4, true, true>"] and "byte-identical" in note and "ntt_pass_kernel" in note
+    # ... and whose LAUNCHING host code is the library's too (a kernel's counters depend on its launch shape): a profile taken with
+    # another planner in ntt_engine, or other option defaults in plonk_api, is not quoted even for byte-identical kernel code
+    for changed in ("host:ntt_engine", "host:plonk_api"):
+        f4 = tmp_path / "planner.json"
+        f4.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": "0" * 16, "kernels": kern,
+                                  "code_hashes": dict(host, **{"ntt_pass_kernel": now["ntt_pass_kernel"], changed: "e" * 16})}))
+        assert bench.load_pmc("2^24@bn254@1", path=str(f4))[0] == {}, changed
     f3 = tmp_path / "nohashes.json"
     f3.write_text(json.dumps({"config": "2^24@bn254@1", "source_hash": "0" * 16, "kernels": kern}))
     assert bench.load_pmc("2^24@bn254@1", path=str(f3))[0] == {}
