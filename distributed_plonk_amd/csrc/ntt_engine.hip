@@ -76,7 +76,10 @@ int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
         if ((rc = upload_powers(&T.g_lo[d], g[d], nt, one, P, stream))) return rc;
         if ((rc = upload_powers(&T.g_hi[d], host_pow2k(g[d], T.lt, P), nt, one, P, stream))) return rc;
     }
-    T.use_shoup = curve == PLONK_BN254 && getenv("PLONK_NTT_NO_SHOUP") == nullptr;
+    // Both fields (round 4): the butterflies' 4p-per-stage growth reaches < 36p on BN254 and < 38p on BLS12-381 (whose inputs arrive < 1.6p: the
+    // inter-pass Montgomery product of a 36p value returns < 36p * p / 2^261 + p); what the multipliers need is x < 2^261 = 70p (BLS12-381) with
+    // limbs < 2^31 — checked on the host build against Python integers up to 40p (tests/test_fp29_host.py), ntt_kernels.hpp has the chain.
+    T.use_shoup = getenv("PLONK_NTT_NO_SHOUP") == nullptr;
     // 2^-k
     Fr two = fp_add(one, one, P), half = fp_inv(two, P);
     T.h_pow2_inv.resize(T.two_adicity + 1);

@@ -230,16 +230,19 @@ __device__ __forceinline__ void ntt_butterflies(F29 (&v)[1 << K], int s0, uint32
     }
 }
 
-// CONTRACT of the SHOUP path (f29_mul_shoup's second loop holds 9 * 2^31 * 2^29 + 9 * 2^58 + carry < 2^63.6 in its 64-bit accumulator only
-// while every limb of x stays below 2^31 and x below 2^261): an operand of a butterfly product has seen AT MOST ONE un-normalised f29_sub4p /
-// f29_add since the last f29_norm — ntt_butterflies normalises after ds == 1 and after the last stage of a step, so a product's operand is
-// either a tile value (normalised) or one lazy butterfly output (limbs < 2^29 + 2^31 ... checked on the host build of this code against Python
-// integers over the whole operand range: tests/test_fp29_host.py) — and the VALUE bound 1.4p + 4p per stage < 40p needs p < 2^254.7 (BN254).
+// CONTRACT of the SHOUP path.  f29_mul_shoup needs x < 2^261 (its quotient estimate is then at most 2 short: result < 3p) and limbs < 2^31 (its
+// second loop holds 9 * 2^31 * 2^29 + 9 * 2^58 + carry < 2^63.6 in the 64-bit accumulator).  Limbs: an operand of a butterfly product has seen
+// AT MOST ONE un-normalised f29_sub4p / f29_add since the last f29_norm — ntt_butterflies normalises after ds == 1 and after the last stage of a
+// step — so its limbs stay below 2^29 + (2^30 + 2^29) = 2^31.  Values: tile values enter a pass below L = 1.36p (first pass: a Montgomery product
+// of canonical data) or L = 1.6p (later passes: the previous pass's plane product of a value below 38p returns < 38p * p / 2^261 + p); the two
+// product-free stages take them to < 2L + 4p + ... < 7.6p, every further stage adds 4p (x + 4p - t, t < 3p): < 7.6p + 4p * 7 = 35.6p after the
+// nine stages of the widest pass.  2^261 = 140p on BN254 and 70p on BLS12-381: both fields qualify (rounds 1-3 excluded BLS12-381 because
+// f29_mul's DOCUMENTED range is 2^259.4 = 23p there; its real requirement is the same x < 2^261, limbs < 2^31, with a result below
+// x * p / 2^261 + p < 2p instead of 1.36p — still below 2^256 for the 8 x 32-bit store and below f29_canon's 2p).  The last pass ends in
+// f29_canon_lazy (< 48p, below 2^261 on both fields).  Host build of this code against Python integers over these ranges: tests/test_fp29_host.py.
 // SHOUP: the butterfly products use the precomputed-quotient multiplier with twiddles fetched from the 80-byte global table (five
 // 128-bit loads per product on the otherwise idle vector-memory pipe; the table is L1-resident) instead of Montgomery products
-// with twiddles from LDS: 143 limb products instead of 171 + 9.  Its result is < 3p, so butterflies subtract from 4p and bounds
-// grow by 4p per stage: < 1.4p + 4p * 9 < 40p after the nine stages of the widest pass — inside f29_mul's 2^259.4 for BN254
-// (p < 2^253.6: 55p) but not for BLS12-381 (23p), which keeps the Montgomery path.
+// with twiddles from LDS: 143 limb products instead of 171 + 9.
 template <int LOG_R, int K, int EPT, bool FIRST, bool SWZ, bool SHOUP>
 __device__ __forceinline__ void ntt_step(const LdsTile& tile, const uint32_t* tw_lds, const F29S* __restrict__ tw_shoup, int s0, uint32_t w, uint32_t t,
                                          uint32_t pitch, const F29Params& fp) {

@@ -224,7 +224,6 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     if (!strcmp(key, "msm_acc_persist")) { ctx->msm_ws.acc_persist = (int)std::max<int64_t>(-65536, std::min<int64_t>(value, 8)); return PLONK_OK; }   // default 4; < 0: an absolute grid of -value workgroups (tests)
     if (!strcmp(key, "msm_reduce_grid")) { ctx->msm_ws.reduce_grid = value ? 1 : 0; return PLONK_OK; }   // experiment: grid reduction (msm_engine.hip, 5b); default 0
     if (!strcmp(key, "ntt_shoup")) {              // precomputed-quotient butterflies (ntt_kernels.hpp); the environment variable PLONK_NTT_NO_SHOUP only sets the initial value
-        if (value && ctx->curve != PLONK_BN254) return plonk_fail(PLONK_ERR_ARG, "ntt_shoup: BN254 only (the 4p-per-stage bound needs 40p of headroom, BLS12-381's Fr leaves 23p)");
         ctx->tables.use_shoup = value != 0;
         return PLONK_OK;
     }

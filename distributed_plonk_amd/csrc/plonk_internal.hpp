@@ -82,7 +82,7 @@ struct NttTables {
     // all device tables hold constants c*2^261 mod p as 9 x 29-bit limbs (fp29.hpp)
     F29* tw_small[2] = {nullptr, nullptr};   // [dir] w_Rmax^e
     F29S* tw_shoup[2] = {nullptr, nullptr};  // [dir] w_Rmax^e prepared for the precomputed-quotient multiplier (plain residue + quotient constant)
-    bool use_shoup = false;                  // BN254 only (bounds, ntt_kernels.hpp: ntt_step); PLONK_NTT_NO_SHOUP=1 keeps the Montgomery butterflies
+    bool use_shoup = false;                  // precomputed-quotient butterflies (bounds: ntt_kernels.hpp); option "ntt_shoup", PLONK_NTT_NO_SHOUP=1 sets the initial value to off
     F29* tw_lo[2] = {nullptr, nullptr};      // [dir] w_Nmax^e
     F29* tw_hi[2] = {nullptr, nullptr};      // [dir] w_Nmax^(e<<lt)
     F29* g_lo[2] = {nullptr, nullptr};       // [0] g^e      [1] g^-e

@@ -22,6 +22,32 @@ def test_ntt_matches_oracle(gpu_workers, oracle, curve, cid, log_n):
         assert np.array_equal(got, want), f"{curve} 2^{log_n} inv={inv} coset={coset}"
 
 
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n", [9, 10, 18])
+def test_ntt_extreme_inputs_and_both_butterfly_forms(gpu_workers, oracle, curve, cid, log_n):
+    """The lazy bounds of the pass kernel at their top (ntt_kernels.hpp: values grow 4p per stage to < 36p with the precomputed-
+    quotient butterflies, which BLS12-381's Fr uses since round 4): inputs of all p - 1, alternating 0 / p - 1 and a single p - 1 among zeros,
+    through a full 2^9-row pass (log_n = 9), a two-pass plan (10) and two full passes (18), every mode, with the Shoup butterflies (the
+    default) and with the Montgomery ones (option ntt_shoup = 0) — bit-exact against the oracle both ways."""
+    w = gpu_workers(curve)
+    n = 1 << log_n
+    pm1 = oracle.field_const(cid, 0, 0) - np.array([1, 0, 0, 0], dtype=np.uint64)       # p - 1: self-inverse under the Montgomery map up to sign, any fixed residue will do
+    rnd = oracle.rand_fr(cid, 4242 + log_n, n)
+    cases = []
+    a = np.tile(pm1, (n, 1)); cases.append(a)
+    b = np.zeros((n, 4), dtype=np.uint64); b[::2] = pm1; cases.append(b)
+    c = np.zeros((n, 4), dtype=np.uint64); c[n - 1] = pm1; cases.append(c)
+    d = rnd.copy(); d[: n // 2] = pm1; cases.append(d)
+    try:
+        for shoup in (1, 0):
+            w.set_option("ntt_shoup", shoup)
+            for v in cases:
+                for inv, coset in MODES:
+                    assert np.array_equal(w.ntt(v, inv, coset), oracle.ntt(cid, v, inv, coset, threads=8)), (curve, log_n, shoup, inv, coset)
+    finally:
+        w.set_option("ntt_shoup", 1)
+
+
 @pytest.mark.parametrize("log_n", [20, 21])
 def test_ntt_large_three_pass(gpu_workers, oracle, log_n):
     w = gpu_workers("bn254")
