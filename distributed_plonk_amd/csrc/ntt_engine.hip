@@ -306,12 +306,16 @@ std::vector<int> ntt_plan_widths(int log_m, int max_log_r) {
 
 
 static int pref_log_t(int log_r) {
-    static const char* ov9 = getenv("PLONK_NTT_LOGT9");     // tuning overrides (experiments)
-    static const char* ov8 = getenv("PLONK_NTT_LOGT8");
-    if (log_r >= 9 && ov9) return atoi(ov9);
-    if (log_r == 8 && ov8) return atoi(ov8);
+    static const char* ov[4] = {getenv("PLONK_NTT_LOGT6"), getenv("PLONK_NTT_LOGT7"), getenv("PLONK_NTT_LOGT8"), getenv("PLONK_NTT_LOGT9")};   // tuning overrides (experiments)
+    if (log_r >= 6 && ov[std::min(log_r, 9) - 6]) return atoi(ov[std::min(log_r, 9) - 6]);
     if (log_r >= 9) return 3;  // 4096-element tile: 144 KiB of the CU's 160 KiB LDS
     if (log_r < 3) return 8;   // EPT = R there: one lane per column
+    // 2^6- and 2^7-row passes (the 7 + 7 + 6 / 7 + 7 + 8 plans of 2^20 ... 2^22-point transforms — configs[1], configs[3] — and the row / column
+    // transforms of the distributed 2-D NTT) take 8-column tiles as well (18 / 36 KiB, eight / four workgroups per CU): that is the shape the bank
+    // swizzle and the precomputed-quotient butterflies are instantiated for — with 32 / 16 columns these passes ran the generic kernel.  Round 4,
+    // same box: 8n coset FFT 2^19 0.65 -> 0.58 ms, 2^20 1.11 -> 1.03, 2^21 1.97 -> 1.79, 2^22 3.85 -> 3.68 (BLS12-381: 3.87 -> 3.66), dense 2^12
+    // 0.075 -> 0.059, 2^19 0.215 -> 0.188; 2^23 and above unchanged; 2^20 step -3.5 % (profiles/r04_small_plans_experiment.txt).
+    if (log_r == 6 || log_r == 7) return 3;
     return 11 - log_r;         // 2048-element tiles (72 KiB: two workgroups per CU)
 }
 
@@ -367,7 +371,7 @@ static bool swizzle_on() {
 template <int LOG_R>
 static hipError_t launch_one(const NttPassParams& P, uint64_t grid, uint32_t threads, size_t lds, hipStream_t stream) {
     // the bank swizzle (ntt_kernels.hpp: sw_fold) is built for the production tile shape: 8 columns, rows >= 2^7, 4 elements per lane
-    if constexpr (LOG_R >= 7) {
+    if constexpr (LOG_R >= 6) {
         if (ntt_ept() == 4 && P.log_t == 3 && P.tile_pitch == 8 && swizzle_on()) {
             if (P.tw_shoup != nullptr) return launch_one_e<LOG_R, 4, true, true>(P, grid, threads, lds, stream);
             return launch_one_e<LOG_R, 4, true>(P, grid, threads, lds, stream);
