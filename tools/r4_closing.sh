@@ -7,7 +7,7 @@ O=$R/gpurun_out
 mkdir -p $O
 cd $R
 echo "== the whole -m gpu suite"
-timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | tail -4 | head -2 | tee $O/r4close_gpu_suite.txt
+timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -3 | tee $O/r4close_gpu_suite.txt
 echo "== smoke()"
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/r4close_smoke.txt
 echo "== driver-style bench"
