@@ -174,9 +174,22 @@ def test_bench_program_single_rank_line_has_every_field(emu_env):
     assert set(d["config"]) >= {"workload", "log_n", "curve", "bases", "scheme", "parallelism", "coset_inputs", "commit_batching"}
 
 
+def test_bench_program_proof_only_sub_run(emu_env):
+    """`--next-rows proof` — what the configs[1] / configs[3] sub-runs of the default bench line use (benchlib/other_configs.py): the step, its
+    verification and ONE verified proof, without the quotient row, the O(n) rows and the same-proof variants."""
+    import json
+    e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "9", "--curve", "bls12_381", "--next-rows", "proof"], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(lines[0])
+    assert d["verified"] is True and d["prover_verified"] is True and set(d["next_rows"]) == {"prover_rounds"} and d["next_rows"]["prover_rounds"]["variants"] == {}
+
+
 def test_differential_fuzz_slice(emu_env):
     """A fixed-seed slice of tools/fuzz_abi.py (random operations, shapes, flags and options against the oracle); long runs are a manual tool —
-    fifteen operations, from single kernels to whole proofs handed to the verifier; under AddressSanitizer it found the two defects recorded in DESIGN §0."""
+    fifteen operations, from single kernels to whole proofs handed to the verifier; under AddressSanitizer it found the two defects recorded in DESIGN §5 and docs/HISTORY.md §0."""
     r = subprocess.run([sys.executable, "tools/fuzz_abi.py", "--seconds", "500", "--max-ops", "60", "--seed", "5", "--max-log", "10"], cwd=ROOT, env=emu_env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz ok: 60 operations" in r.stdout, (r.stdout + r.stderr)[-2000:]

@@ -1,12 +1,12 @@
 #!/bin/bash
 # First GPU call for the grid reduction ("msm_reduce_grid", msm_engine.hip 5b — built at the end of round 3 with no GPU minutes left: parity on the host
-# emulation only).  One gpurun call, ~6 min:   gpurun --timeout 900 -- 'bash tools/ab_reduce_grid.sh'
+# emulation only).  One gpurun call, ~6 min:   gpurun --timeout 900 -- 'bash tools/experiments/r04/ab_reduce_grid.sh'
 #   1. its parity test on the real device (both curves, every window width, batched round);
 #   2. one MSM alone at 2^20 / 2^21 / 2^24 points, pyramid vs grid, per-phase HIP-event times (msm_reduce is the line to read);
 #   3. the step at 2^20 and 2^24 and rank 0's share of an 8-rank job, pyramid vs grid, same box, same call, verified.
 # Expected from the structure: the reduction of a 2^20 / 2^21-point MSM several times shorter (8 + 2 dependent launches of 5- and 16-deep
 # addition chains -> 2 launches of tree sums), neutral at 2^24 (same two additions per bucket).  Adopt as the default only if (3) agrees.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round 4, GPU call 1 (VERDICT r3 "next" #1a, #2, #3): measure what round 3 built blind, then collect the evidence the next steps need.
-#   gpurun --timeout 2100 -- 'bash tools/r4_call1.sh'
-#   A. tools/round4_opening.sh (new tests, fuzzer on the real library, grid-reduction A/B, polynomial_parallel busiest rank)
+#   gpurun --timeout 2100 -- 'bash tools/experiments/r04/r4_call1.sh'
+#   A. tools/experiments/r04/round4_opening.sh (new tests, fuzzer on the real library, grid-reduction A/B, polynomial_parallel busiest rank)
 #   B. stall attribution of ntt_pass_kernel<8,4,true,true>: two SQ counter passes of the zero-padded coset FFT at 2^24 (counters only)
 #   C. BLS12-381 alone: MSM 2^22 and coset FFT 2^22 kernel stats (no second context beside them)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
-sed -i 's/--seconds 180/--seconds 100/' tools/round4_opening.sh
-timeout 1300 bash tools/round4_opening.sh > $O/r4open_all.txt 2>&1
+sed -i 's/--seconds 180/--seconds 100/' tools/experiments/r04/round4_opening.sh
+timeout 1300 bash tools/experiments/r04/round4_opening.sh > $O/r4open_all.txt 2>&1
 tail -60 $O/r4open_all.txt
 
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, GPU call 10: what bounds the quotient kernel?  SQ stall counters + HBM bytes of the shipped compact kernel (quotient_fuse = 6) and of the
 # round 2-3 kernel (0), 2^27 points, with the 25 inputs distinct and with all of them aliased to ONE buffer.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 P=$O/r4_quot_pmc
 mkdir -p $P

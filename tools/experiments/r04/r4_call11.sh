@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, GPU call 11: window width at 2^20 points and persistent-wave count on BLS12-381 (3 waves per SIMD there), in the step; one box, alternating.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

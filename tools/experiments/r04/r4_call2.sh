@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round 4, GPU call 2: A/Bs for the commitments phase (VERDICT r3 next #1b) and BLS12-381 (next #2), one box, one call.
-#   gpurun --timeout 1800 -- 'bash tools/r4_call2.sh'
+#   gpurun --timeout 1800 -- 'bash tools/experiments/r04/r4_call2.sh'
 #   A. tools/mb: v_mad_u64_u32 as a DEPENDENT chain (1 / 2 / 4 accumulators) at 1-4 waves per SIMD
 #   B. 2^24 BN254 step, commitments phase: shipped / grid reduction / side kernels at wave priority 3 / fewer persistent accumulate waves
 #   C. 2^22 BLS12-381 step: the same knobs + forced windows
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,10 +1,10 @@
 #!/bin/bash
 # Round 4, GPU call 3: the accumulator pins of fp29.hpp / flimb.hpp without their s_nop (profiles/r04_pin_nop_experiment.txt).
-#   gpurun --timeout 1800 -- 'bash tools/r4_call3.sh'
+#   gpurun --timeout 1800 -- 'bash tools/experiments/r04/r4_call3.sh'
 # Four builds of the same sources (distributed_plonk_amd/lib/variants/*): pin_rw = the round 1-3 form `asm("" : "+v"(acc))` (one s_nop 0 per mad),
 # pin_use = `asm volatile("" :: "v"(acc))` (no VGPR definition, no s_nop), pin_use_nohor = the same + -slp-vectorize-hor=false,
 # nopin_nohor = no pins at all, SLP's horizontal-reduction splitting switched off instead.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, GPU call 4: the per-unit pin / SLP flags in the product build (MSM: no pins), the compact quotient kernel, the refactored bench.py.
-#   gpurun --timeout 2400 -- 'bash tools/r4_call4.sh'
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+#   gpurun --timeout 2400 -- 'bash tools/experiments/r04/r4_call4.sh'
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

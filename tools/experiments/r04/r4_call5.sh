@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, GPU call 5: same-box A/B of the MSM unit built without pins (product) against the round-3 form (variant msm_rw); what bounds the quotient
 # kernel (26 streams vs 1); the whole -m gpu suite on the product build.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

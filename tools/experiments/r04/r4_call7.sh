@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 4, GPU call 7: precomputed-quotient (Shoup) butterflies for BLS12-381's Fr: parity, then A/B in one library (PLONK_NTT_NO_SHOUP=1
 # keeps the Montgomery butterflies), alternating on one box.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

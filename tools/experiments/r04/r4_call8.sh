@@ -2,7 +2,7 @@
 # Round 4, GPU call 8: pass plans of the sizes BELOW 2^24 (configs[1]: 2^20 BN254, configs[3]: 2^22 BLS12-381), whose balanced 7 + 7 + 6 / 7 + 7 + 8 split
 # runs the generic pass kernel (16-column tiles: no bank swizzle, no precomputed-quotient butterflies).  Knobs: PLONK_NTT_LOGT7=3 (8-column tiles for 2^7-row
 # passes), PLONK_NTT_PREFER8=1 (8 + 8 + remainder).  One box, alternating.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 4, GPU call 9: 8-column tiles (swizzled + Shoup instantiation) also for 2^6-row passes?  PLONK_NTT_LOGT6=3 against the default (32 columns, generic kernel).
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
