@@ -162,18 +162,20 @@ __device__ __forceinline__ void quotient_point_unlifted(const QuotParams& P, con
     store_fr(P.out + i, f29_to_sat(out));
 }
 
-// The COMPACT formulation (round 4; option quotient_fuse = 6): the same arithmetic as quotient_point_unlifted — same
-// products, same lazy classes, same constants, same result bits — with the two repetitive parts ROLLED: the four q_hash * w^5 terms and the
-// five wire factors of the permutation argument each run as a loop of one body (#pragma unroll 1) that re-reads its wire value (an L1 / L2
-// hit: the point loaded it for the linear terms a few hundred instructions earlier) and picks its selector / sigma pointer and its k_j*beta
-// constant from the kernel-argument block with the scalar loop counter.  28 product instances in the code instead of 56: the kernel is
-// ~40 KB of machine code (llvm-readelf) — inside the 64 KiB instruction cache two CUs share on EVERY box
-// (profiles/r03_quotient_slow_mode.txt: above it a "slow" box runs the kernel up to 2x slower) — and the five wire values no longer stay in
-// registers across the whole point.
+// The COMPACT formulation (round 4; option quotient_fuse = 6, the default): the same arithmetic as quotient_point_unlifted —
+// same products, same lazy classes, same constants, same result bits — with the two repetitive parts written as loops of one body
+// (#pragma unroll 1): the four q_hash * w^5 terms and the five wire factors of the permutation argument re-read their wire value (an L1 / L2
+// hit: the point loaded it for the linear terms a few hundred instructions earlier) and pick their selector / sigma pointer and their k_j*beta
+// constant from the kernel-argument block with the scalar loop counter, so the five wire values no longer stay in registers across the whole
+// point and nothing spills (the round 2-3 kernel: 208 B of scratch per lane at its 128-VGPR cap; this one: 141 VGPRs, none).
+// What it does NOT do is shrink the code: hipcc had left the same loops of quotient_point_unlifted rolled already (its unroll budget), and
+// llvm-readelf gives 67 656 bytes for this kernel against 67 888 — both still at the edge of the 64 KiB instruction cache two CUs share
+// (profiles/r03_quotient_slow_mode.txt).  Measured: -3 % on two boxes (56.0 -> 54.4 ms, 56.5 -> 54.7 ms at 2^27 points).
 __device__ __forceinline__ void quotient_point_compact(const QuotParams& P, const uint64_t i) {
     // Operand loads are issued ONE PRODUCT AHEAD of their use (raw 256-bit values, 8 VGPRs each, converted at the use) with a scheduling
-    // barrier behind every batch of loads: a wave's 26 loads otherwise sit directly in front of the product that needs them, four waves per
-    // SIMD cannot cover ~1.3 us of HBM latency 26 times per point, and the kernel ran at 46 % of its VALU issue rate and 26 % of HBM peak.
+    // barrier behind every batch of loads, so that no product waits for the load in front of it.  The kernel is bound by VALU issue either way
+    // (round 4 counters: 12.5 k VALU instructions per point = 98-100 % of the launch's busy cycles): the prefetch is worth what the lost
+    // scratch traffic is, no more.
     const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
     const F29Params& fp = P.fp;
 #define QLOAD(ptr) load_fr((ptr) + i)

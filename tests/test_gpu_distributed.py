@@ -266,6 +266,55 @@ def test_in_library_rccl_transport_single_rank(oracle):
             wk.close()
 
 
+def test_collectives_of_a_device_come_from_one_host_thread():
+    """comm_rccl.hip: the per-device total order of collectives only prevents the cross-communicator deadlock if every rank issues them in the
+    same order, which two racing host threads cannot promise — the first thread to issue a collective on a device owns its collectives, another
+    thread is refused with PLONK_ERR_STATE instead of deadlocking with the peers; the owner is forgotten with the device's last
+    communicator."""
+    import threading
+    from distributed_plonk_amd._ffi import PlonkError
+    from distributed_plonk_amd.worker import PlonkWorker
+    wk = PlonkWorker(me=0, device=0, curve="bn254")
+    try:
+        wk.comm_init(PlonkWorker.comm_unique_id(), 0, 1)
+        a, b = wk.alloc(4096), wk.alloc(4096)
+        a.upload(np.arange(512, dtype=np.uint64))
+        wk.comm_alltoall_dev(a.ptr, b.ptr, 4096)                   # this thread now owns device 0's collectives
+        wk.sync()
+        seen = []
+
+        def other():
+            try:
+                wk.comm_allgather_dev(a.ptr, b.ptr, 4096)
+                seen.append("issued")
+            except PlonkError as ex:
+                seen.append(ex.code)
+
+        t = threading.Thread(target=other)
+        t.start(); t.join()
+        assert seen == [-4], seen                                  # PLONK_ERR_STATE, and nothing was enqueued
+        wk.comm_allgather_dev(a.ptr, b.ptr, 4096)                  # the owner carries on
+        wk.sync()
+        assert np.array_equal(b.download((512,)), np.arange(512, dtype=np.uint64))
+        wk.comm_destroy()                                          # last communicator of the device: ownership is released ...
+        seen.clear()
+
+        def fresh():
+            try:
+                wk.comm_init(PlonkWorker.comm_unique_id(), 0, 1)
+                wk.comm_allgather_dev(a.ptr, b.ptr, 4096)          # ... so another thread may own the next communicator's collectives
+                wk.sync()
+                seen.append("issued")
+            except PlonkError as ex:
+                seen.append(ex.code)
+
+        t = threading.Thread(target=fresh)
+        t.start(); t.join()
+        assert seen == ["issued"], seen
+    finally:
+        wk.close()
+
+
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
 @pytest.mark.parametrize("log_N,S,length_of", [
     (11, 1, lambda N: N // 8 + 3), (11, 2, lambda N: N // 8 + 3),      # r = 32, c = 64: 9 leading coefficients per row, 8 classes of 8
