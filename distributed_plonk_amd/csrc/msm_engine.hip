@@ -544,10 +544,34 @@ template <typename T> __device__ __forceinline__ void store8(T* p, const T& v) {
     for (unsigned i = 0; i < sizeof(T) / 8; i++) d[i] = s[i];
 }
 
+// Resident form of a base point (round 4).  Rounds 1-3 kept bases as unsaturated limbs (9 x 29 bits per coordinate: 72 B per BN254 point, 112 B on
+// BLS12-381) so that a gather needed no re-limbing — but a 72-byte record straddles 64-byte sectors, and the accumulation gathers every base once
+// per window: PMC showed 127 GB of fetches per batched launch for 3 GB of algorithmic bytes.  Bases now rest as the same canonical R'-Montgomery
+// residues in SATURATED 32-bit words, x || y = 64 B (BN254) / 96 B (BLS12-381): a BN254 record is exactly one aligned 64-byte sector, fetched with
+// four dwordx4 loads and re-limbed in registers (+30 of ~2500 VALU instructions per addition).  Infinity stays (0, 0).  Same box, alternating
+// builds (profiles/r04_packed_bases_experiment.txt): accumulate 16.23 -> 15.6 ms at 2^24, commitments of the 2^24 step 275 -> 271 ms, of the 2^20
+// step 23.9 -> 23.5 ms, BLS12-381 unchanged; 11 % less resident memory.
+template <int NQ> using BaseRec = AffPt<NQ>;
+template <int NQ> __device__ __forceinline__ AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> load_base(const BaseRec<NQ>* p) {
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    const AffPt<NQ> a = load16(p);
+    AffL<NL, B> r;
+    r.x = fl_from_sat<NL, B, NQ>(a.x);
+    r.y = fl_from_sat<NL, B, NQ>(a.y);
+    return r;
+}
+template <int NQ> __device__ __forceinline__ void store_base(BaseRec<NQ>* p, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& q) {   // q canonical (< p), normalised
+    constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
+    AffPt<NQ> a;
+    a.x = fl_to_sat<NL, B, NQ>(q.x);
+    a.y = fl_to_sat<NL, B, NQ>(q.y);
+    store16(p, a);
+}
+
 // SRS bases: reference layout (x||y, R = 2^(32N) Montgomery, canonical) -> resident limb form (R' Montgomery)
 template <int NQ>
 __global__ void __launch_bounds__(256) bases_to_limbs_kernel(const AffPt<NQ>* __restrict__ in, uint64_t n,
-                                                             AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ out,
+                                                             BaseRec<NQ>* __restrict__ out,
                                                              const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -557,7 +581,7 @@ __global__ void __launch_bounds__(256) bases_to_limbs_kernel(const AffPt<NQ>* __
     AffL<NL, B> o;
     o.x = fl_canon_lt2p(fl_mul(fl_from_sat<NL, B, NQ>(a.x), fix, P), P);
     o.y = fl_canon_lt2p(fl_mul(fl_from_sat<NL, B, NQ>(a.y), fix, P), P);
-    store8(out + i, o);
+    store_base<NQ>(out + i, o);
 }
 
 template <int NQ>
@@ -580,7 +604,7 @@ __device__ __forceinline__ void store_std(XyzzPt<NQ>* dst, const XyzzL<LimbGeom<
 // bucket, which is queued for msm_accumulate_redo_kernel — keeps calls, scratch and the doubling
 // formula out of this kernel.
 template <int NQ, bool FUSED_Y3>
-__global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+__global__ void __launch_bounds__(256) msm_accumulate_kernel(const BaseRec<NQ>* __restrict__ bases,
                                                              const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                              const uint32_t* __restrict__ order, uint64_t nbuckets, SetGeom geom,
                                                              uint32_t heavy_thresh, XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, uint32_t* __restrict__ redo_count,
@@ -616,13 +640,13 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
                 uint64_t seg = seg_first(geom, b, &w);
                 const uint64_t step = seg_step(geom);
                 uint32_t j = offsets[seg], end = offsets[seg + 1];
-                const AffL<NL, B>* tb = bases;                               // plane t: 2^(c*G*t) * P_i
+                const BaseRec<NQ>* tb = bases;                               // plane t: 2^(c*G*t) * P_i
                 XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
                 bool ok = true;
                 for (uint32_t it = 0; it < total; it++) {
                     while (j == end) { seg += step; tb += geom.tab_stride; j = offsets[seg]; end = offsets[seg + 1]; }   // `total` guarantees a next entry
                     const uint32_t e = sorted[j++];
-                    AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                    AffL<NL, B> q = load_base<NQ>(tb + (e & 0x7fffffffu));
                     if (affl_is_inf(q)) continue;
                     if (e >> 31) q = affl_neg(q, P);
                     if (!xyzzl_madd_fast<NL, B, FUSED_Y3>(acc, q, P)) { ok = false; break; }
@@ -638,7 +662,7 @@ __global__ void __launch_bounds__(256) msm_accumulate_kernel(const AffL<LimbGeom
 // Heavy buckets: HEAVY_SEGS workgroups share one bucket (strided slices), every lane accumulates a strided subset
 // with the complete addition, an LDS tree folds the workgroup, msm_heavy_finish_kernel folds the segments.
 template <int NQ>
-__global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+__global__ void __launch_bounds__(256) msm_heavy_kernel(const BaseRec<NQ>* __restrict__ bases,
                                                         const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                         SetGeom geom,
                                                         const uint32_t* __restrict__ heavy_count, const uint32_t* __restrict__ heavy_list,
@@ -654,12 +678,12 @@ __global__ void __launch_bounds__(256) msm_heavy_kernel(const AffL<LimbGeom<NQ>:
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
         uint32_t w;
         uint64_t sg = seg_first(geom, b, &w);
-        const AffL<NL, B>* tb = bases;
+        const BaseRec<NQ>* tb = bases;
         for (; w < geom.W1; w += geom.G, sg += seg_step(geom), tb += geom.tab_stride) {
             const uint32_t beg = offsets[sg], end = offsets[sg + 1];
             for (uint32_t j = beg + seg * blockDim.x + threadIdx.x; j < end; j += HEAVY_SEGS * blockDim.x) {
                 const uint32_t e = sorted[j];
-                AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                AffL<NL, B> q = load_base<NQ>(tb + (e & 0x7fffffffu));
                 if (affl_is_inf(q)) continue;            // before negating: affl_neg would turn (0,0) into (0, 2p)
                 if (e >> 31) q = affl_neg(q, P);
                 acc = xyzzl_madd(acc, q, P);
@@ -695,7 +719,7 @@ __global__ void __launch_bounds__(64) msm_heavy_finish_kernel(const uint32_t* __
 }
 
 template <int NQ>
-__global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ bases,
+__global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const BaseRec<NQ>* __restrict__ bases,
                                                                  const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ offsets,
                                                                  SetGeom geom,
                                                                  XyzzL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ buckets, const uint32_t* __restrict__ redo_count,
@@ -709,12 +733,12 @@ __global__ void __launch_bounds__(64) msm_accumulate_redo_kernel(const AffL<Limb
         XyzzL<NL, B> acc = xyzzl_inf<NL, B>();
         uint32_t w;
         uint64_t sg = seg_first(geom, b, &w);
-        const AffL<NL, B>* tb = bases;
+        const BaseRec<NQ>* tb = bases;
         for (; w < geom.W1; w += geom.G, sg += seg_step(geom), tb += geom.tab_stride) {
             const uint32_t beg = offsets[sg], end = offsets[sg + 1];
             for (uint32_t j = beg; j < end; j++) {
                 const uint32_t e = sorted[j];
-                AffL<NL, B> q = load8(tb + (e & 0x7fffffffu));
+                AffL<NL, B> q = load_base<NQ>(tb + (e & 0x7fffffffu));
                 if (affl_is_inf(q)) continue;
                 if (e >> 31) q = affl_neg(q, P);
                 acc = xyzzl_madd(acc, q, P);
@@ -943,16 +967,16 @@ template <int NQ> static const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& fl_p
     return P;
 }
 
-size_t msm_limb_base_bytes(int curve) { return curve == PLONK_BN254 ? sizeof(AffL<9, 29>) : sizeof(AffL<14, 28>); }
+size_t msm_limb_base_bytes(int curve) { return curve == PLONK_BN254 ? sizeof(BaseRec<8>) : sizeof(BaseRec<12>); }
 
 // XY (reference layout) -> resident limb form; d_out holds n * msm_limb_base_bytes(curve) bytes
 int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream_t stream) {
     if (n == 0) return PLONK_OK;
     const uint32_t grid = (uint32_t)((n + 255) / 256);
     if (curve == PLONK_BN254)
-        hipLaunchKernelGGL(bases_to_limbs_kernel<8>, dim3(grid), dim3(256), 0, stream, (const AffPt<8>*)d_xy, (uint64_t)n, (AffL<9, 29>*)d_out, fl_params<8>(curve));
+        hipLaunchKernelGGL(bases_to_limbs_kernel<8>, dim3(grid), dim3(256), 0, stream, (const AffPt<8>*)d_xy, (uint64_t)n, (BaseRec<8>*)d_out, fl_params<8>(curve));
     else
-        hipLaunchKernelGGL(bases_to_limbs_kernel<12>, dim3(grid), dim3(256), 0, stream, (const AffPt<12>*)d_xy, (uint64_t)n, (AffL<14, 28>*)d_out, fl_params<12>(curve));
+        hipLaunchKernelGGL(bases_to_limbs_kernel<12>, dim3(grid), dim3(256), 0, stream, (const AffPt<12>*)d_xy, (uint64_t)n, (BaseRec<12>*)d_out, fl_params<12>(curve));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "bases_to_limbs launch: %s", hipGetErrorString(e));
     return PLONK_OK;
@@ -972,13 +996,13 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 // What is left (+8 % per addition at 4 planes, +15 % at 13: the segment boundaries inside the loop) cancels what the smaller pyramid saves: OFF by
 // default (`msm_precompute` = 0), kept as an option with its tests (tests/test_gpu_msm_table.py).
 template <int NQ>
-__global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* __restrict__ table, uint64_t n, uint64_t stride, int shift, int T,
+__global__ void __launch_bounds__(64) msm_table_kernel(BaseRec<NQ>* __restrict__ table, uint64_t n, uint64_t stride, int shift, int T,
                                                        const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> P,
                                                        const FL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B> pm2 /* p - 2, limb form */) {
     constexpr int NL = LimbGeom<NQ>::NL, B = LimbGeom<NQ>::B;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    AffL<NL, B> q = load8(table + i);
+    AffL<NL, B> q = load_base<NQ>(table + i);
     for (int w = 1; w < T; w++) {
         if (!affl_is_inf(q)) {
             XyzzL<NL, B> a = xyzzl_dbl_affine(q, P);
@@ -993,7 +1017,7 @@ __global__ void __launch_bounds__(64) msm_table_kernel(AffL<LimbGeom<NQ>::NL, Li
             q.x = fl_canon_lt2p(fl_mul(a.x, fl_sqr(u, P), P), P);
             q.y = fl_canon_lt2p(fl_mul(a.y, inv, P), P);
         }
-        store8(table + (uint64_t)w * stride + i, q);
+        store_base<NQ>(table + (uint64_t)w * stride + i, q);
     }
 }
 
@@ -1082,7 +1106,7 @@ template <int NQ> static int msm_table_build_t(int curve, void* d_table, size_t 
     Fp<NQ> pm2;
     uint64_t br = 2;
     for (int i = 0; i < NQ; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
-    hipLaunchKernelGGL(msm_table_kernel<NQ>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, stream, (AffL<NL, B>*)d_table, (uint64_t)n, (uint64_t)stride, shift, T,
+    hipLaunchKernelGGL(msm_table_kernel<NQ>, dim3((uint32_t)((n + 63) / 64)), dim3(64), 0, stream, (BaseRec<NQ>*)d_table, (uint64_t)n, (uint64_t)stride, shift, T,
                        fl_params<NQ>(curve), fl_from_sat<NL, B, NQ>(pm2));
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "msm_table launch: %s", hipGetErrorString(e));
@@ -1130,7 +1154,7 @@ static int plan_window(size_t n, int bits, int window_bits, const MsmTable& tab,
 // reduction pyramid each run once over K times the work — no per-MSM launch gaps, wave tails or host round trips, which is what
 // bounds small MSMs (2^20 - 2^21 points per rank / per configs[1]).  lens[k] <= n valid scalars in vector k.
 template <int NQ>
-static int msm_slice(int curve, const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont,
+static int msm_slice(int curve, const BaseRec<NQ>* d_bases, const uint32_t* const* d_scalars, const size_t* lens, int K, bool scalars_mont,
                      size_t n, XyzzPt<NQ>* h_result, MsmWorkspace& ws, int window_bits, const MsmTable& tab, hipStream_t stream) {
     const FpParams<NQ>& P = fq_params<NQ>(curve);
     const int bits = fr_params(curve).bits;
@@ -1436,7 +1460,7 @@ static int msm_run_t(int curve, const void* d_bases, const uint32_t* const* d_sc
                 ln[k] = lens[k0 + k] > s ? std::min(lens[k0 + k] - s, m) : 0;
             }
             std::vector<XyzzPt<NQ>> part(kn);
-            int rc = msm_slice<NQ>(curve, (const AffL<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>*)d_bases + s, ptrs.data(), ln.data(), kn, scalars_mont, m, part.data(), ws,
+            int rc = msm_slice<NQ>(curve, (const BaseRec<NQ>*)d_bases + s, ptrs.data(), ln.data(), kn, scalars_mont, m, part.data(), ws,
                                    window_bits, tab, stream);
             if (rc) return rc;
             for (int k = 0; k < kn; k++) total[k0 + k] = xyzz_add(total[k0 + k], part[k], P);

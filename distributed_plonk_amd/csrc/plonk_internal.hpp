@@ -184,7 +184,7 @@ struct MsmTable {
     uint64_t stride = 0;  // points per plane (= n_bases)
     bool force = false;   // msm_precompute = 2: use the table for every MSM it can serve, whatever the cost model says (tests, experiments)
 };
-// bases: device, RESIDENT LIMB FORM produced by bases_to_limbs() (72 B BN254 / 112 B BLS12-381 per point); with a table,
+// bases: device, RESIDENT FORM produced by bases_to_limbs() (64 B BN254 / 96 B BLS12-381 per point: msm_engine.hip, BaseRec); with a table,
 // the pointer addresses plane 0 (+ the range start) and the other planes follow at multiples of tab.stride.
 // scalars: device, canonical 8xu32 — or Montgomery-form Fr when scalars_mont (into_repr is then taken inside the digit kernel).
 // out_jac: host, 3*Q*... written as X||Y||Z Montgomery u32 limbs.

@@ -269,7 +269,7 @@ int plonk_synth_srs(plonk_ctx* ctx, const uint64_t* tau, size_t n, void* d_out);
 int plonk_synth_circuit(plonk_ctx* ctx, uint64_t seed, size_t n, size_t num_inputs, const uint64_t* k, void* d_wires, void* d_selector_evals,
                         void* d_sigma_evals, void* d_id_perm, void* d_perm_idx, void* d_pub_input);
 /* Use n_bases points already in HBM (PLONK_BASES_XY) as the SRS without a host round trip; they are
- * re-encoded into the library's resident limb form (72 B / 112 B per point), the caller keeps its buffer. */
+ * re-encoded into the library's resident form (x || y as canonical R'-Montgomery residues in 32-bit words: 64 B / 96 B per point), the caller keeps its buffer. */
 int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_bases, size_t domain_size,
                    size_t quot_domain_size);
 /* element-wise field ops on the device, for pinning the arithmetic layer.
