@@ -83,7 +83,7 @@ def plan(args, S):
         problems.append(f"{S} ranks: the coset-class scheme needs N <= 8n/n = 8 classes")
     GiB = float(1 << 30)
     q_bytes = 64 if args.curve == "bn254" else 96
-    limb_bytes = 72 if args.curve == "bn254" else 112
+    limb_bytes = 64 if args.curve == "bn254" else 96                      # resident base record (msm_engine.hip: BaseRec)
     me_ = 0 if args.n_domain_only else m
     msm_ws = 3 * 4 * 15 * min(n // S, 1 << 26)                          # digit / sorted-index arrays of one MSM slice
     if S == 1:

@@ -171,7 +171,7 @@ class ClassProver(Prover):
     key_range = None: `worker.init(ck, n, 8n)` was given the WHOLE commit key (replicated), each polynomial's coefficients are split
     evenly.  key_range = (lo, hi): the worker (and the commit_helper) hold only bases [lo, hi) — `key_shard_range(len(ck), rank, G)` —
     and this rank commits, for every polynomial, the coefficients with index in [lo, hi): the key is sharded G ways like the
-    reference's (dispatcher2.rs:260-266), 72 / 112 B per point resident."""
+    reference's (dispatcher2.rs:260-266), 64 / 96 B per point resident."""
 
     def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None):
         super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper)

@@ -984,7 +984,7 @@ int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream
 
 // ---------------------------------------------------------------------------------------------- fixed-base window table
 // The SRS is fixed between `init` calls (worker.rs:141), so shifted copies of it can be built once and kept resident: plane t holds
-// 2^(c*G*t) * P_i (T planes x 72 B per point; 288 GB of HBM make this cheap).  Window w = g + t*G of a scalar then reads its bases from
+// 2^(c*G*t) * P_i (T planes x 64 / 96 B per point; 288 GB of HBM make this cheap).  Window w = g + t*G of a scalar then reads its bases from
 // plane t and adds into the bucket set of window g: a scalar vector needs G bucket sets instead of W — the reduction pyramid, the
 // bucket ordering and the host fold shrink W/G-fold (G = 1: one set for all windows), and with fewer, fuller buckets a wider window pays.
 // Lane i walks its point through the T-1 shifts: c*G doublings (lazy XYZZ), one Fermat inversion, back to the canonical affine limb form

@@ -1,0 +1,22 @@
+#!/bin/bash
+# Round 4, the last GPU call, on the FINAL sources (after the packed base records): the whole -m gpu suite, smoke(), the driver-style bench line,
+# kernel stats + PMC (pmc_current.json gets the final source hash).
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -2 | tee $O/r4final_gpu_suite.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/r4final_smoke.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/r04_bench_2p24_final.json 2> $O/r4final_bench.err; echo "bench rc $?"
+timeout 900 bash tools/collect_profiles.sh r04 2>&1 | tail -4
+python - <<'PY'
+import json
+d = json.load(open("gpurun_out/r04_bench_2p24_final.json"))
+print("step", d["ms_per_step"], d["phases_ms"]["transforms"], d["phases_ms"]["commitments"], "verified", d["verified"], "proof", d.get("proof_ms"), d.get("prover_verified"), d.get("proof_variants_ms"))
+print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}, [(r["kernel"], r["achieved"], r["frac"], r["avg_launch_ms"]) for r in d["roofline_other"]])
+for oc in d.get("other_configs") or []:
+    print({k: oc.get(k) for k in ("config", "ms_per_step", "phases_ms", "verified", "proof_ms", "prover_verified", "error")})
+print("next rows", {k: (v.get("ms"), v.get("frac")) for k, v in (d.get("next_rows") or {}).items() if isinstance(v, dict) and "ms" in v})
+print("rounds", d["next_rows"]["prover_rounds"]["rounds_ms"])
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["extrapolated_to_bench_size"]["value"])
+PY
