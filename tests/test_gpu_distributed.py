@@ -271,9 +271,12 @@ def test_collectives_of_a_device_come_from_one_host_thread():
     same order, which two racing host threads cannot promise — the first thread to issue a collective on a device owns its collectives, another
     thread is refused with PLONK_ERR_STATE instead of deadlocking with the peers; the owner is forgotten with the device's last
     communicator."""
+    import os
     import threading
     from distributed_plonk_amd._ffi import PlonkError
     from distributed_plonk_amd.worker import PlonkWorker
+    if os.environ.get("PLONK_ALLOW_HOSTEMU") == "1":
+        pytest.skip("a property of comm_rccl.hip; the emulation's shared-memory communicator (tests/hostemu/comm_local.cpp) has no stream order to protect")
     wk = PlonkWorker(me=0, device=0, curve="bn254")
     try:
         wk.comm_init(PlonkWorker.comm_unique_id(), 0, 1)
