@@ -1,0 +1,24 @@
+#!/bin/bash
+# The closing collection of a round, on the sources that ship (nothing that changes a kernel lands after it): the whole -m gpu suite,
+# smoke(), the driver-style bench line, kernel stats + PMC (tools/collect_profiles.sh: pmc_current.json gets the shipped source hash).  ~6 GPU-minutes.
+#   gpurun --timeout 2400 -- 'bash tools/closing_collection.sh r05'      then copy what tools/collect_profiles.sh prints into profiles/
+TAG=${1:-r04}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out
+mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests -m gpu -x -q -p no:cacheprovider 2>&1 | grep -E "passed|failed|error" | tail -2 | tee $O/${TAG}_closing_gpu_suite.txt
+timeout 200 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1 | tee $O/${TAG}_closing_smoke.txt
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > $O/${TAG}_bench_2p24_final.json 2> $O/${TAG}_closing_bench.err; echo "bench rc $?"
+timeout 900 bash tools/collect_profiles.sh $TAG 2>&1 | tail -4
+python - $TAG <<'PY'
+import json, sys
+d = json.load(open(f"gpurun_out/{sys.argv[1]}_bench_2p24_final.json"))
+print("step", d["ms_per_step"], d["phases_ms"]["transforms"], d["phases_ms"]["commitments"], "verified", d["verified"], "proof", d.get("proof_ms"), d.get("prover_verified"), d.get("proof_variants_ms"))
+print("roofline", {k: d["roofline"][k] for k in ("kernel", "achieved", "frac", "avg_launch_ms")}, [(r["kernel"], r["achieved"], r["frac"], r["avg_launch_ms"]) for r in d["roofline_other"]])
+for oc in d.get("other_configs") or []:
+    print({k: oc.get(k) for k in ("config", "ms_per_step", "phases_ms", "verified", "proof_ms", "prover_verified", "error")})
+print("next rows", {k: (v.get("ms"), v.get("frac")) for k, v in (d.get("next_rows") or {}).items() if isinstance(v, dict) and "ms" in v})
+print("rounds", d["next_rows"]["prover_rounds"]["rounds_ms"])
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["extrapolated_to_bench_size"]["value"])
+PY

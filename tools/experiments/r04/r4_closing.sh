@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 4 closing collection on the SHIPPED sources: the whole -m gpu suite, the driver-style bench line, kernel stats + PMC
 # (tools/collect_profiles.sh: pmc_current.json gets the shipped source hash), BLS12-381 alone under the SQ counters.
-#   gpurun --timeout 3000 -- 'bash tools/r4_closing.sh'
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+#   gpurun --timeout 3000 -- 'bash tools/experiments/r04/r4_closing.sh'
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round 4, last GPU call: evidence on the SHIPPED library that the closing collection does not cover — the N > 1 code path on one GPU (--multi-path through
 # real communicators; rank 0's share of 8 ranks), configs[4]'s n-domain as a 1-GPU stress run, the fuzzer for two more minutes, clocks beside the step.
-#   gpurun --timeout 1500 -- 'bash tools/r4_evidence.sh'
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+#   gpurun --timeout 1500 -- 'bash tools/experiments/r04/r4_evidence.sh'
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

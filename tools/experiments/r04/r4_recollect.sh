@@ -1,7 +1,7 @@
 #!/bin/bash
 # After a comment-only edit of csrc/quotient.hip (machine code unchanged, source hash changed): the new test of the collective order, the quotient and
 # distributed suites, and the kernel stats + PMC passes again so that profiles/pmc_current.json carries the source hash of the library that ships.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
