@@ -156,12 +156,12 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
 
 
 def test_bench_program_single_rank_line_has_every_field(emu_env):
-    """`python bench.py` as the driver runs it at N = 1 (here: 2^9 gates on the emulation): the headline, the verification against the oracle, the
+    """`python bench.py` as the driver runs it at N = 1 (here: 2^7 gates on the emulation): the headline, the verification against the oracle, the
     next rows and the verified proof all execute, and the line carries exactly the top-level fields the round-3 program printed (the refactoring
     of bench.py into benchlib/ must not lose or rename one; an emulated line has no clock-derived field by construction)."""
     import json
     e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "9"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
     d = json.loads(lines[0])
@@ -179,7 +179,7 @@ def test_bench_program_proof_only_sub_run(emu_env):
     verification and ONE verified proof, without the quotient row, the O(n) rows and the same-proof variants."""
     import json
     e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "9", "--curve", "bls12_381", "--next-rows", "proof"], cwd=ROOT, env=e,
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7", "--curve", "bls12_381", "--next-rows", "proof"], cwd=ROOT, env=e,
                        capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
