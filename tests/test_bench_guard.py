@@ -148,3 +148,17 @@ def test_the_bench_program_stays_reviewable():
             if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef)):
                 assert node.end_lineno - node.lineno + 1 <= 150, (f, node.name)
     assert sum(1 for _ in open(os.path.join(ROOT, "bench.py"))) <= 200
+
+
+def test_committed_pmc_profile_was_collected_from_the_shipped_sources():
+    """`roofline.traffic` / `valu_issue` of the driver's bench line must come from counters collected on the sources that ship, not
+    through the per-kernel machine-code exception: profiles/pmc_current.json carries the source hash of the kernel sources in this tree.  (After a
+    kernel edit this fails until the closing collection — tools/closing_collection.sh on an MI355X — has been re-run and its pmc_current.json copied.)"""
+    import bench
+    from distributed_plonk_amd import build
+    with open(os.path.join(ROOT, "profiles", "pmc_current.json")) as f:
+        db = json.load(f)
+    assert db["source_hash"] == build.source_hash(), "profiles/pmc_current.json is stale: re-run tools/closing_collection.sh on the GPU box and copy gpurun_out/pmc_current.json"
+    pmc, note = bench.load_pmc("2^24@bn254@1")
+    assert note is None and {"ntt_pass_kernel", "msm_accumulate_kernel"} <= set(pmc)
+    assert pmc["ntt_pass_kernel"]["traffic_bytes"] > 2 ** 31 and pmc["msm_accumulate_kernel"]["SQ_INSTS_VALU"] > 10 ** 9
