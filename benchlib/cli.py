@@ -45,6 +45,12 @@ def parse():
                          "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass), the 25 forward "
                          "coset FFTs from zero-padded rows (plonk_fft1_dev_compact), two lanes so that exchanges overlap the next transform's passes.  "
                          "The other scheme is timed after the headline and reported as `other_scheme`")
+    ap.add_argument("--overlap-phases", default="auto", choices=["auto", "on", "off"],
+                    help="N = 1: issue the step's transforms on their own context WHILE the 13 commitments run on the two commitment contexts, instead "
+                         "of one phase after the other.  Measured with the shipped library (tools/overlap_probe.py, profiles/r04_overlap_probe.txt): "
+                         "-10.6 % at 2^20 BN254, -5.6 % at 2^22 BLS12-381, -1.9 % at 2^24 BN254.  'auto' = on up to 2^22 gates (launch gaps and wave "
+                         "tails are a tenth of such a step), off above (the 2^24 line keeps per-launch NTT timings that a concurrent accumulation would "
+                         "stretch: they are what `roofline` is computed from)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: validate the arguments for this --gpus (divisibility of r and n, class count, buffer sizes per rank) and print the plan")
     ap.add_argument("--multi-path", action="store_true",

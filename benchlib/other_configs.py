@@ -18,15 +18,21 @@ def other_configs(args):
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", args.bases,
                "--no-cpu-baseline", "--next-rows", "proof", "--no-other-configs"] + extra
         try:
-            res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            fallback = None
+            try:
+                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+            except Exception as ex:         # noqa: BLE001 - these sizes overlap their two phases by default (--overlap-phases auto): if that run fails,
+                fallback = repr(ex)         # the phase-after-phase form of rounds 1-3 still gives the line, and the failure is recorded beside it
+                res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
             d_ = json.loads(res.stdout.decode().strip().splitlines()[-1])
             rf = d_.get("roofline") or {}
             other.append({"config": label, "ms_per_step": d_["ms_per_step"], "constraints_per_s": d_["value"], "steps": d_["steps"],
                           "phases_ms": {k_: v_ for k_, v_ in (d_.get("phases_ms") or {}).items() if k_ != "note"},
+                          "phase_overlap": (d_.get("config") or {}).get("phase_overlap"),      # True: `frac` below is from launches stretched by the overlap
                           "dominant_kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_ms": rf.get("avg_launch_ms"),
                           "verified": d_.get("verified"), "verification": d_.get("verification"),
                           "proof_ms": d_.get("proof_ms"), "proof_constraints_per_s": d_.get("proof_constraints_per_s"),
-                          "prover_verified": d_.get("prover_verified")})
+                          "prover_verified": d_.get("prover_verified"), **({"overlap_run_failed": fallback} if fallback else {})})
         except Exception as ex:             # noqa: BLE001 - the extra lines must never break the headline
             other.append({"config": label, "error": repr(ex)})
     return other

@@ -56,6 +56,9 @@ class Bench:
         self.multi = self.S > 1 or args.multi_path
         self.n_lanes = 2 if self.multi else 1
         self.phase = {"ntt": 0.0, "msm": 0.0}              # host-clock split of the step at its one internal sync point (this rank)
+        # N = 1 only: the transforms on a context of their own, issued while the commitment threads run (--overlap-phases; cli.py has the numbers)
+        self.overlap = (not self.multi and self.S == 1 and self.nbig > 0 and
+                        (args.overlap_phases == "on" or (args.overlap_phases == "auto" and args.log_n <= 22)))
         self._contexts()
         self._inputs()
         self._class_scheme_inputs()
@@ -73,6 +76,7 @@ class Bench:
         self.n_commit_lanes = max(2, int(os.environ.get("PLONK_BENCH_COMMIT_LANES", "2")))      # experiment knob; 2 is the measured choice
         self.workers = [PlonkWorker(me=self.rank, device=self.local_rank, curve=args.curve) for _ in range(self.n_commit_lanes)]
         self.w = self.workers[0]
+        self.wt = PlonkWorker(me=self.rank, device=self.local_rank, curve=args.curve) if self.overlap else self.w      # the transforms' context
         self.q64 = self.w.q64
         if os.environ.get("PLONK_BENCH_MSM_WINDOW"):                 # experiment knob: force the Pippenger window (0 / unset: the library's cost model)
             for x in self.workers:
@@ -145,7 +149,7 @@ class Bench:
         self.bases = w.alloc(n_loc * 16 * self.q64)
         # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
         w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, self.bases.ptr)
-        for x in self.workers:
+        for x in self.workers + ([self.wt] if self.wt is not self.w else []):
             x.init_dev(self.bases.ptr, n_loc, n, m if nbig else 0)      # both contexts hold the SRS shard in the resident limb form
             x.sync()
         # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
@@ -191,7 +195,7 @@ class Bench:
     def ntt(self, lane, bufs, size, inv, coset, is_quot):
         """one whole-vector / distributed transform; the pair ping-pongs (the next step transforms this step's output)"""
         if self.S == 1:
-            self.w.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
+            self.wt.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
         else:
             self.provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
@@ -200,7 +204,7 @@ class Bench:
         """quot_domain.coset_fft of polynomial i of the step (dispatcher2.rs:387-424)."""
         buf_m = self.buf_m
         if self.padded:
-            self.w.coset_eval_dev(self.polys[i % len(self.polys)].ptr, self.poly_len, self.m, self.gen_limbs, buf_m[lane][0].ptr)
+            self.wt.coset_eval_dev(self.polys[i % len(self.polys)].ptr, self.poly_len, self.m, self.gen_limbs, buf_m[lane][0].ptr)
         elif self.rows_compact:
             self.provers[lane].fft_dev(self.rows_compact[i % len(self.rows_compact)].ptr, buf_m[lane][1].ptr, self.m, True, False, True, out_layout=1,
                                        row_len=self.row_len_m)
@@ -279,14 +283,26 @@ class Bench:
         self.phase["msm"] += time.perf_counter() - t_mid
         return res
 
+    def _overlapped_finish(self, t_in, handle):
+        """--overlap-phases: the commitment threads were started before the first transform was issued"""
+        self.wt.sync()
+        t_mid = time.perf_counter()
+        res = self.commits_finish(handle)
+        self.phase["ntt"] += t_mid - t_in                    # the transforms, with commitments running beside them
+        self.phase["msm"] += time.perf_counter() - t_mid     # what was left of the commitments after the last transform
+        return res
+
     def step_ref2d(self):
         t_in = time.perf_counter()
+        handle = self.commits_start(N_MSM) if self.overlap else None
         for i in range(N_NTT_SMALL):
             self.ntt(i % self.n_lanes, self.buf_n[i % len(self.buf_n)], self.n, True, False, False)
         for i in range(self.nbig - 1):
             self.coset_fft_8n(i % self.n_lanes, i)
         if self.nbig:
             self.ntt(0, self.buf_m[0], self.m, True, True, True)
+        if self.overlap:
+            return self._overlapped_finish(t_in, handle)
         return self._commit_phase(t_in)
 
     def step_classes(self):
@@ -321,7 +337,7 @@ class Bench:
             self.torch.cuda.synchronize()
 
     def full_sync(self):
-        for x in set(self.workers):
+        for x in set(self.workers) | {self.wt}:
             x.sync()
         self.dev_sync()
         if self.world > 1:
@@ -363,7 +379,7 @@ class Bench:
         if self.buf_n or self.buf_m:
             self.release_step_buffers()
         self.bases.free()
-        for x in self.workers:
+        for x in self.workers + ([self.wt] if self.wt is not self.w else []):
             x.close()
         if self.dist.is_initialized():
             self.dist.destroy_process_group()

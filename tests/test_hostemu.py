@@ -155,13 +155,17 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
 
 
-def test_bench_program_single_rank_line_has_every_field(emu_env):
+@pytest.mark.parametrize("overlap", ["off", "auto"])
+def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
     """`python bench.py` as the driver runs it at N = 1 (here: 2^7 gates on the emulation): the headline, the verification against the oracle, the
     next rows and the verified proof all execute, and the line carries exactly the top-level fields the round-3 program printed (the refactoring
-    of bench.py into benchlib/ must not lose or rename one; an emulated line has no clock-derived field by construction)."""
+    of bench.py into benchlib/ must not lose or rename one; an emulated line has no clock-derived field by construction).  "off": the step as the
+    2^24 line runs it, one phase after the other; "auto": at this size the transforms are issued while the commitment threads run (the
+    configs[1] / configs[3] sub-runs)."""
     import json
     e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
-    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7"], cwd=ROOT, env=e, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7", "--overlap-phases", overlap], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
     d = json.loads(lines[0])
@@ -171,7 +175,8 @@ def test_bench_program_single_rank_line_has_every_field(emu_env):
     assert d["prover_verified"] is True
     assert set(d["next_rows"]) == {"quotient_evals_kernel", "perm_product", "poly_eval", "poly_lincomb_20_terms", "poly_div_linear", "prover_rounds"}
     assert all(v.get("same_proof_as_the_verified_one") for v in d["next_rows"]["prover_rounds"]["variants"].values()), d["next_rows"]["prover_rounds"]["variants"]
-    assert set(d["config"]) >= {"workload", "log_n", "curve", "bases", "scheme", "parallelism", "coset_inputs", "commit_batching"}
+    assert set(d["config"]) >= {"workload", "log_n", "curve", "bases", "scheme", "parallelism", "coset_inputs", "commit_batching", "phase_overlap"}
+    assert d["config"]["phase_overlap"] is (overlap == "auto")
 
 
 def test_bench_program_proof_only_sub_run(emu_env):
