@@ -20,7 +20,10 @@ def other_configs(args):
         try:
             fallback = None
             try:
-                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                # under the headline watchdog (benchlib/line.py): were the overlapped warm-up / timed steps ever to hang, the sub-run ends itself
+                # after a minute with exit code 4 instead of sitting out the timeout below
+                env = dict(os.environ, PLONK_BENCH_WATCHDOG="1", PLONK_BENCH_HEADLINE_BUDGET_S="60")
+                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True, env=env)
             except Exception as ex:         # noqa: BLE001 - these sizes overlap their two phases by default (--overlap-phases auto): if that run fails,
                 fallback = repr(ex)         # the phase-after-phase form of rounds 1-3 still gives the line, and the failure is recorded beside it
                 res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
