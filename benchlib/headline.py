@@ -30,7 +30,7 @@ def timed_steps(b, guard):
     dt = time.perf_counter() - t0
     phases_ms = {"transforms": round(b.phase["ntt"] / args.steps * 1e3, 3), "commitments": round(b.phase["msm"] / args.steps * 1e3, 3),
                  "note": ("--overlap-phases: the commitments run on their contexts WHILE the transforms are issued; 'transforms' = host clock until the last "
-                          "transform has finished, 'commitments' = what was left of the commitments after that") if getattr(b, "overlap", False) else
+                          "transform has finished, 'commitments' = what was left of the commitments after that") if (b.overlap or b.overlap_multi) else
                          "rank 0's host clock, split at the step's internal sync: the 33 transforms (with their exchanges), then the 13 commitments"}
     w.profile_enable(False)
     return b.max_over_ranks(dt), phases_ms
@@ -133,7 +133,7 @@ def _config(b):
                          f"2^{args.log_n}-gate {args.curve} circuit, n-domain part only (the 8n domain does not exist): 7 NTT(n) + 13 commit(n)"),
             "log_n": args.log_n, "curve": args.curve, "bases": args.bases, "scheme": scheme, "parallelism": parallelism, "coset_inputs": coset_inputs,
             "commit_batching": "plonk_commit_many_dev per prover round (5, 1, 5, 2), split over two contexts" if b.commit_batch else "one MSM per commitment",
-            "phase_overlap": bool(b.overlap), "rccl": b.rccl_info, **({"experiment_opts": b.experiment_opts} if b.experiment_opts else {})}
+            "phase_overlap": bool(b.overlap or b.overlap_multi), "rccl": b.rccl_info, **({"experiment_opts": b.experiment_opts} if b.experiment_opts else {})}
 
 
 def _exchange(b, kernels, phases_ms):

@@ -59,6 +59,11 @@ class Bench:
         # N = 1 only: the transforms on a context of their own, issued while the commitment threads run (--overlap-phases; cli.py has the numbers)
         self.overlap = (not self.multi and self.S == 1 and self.nbig > 0 and
                         (args.overlap_phases == "on" or (args.overlap_phases == "auto" and args.log_n <= 22)))
+        # N > 1 (and its one-GPU diagnostics): only on request, never by 'auto' — built at the end of round 4 without a GPU minute left, so
+        # NOT measured.  The two transform lanes get contexts (and communicators) of their own; the commitment threads run on the two commitment
+        # contexts while the main thread issues the distributed transforms, so the 33 all-to-alls are also covered by the MSMs of the step.
+        # Every collective still comes from the main thread, in the same order on every rank (all-to-alls, then the point all-gather).
+        self.overlap_multi = (self.multi and self.nbig > 0 and args.overlap_phases == "on" and (args.transport == "rccl" or bool(self.sim)))
         self._contexts()
         self._inputs()
         self._class_scheme_inputs()
@@ -77,6 +82,7 @@ class Bench:
         self.workers = [PlonkWorker(me=self.rank, device=self.local_rank, curve=args.curve) for _ in range(self.n_commit_lanes)]
         self.w = self.workers[0]
         self.wt = PlonkWorker(me=self.rank, device=self.local_rank, curve=args.curve) if self.overlap else self.w      # the transforms' context
+        self.step_workers = [PlonkWorker(me=self.rank, device=self.local_rank, curve=args.curve) for _ in range(self.n_lanes)] if self.overlap_multi else []
         self.q64 = self.w.q64
         if os.environ.get("PLONK_BENCH_MSM_WINDOW"):                 # experiment knob: force the Pippenger window (0 / unset: the library's cost model)
             for x in self.workers:
@@ -100,13 +106,17 @@ class Bench:
         if (self.world > 1 or args.multi_path) and self.transport == "rccl" and not self.sim:
             # one RCCL communicator per context (two streams -> two communicators), created in the same order on every rank; the
             # 128-byte ids travel once through the launcher's rendezvous — nothing else of the data path touches torch
-            ids = [PlonkWorker.comm_unique_id() for _ in self.workers] if self.rank == 0 else [None] * len(self.workers)
+            with_comm = self.workers + self.step_workers
+            ids = [PlonkWorker.comm_unique_id() for _ in with_comm] if self.rank == 0 else [None] * len(with_comm)
             dist.broadcast_object_list(ids, src=0)
-            for x, uid in zip(self.workers, ids):
+            for x, uid in zip(with_comm, ids):
                 x.comm_init(uid, self.rank, self.world)
             r_, w_, v_ = self.w.comm_info()
-            self.rccl_info = {"rank0_reports_world": w_, "rccl_version": v_, "communicators_per_rank": len(self.workers)}
+            self.rccl_info = {"rank0_reports_world": w_, "rccl_version": v_, "communicators_per_rank": len(with_comm)}
         self.provers = [RankProver(x, self.rank, self.S, exchange=self.noop_exchange, transport=self.transport) for x in self.workers[:self.n_lanes]]
+        # the provers of the STEP: their own contexts under --overlap-phases on, else the two above (the legs after the headline always use those)
+        self.step_provers = ([RankProver(x, self.rank, self.S, exchange=self.noop_exchange, transport=self.transport) for x in self.step_workers]
+                             if self.overlap_multi else self.provers)
         self.torch_comm = None
         if self.multi and self.transport == "torch" and not self.sim:
             from distributed_plonk_amd.class_prover import TorchComm
@@ -149,7 +159,7 @@ class Bench:
         self.bases = w.alloc(n_loc * 16 * self.q64)
         # SRS shard of this rank: pairwise-distinct points (or 2^11 random points tiled, dispatcher.rs:190-196)
         w.synth_bases(0x5EED + rank, 0 if args.bases == "distinct" else min(n_loc, 1 << 11), n_loc, self.bases.ptr)
-        for x in self.workers + ([self.wt] if self.wt is not self.w else []):
+        for x in self.workers + self._extra_contexts():
             x.init_dev(self.bases.ptr, n_loc, n, m if nbig else 0)      # both contexts hold the SRS shard in the resident limb form
             x.sync()
         # reference2d on N > 1 ranks: the zero-padded polynomial arrives as this rank's decimated rows, of which only the leading
@@ -191,13 +201,17 @@ class Bench:
             w.synth_fr(0xC0EFF + i, b.ptr, self.poly_len)
         w.synth_fr(0x5EC7, self.cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
 
+    def _extra_contexts(self):
+        """the contexts --overlap-phases adds to the two commitment contexts"""
+        return ([self.wt] if self.wt is not self.w else []) + self.step_workers
+
     # ------------------------------------------------------------------------------------------------ the operations of a step
     def ntt(self, lane, bufs, size, inv, coset, is_quot):
         """one whole-vector / distributed transform; the pair ping-pongs (the next step transforms this step's output)"""
         if self.S == 1:
             self.wt.ntt_dev(bufs[0].ptr, bufs[1].ptr, size, inv, coset)
         else:
-            self.provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
+            self.step_provers[lane].fft_dev(bufs[0].ptr, bufs[1].ptr, size, is_quot, inv, coset, out_layout=1)
         bufs[0], bufs[1] = bufs[1], bufs[0]
 
     def coset_fft_8n(self, lane, i):
@@ -206,7 +220,7 @@ class Bench:
         if self.padded:
             self.wt.coset_eval_dev(self.polys[i % len(self.polys)].ptr, self.poly_len, self.m, self.gen_limbs, buf_m[lane][0].ptr)
         elif self.rows_compact:
-            self.provers[lane].fft_dev(self.rows_compact[i % len(self.rows_compact)].ptr, buf_m[lane][1].ptr, self.m, True, False, True, out_layout=1,
+            self.step_provers[lane].fft_dev(self.rows_compact[i % len(self.rows_compact)].ptr, buf_m[lane][1].ptr, self.m, True, False, True, out_layout=1,
                                        row_len=self.row_len_m)
             buf_m[lane][0], buf_m[lane][1] = buf_m[lane][1], buf_m[lane][0]
         else:
@@ -285,7 +299,8 @@ class Bench:
 
     def _overlapped_finish(self, t_in, handle):
         """--overlap-phases: the commitment threads were started before the first transform was issued"""
-        self.wt.sync()
+        for x in (self.step_workers or [self.wt]):
+            x.sync()
         t_mid = time.perf_counter()
         res = self.commits_finish(handle)
         self.phase["ntt"] += t_mid - t_in                    # the transforms, with commitments running beside them
@@ -294,14 +309,15 @@ class Bench:
 
     def step_ref2d(self):
         t_in = time.perf_counter()
-        handle = self.commits_start(N_MSM) if self.overlap else None
+        overlap = self.overlap or self.overlap_multi
+        handle = self.commits_start(N_MSM) if overlap else None
         for i in range(N_NTT_SMALL):
             self.ntt(i % self.n_lanes, self.buf_n[i % len(self.buf_n)], self.n, True, False, False)
         for i in range(self.nbig - 1):
             self.coset_fft_8n(i % self.n_lanes, i)
         if self.nbig:
             self.ntt(0, self.buf_m[0], self.m, True, True, True)
-        if self.overlap:
+        if overlap:
             return self._overlapped_finish(t_in, handle)
         return self._commit_phase(t_in)
 
@@ -337,7 +353,7 @@ class Bench:
             self.torch.cuda.synchronize()
 
     def full_sync(self):
-        for x in set(self.workers) | {self.wt}:
+        for x in set(self.workers) | set(self._extra_contexts()):
             x.sync()
         self.dev_sync()
         if self.world > 1:
@@ -379,7 +395,7 @@ class Bench:
         if self.buf_n or self.buf_m:
             self.release_step_buffers()
         self.bases.free()
-        for x in self.workers + ([self.wt] if self.wt is not self.w else []):
+        for x in self.workers + self._extra_contexts():
             x.close()
         if self.dist.is_initialized():
             self.dist.destroy_process_group()

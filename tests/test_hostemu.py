@@ -155,6 +155,17 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
 
 
+def test_bench_program_multi_rank_with_phases_overlapped(emu_env):
+    """`--overlap-phases on` at N > 1 (never chosen by 'auto'; built without a GPU at the end of round 4): the two transform lanes on contexts and
+    communicators of their own, the distributed transforms issued from the main thread while the commitment threads run, the point all-gather
+    after the last all-to-all — same order of collectives on every rank, or this run would hang in the shared-memory communicator."""
+    from conftest import free_port
+    d = _bench_dry_run(emu_env, 2, free_port(), ("--overlap-phases", "on", "--no-class-prover", "--no-poly-parallel"))
+    assert d["emulated"] is True and d["config"]["phase_overlap"] is True and d["config"]["rccl"]["communicators_per_rank"] == 4
+    assert d["verified"] is True and all(d["verification"].values()), d["verification"]
+    assert d.get("aborted_optional_leg") is None and "error" not in (d["other_scheme"] or {}), d
+
+
 @pytest.mark.parametrize("overlap", ["off", "auto"])
 def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
     """`python bench.py` as the driver runs it at N = 1 (here: 2^7 gates on the emulation): the headline, the verification against the oracle, the
