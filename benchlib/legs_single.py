@@ -175,19 +175,37 @@ def _small_rows(b, inst, fs, consts):
     return small
 
 
-def _variants(b, inst, vk, pub, bl, proof):
-    """variants of the same rounds (identical proofs): the quotient from 6 cosets of H_n instead of the 8n-point domain,
-    and/or the 18 proving-key evaluation vectors kept resident across proofs (72 / 54 GiB at 2^24)"""
+def _variants(b, inst, vk, pub, bl, proof, full=True):
+    """variants of the same rounds (identical proofs).  Always: the reference's work with the 18 proving-key coset FFTs issued on a third
+    context beside rounds 1 and 2 (Prover(fft_helper=...): built at the end of round 4 without a GPU — this entry is its measurement).
+    `full`: the quotient from 6 cosets of H_n instead of the 8n-point domain, and/or the 18 proving-key evaluation vectors kept resident
+    across proofs (72 / 54 GiB at 2^24)"""
     from distributed_plonk_amd.prover import Prover
+    from distributed_plonk_amd.worker import PlonkWorker
     np, w, n = b.np, b.w, b.n
     variants = {}
     same_as_headline_proof = lambda pr: bool(all(np.array_equal(pr[k_][0], proof[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof"))
                                              and np.array_equal(np.stack(pr["wires_evals"]), np.stack(proof["wires_evals"])))
-    for vname, kw in (("resident_key_cosets", dict(cache_key_cosets=True)),
-                      ("six_cosets", dict(quotient_mode="classes6")),
-                      ("six_cosets_resident_key", dict(quotient_mode="classes6", cache_key_cosets=True))):
+    helper = None
+
+    def fft_helper():
+        """the third context: the step's transform context when the run has one (--overlap-phases), else a temporary one"""
+        nonlocal helper
+        if b.wt is not b.w:
+            return b.wt
+        helper = PlonkWorker(me=b.rank, device=b.local_rank, curve=b.args.curve)
+        helper.init_dev(inst.d_ck.ptr, inst.key_size, n, 8 * n)
+        helper.sync()
+        return helper
+
+    todo = [("key_coset_ffts_beside_rounds_1_2", lambda: dict(fft_helper=fft_helper()))]
+    if full:
+        todo += [("resident_key_cosets", lambda: dict(cache_key_cosets=True)),
+                 ("six_cosets", lambda: dict(quotient_mode="classes6")),
+                 ("six_cosets_resident_key", lambda: dict(quotient_mode="classes6", cache_key_cosets=True))]
+    for vname, kw_of in todo:
         try:
-            pvc = Prover(w, b.args.log_n, commit_helper=b.workers[1], **kw)
+            pvc = Prover(w, b.args.log_n, commit_helper=b.workers[1], **kw_of())
             pvc.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
             pvc._key["vk"] = vk                                          # same key: the 18 commitments are not repeated
             t_v = pr = None
@@ -202,6 +220,8 @@ def _variants(b, inst, vk, pub, bl, proof):
             pvc.close()
         except Exception as ex:     # noqa: BLE001 - a variant is a side note of a side leg
             variants[vname] = {"error": str(ex)}
+    if helper is not None:
+        helper.close()
     return variants
 
 
@@ -244,7 +264,7 @@ def prover_rounds(b, with_small_rows=True, with_variants=True):
     prover_verified = (bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s")) if not args.no_verify else None
     small = _small_rows(b, inst, fs, consts) if with_small_rows else {}
     pv.close()
-    variants = _variants(b, inst, vk, pub, bl, proof) if with_variants else {}
+    variants = _variants(b, inst, vk, pub, bl, proof, full=with_variants)
     row = {
         "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
         "rounds_ms": rounds,

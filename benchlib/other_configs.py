@@ -35,7 +35,7 @@ def other_configs(args):
                           "dominant_kernel": rf.get("kernel"), "frac": rf.get("frac"), "avg_launch_ms": rf.get("avg_launch_ms"),
                           "verified": d_.get("verified"), "verification": d_.get("verification"),
                           "proof_ms": d_.get("proof_ms"), "proof_constraints_per_s": d_.get("proof_constraints_per_s"),
-                          "prover_verified": d_.get("prover_verified"), **({"overlap_run_failed": fallback} if fallback else {})})
+                          "prover_verified": d_.get("prover_verified"), "proof_variants_ms": d_.get("proof_variants_ms"), **({"overlap_run_failed": fallback} if fallback else {})})
         except Exception as ex:             # noqa: BLE001 - the extra lines must never break the headline
             other.append({"config": label, "error": repr(ex)})
     return other

@@ -60,10 +60,16 @@ class Prover:
     XY has no flag byte, and (0, 1) there would be read as a finite (off-curve) point."""
 
     def __init__(self, worker: PlonkWorker, log_n: int, cache_key_cosets: bool = False, quotient_mode: str = "coset8n",
-                 commit_helper: Optional[PlonkWorker] = None):
+                 commit_helper: Optional[PlonkWorker] = None, fft_helper: Optional[PlonkWorker] = None):
         """commit_helper: a second context on the same GPU, `init`-ed with the same commit key: independent commitments of a
         round are then issued from two host threads on two streams (the sort / reduction phases and the wave tail of one MSM
         overlap the bucket accumulation of the other: ~9 % per commitment at 2^24 points).
+        fft_helper (quotient_mode "coset8n" without cache_key_cosets only): another context on the same GPU, `init`-ed for the same
+        domains.  18 of round 3's 25 coset FFTs are of proving-key polynomials and depend on nothing a proof draws; with a helper
+        they are issued on its stream by a host thread of their own at the START of the proof, beside the transforms and
+        commitments of rounds 1 and 2, and round 3 only joins them.  Same proof bytes.  What it is worth is the phase overlap
+        measured for the op mix (profiles/r04_overlap_probe.txt: -10.6 % at 2^20, -1.9 % at 2^24); unmeasured for the proof itself
+        (built when round 4's GPU time was spent): off unless a helper is passed.
         quotient_mode "coset8n": round 3 exactly as the reference does it (25 coset FFTs over the 8n-point domain, one coset
         iFFT).  "classes6": the same quotient polynomial from 6n evaluations — see _quotient_poly_classes."""
         self.w = worker
@@ -77,6 +83,8 @@ class Prover:
             raise ValueError("classes6 needs n >= 16: below that 5n+7 >= 6n-1 and the degree check of dispatcher2.rs:511-518 is vacuous")
         self.quotient_mode = quotient_mode
         self.commit_helper = commit_helper
+        self.fft_helper = fft_helper
+        self._key_ffts = None                 # (thread, 18 device pointers, errors) while the key's coset FFTs run beside rounds 1-2
         self._cls = None
         self._key = None
         self._bufs = []
@@ -293,6 +301,37 @@ class Prover:
         tick("round3_quotient", t0)
         return d_quot.ptr
 
+    def _key_ffts_start(self, alloc):
+        """fft_helper: the 18 key coset FFTs on the helper's stream, from a thread of their own (see __init__)"""
+        if self.fft_helper is None or self.quotient_mode != "coset8n" or self._key["cos"] is not None:
+            return
+        import threading
+        m, key, h, gen = self.m, self._key, self.fft_helper, self._gen_limbs
+        d_kc = alloc(18 * m)
+        kc = [d_kc.ptr + j * m * 32 for j in range(18)]
+        self.w.sync()                                   # the helper's stream reads the key polynomials this context's stream wrote
+        errs = []
+
+        def run():
+            try:
+                for j, src in enumerate(key["sel"] + key["sig"]):
+                    h.coset_eval_dev(src, self.n, m, gen, kc[j])
+                h.sync()
+            except BaseException as ex:     # noqa: BLE001 - re-raised by _key_ffts_join
+                errs.append(ex)
+
+        th = threading.Thread(target=run)
+        th.start()
+        self._key_ffts = (th, kc, errs)
+
+    def _key_ffts_join(self):
+        th, kc, errs = self._key_ffts
+        self._key_ffts = None
+        th.join()
+        if errs:
+            raise errs[0]
+        return kc
+
     def _quotient_poly(self, alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma) -> int:
         """Round 3 between the challenges and the split commitments (dispatcher2.rs:362-509): 25 coset FFTs over the 8n domain,
         the pointwise quotient evaluation, one coset iFFT.  Returns a device pointer to the m quotient coefficients."""
@@ -300,7 +339,9 @@ class Prover:
             return self._quotient_poly_classes(alloc, tick, wire_polys, perm_poly, pi_poly, alpha, beta, gamma)
         w, n, m, key = self.w, self.n, self.m, self._key
         t0 = time.perf_counter()
-        if key["cos"] is None:
+        if self._key_ffts is not None:
+            kc = self._key_ffts_join()
+        elif key["cos"] is None:
             d_kc = alloc(18 * m)
             kc = [d_kc.ptr + j * m * 32 for j in range(18)]
             for j, src in enumerate(key["sel"] + key["sig"]):
@@ -359,6 +400,18 @@ class Prover:
             w.sync()
             T[name] = T.get(name, 0.0) + (time.perf_counter() - t0) * 1e3
 
+        self._key_ffts_start(alloc)
+        try:
+            return self._rounds(wev, d_id, d_idx, d_pi, blinders, challenge, check_degree, keep, alloc, tick, proof)
+        finally:
+            if self._key_ffts is not None:              # an exception before round 3: do not leave the helper's thread behind
+                self._key_ffts[0].join()
+                self._key_ffts = None
+
+    def _rounds(self, wev, d_id, d_idx, d_pi, blinders, challenge, check_degree, keep, alloc, tick, proof) -> dict:
+        w, f, n, m, key = self.w, self.f, self.n, self.m, self._key
+        p = f.p
+        L, I = f.to_limbs, f.from_limbs
         # ---- Round 1 (:296-322): wire polynomials and their commitments
         t0 = time.perf_counter()
         WP = n + 2

@@ -192,7 +192,8 @@ def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
 
 def test_bench_program_proof_only_sub_run(emu_env):
     """`--next-rows proof` — what the configs[1] / configs[3] sub-runs of the default bench line use (benchlib/other_configs.py): the step, its
-    verification and ONE verified proof, without the quotient row, the O(n) rows and the same-proof variants."""
+    verification and ONE verified proof, without the quotient row, the O(n) rows and the same-proof variants that do less than the
+    reference's work (the one that only re-schedules it stays: Prover(fft_helper=...))."""
     import json
     e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
     r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7", "--curve", "bls12_381", "--next-rows", "proof"], cwd=ROOT, env=e,
@@ -200,7 +201,9 @@ def test_bench_program_proof_only_sub_run(emu_env):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
     d = json.loads(lines[0])
-    assert d["verified"] is True and d["prover_verified"] is True and set(d["next_rows"]) == {"prover_rounds"} and d["next_rows"]["prover_rounds"]["variants"] == {}
+    assert d["verified"] is True and d["prover_verified"] is True and set(d["next_rows"]) == {"prover_rounds"}
+    var = d["next_rows"]["prover_rounds"]["variants"]          # only the one that does the reference's work (key coset FFTs beside rounds 1-2)
+    assert set(var) == {"key_coset_ffts_beside_rounds_1_2"} and var["key_coset_ffts_beside_rounds_1_2"]["same_proof_as_the_verified_one"] is True, var
 
 
 def test_differential_fuzz_slice(emu_env):
@@ -236,3 +239,62 @@ print("devices ok")
 """
     r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=emu_env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "devices ok" in r.stdout, (r.stdout + r.stderr)[-2000:]
+
+
+def test_prover_key_coset_ffts_beside_rounds_1_and_2(emu_env):
+    """Prover(fft_helper=...): the 18 proving-key coset FFTs of round 3 issued on a third context by a thread of their own while rounds 1 and 2
+    run (built at the end of round 4 without a GPU: an option, off by default, kept off the `-m gpu` list until it has met the device).  Same
+    proof as the plain prover, bit for bit; accepted by the verifier; an unsatisfied witness still
+    raises and leaves no thread behind."""
+    code = r"""
+import threading
+import numpy as np
+from distributed_plonk_amd.worker import PlonkWorker
+from distributed_plonk_amd.prover import Prover, WrongQuotientPolyDegree
+from distributed_plonk_amd.synthetic import SyntheticInstance
+from distributed_plonk_amd.transcript import PlonkTranscript
+from oracle import bigint_ref as B, oracle as O, verifier_ref as V
+for curve, cid, log_n in (("bn254", 0, 5),):
+    TAU = 0x1234567 + cid
+    w, c2, h = (PlonkWorker(me=0, device=0, curve=curve) for _ in range(3))
+    inst = SyntheticInstance(w, log_n, seed=77 + cid, num_inputs=3, tau=TAU, helpers=(c2, h))
+    bl = {"wires": O.rand_fr(cid, 3, 10).reshape(5, 2, 4), "perm": O.rand_fr(cid, 4, 3)}
+    pub = inst.public_inputs()
+    proofs = []
+    for kw in ({}, {"fft_helper": h, "commit_helper": c2}):
+        pv = Prover(w, log_n, **kw)
+        pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+        for it in range(2):                                   # the second proof reuses the named work buffers
+            pr = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, pv.fiat_shamir(pub))
+        vk = pv.verifying_key()
+        proofs.append(pr)
+        assert pv._key_ffts is None
+        pv.close()
+    for pr in proofs[1:]:
+        for k_ in ("wires_poly_comms", "split_quot_poly_comms"):
+            assert all(np.array_equal(a[0], b[0]) and a[1] == b[1] for a, b in zip(pr[k_], proofs[0][k_])), k_
+        for k_ in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+            assert np.array_equal(pr[k_][0], proofs[0][k_][0]) and pr[k_][1] == proofs[0][k_][1], k_
+        for k_ in ("wires_evals", "wire_sigma_evals"):
+            assert np.array_equal(np.stack(pr[k_]), np.stack(proofs[0][k_])), k_
+        assert np.array_equal(pr["perm_next_eval"], proofs[0]["perm_next_eval"])
+    V.verify(B.CURVES[curve], vk, pub, proofs[1], TAU, transcript=PlonkTranscript(curve))
+    # an unsatisfied witness: the degree check raises after the helper's thread has been joined
+    bad = w.alloc(inst.n * 32)
+    bad.upload(O.rand_fr(cid, 99, inst.n))
+    pv = Prover(w, log_n, fft_helper=h)
+    pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+    before = threading.active_count()
+    try:
+        pv.prove_dev([bad.ptr] + list(inst.wev[1:]), inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, pv.fiat_shamir(pub))
+        raise SystemExit("an unsatisfied witness was proved")
+    except WrongQuotientPolyDegree:
+        pass
+    assert pv._key_ffts is None and threading.active_count() == before
+    pv.close(); bad.free(); inst.close()
+    for x in (w, c2, h):
+        x.close()
+print("helper ok")
+"""
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, env=emu_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "helper ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
