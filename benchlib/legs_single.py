@@ -176,8 +176,8 @@ def _small_rows(b, inst, fs, consts):
 
 
 def _variants(b, inst, vk, pub, bl, proof, full=True):
-    """variants of the same rounds (identical proofs).  Always: the reference's work with the 18 proving-key coset FFTs issued on a third
-    context beside rounds 1 and 2 (Prover(fft_helper=...): built at the end of round 4 without a GPU — this entry is its measurement).
+    """variants of the same rounds (identical proofs).  In the sub-runs: the reference's work with the 18 proving-key coset FFTs issued on a
+    third context beside rounds 1 and 2 (Prover(fft_helper=...): built at the end of round 4 without a GPU — this entry is its measurement).
     `full`: the quotient from 6 cosets of H_n instead of the 8n-point domain, and/or the 18 proving-key evaluation vectors kept resident
     across proofs (72 / 54 GiB at 2^24)"""
     from distributed_plonk_amd.prover import Prover
@@ -198,7 +198,12 @@ def _variants(b, inst, vk, pub, bl, proof, full=True):
         helper.sync()
         return helper
 
-    todo = [("key_coset_ffts_beside_rounds_1_2", lambda: dict(fft_helper=fft_helper()))]
+    import os
+    # Where the untimed variant runs: in the `--next-rows proof` runs (the configs[1] / configs[3] sub-runs, own processes: whatever happened there
+    # could not cost the 2^24 line), not in the process that carries the headline unless PLONK_BENCH_HELPER_VARIANT=1 asks for it; never in
+    # the fall-back run of benchlib/other_configs.py.
+    want = (not full or os.environ.get("PLONK_BENCH_HELPER_VARIANT") == "1") and not os.environ.get("PLONK_BENCH_NO_HELPER_VARIANT")
+    todo = [("key_coset_ffts_beside_rounds_1_2", lambda: dict(fft_helper=fft_helper()))] if want else []
     if full:
         todo += [("resident_key_cosets", lambda: dict(cache_key_cosets=True)),
                  ("six_cosets", lambda: dict(quotient_mode="classes6")),

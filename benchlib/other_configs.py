@@ -26,7 +26,8 @@ def other_configs(args):
                 res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True, env=env)
             except Exception as ex:         # noqa: BLE001 - these sizes overlap their two phases by default (--overlap-phases auto): if that run fails,
                 fallback = repr(ex)         # the phase-after-phase form of rounds 1-3 still gives the line, and the failure is recorded beside it
-                res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True)
+                res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True,
+                                     env=dict(os.environ, PLONK_BENCH_NO_HELPER_VARIANT="1"))      # nothing of what round 4 built untimed
             d_ = json.loads(res.stdout.decode().strip().splitlines()[-1])
             rf = d_.get("roofline") or {}
             other.append({"config": label, "ms_per_step": d_["ms_per_step"], "constraints_per_s": d_["value"], "steps": d_["steps"],
