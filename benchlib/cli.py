@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--overlap-phases", default="auto", choices=["auto", "on", "off"],
                     help="N = 1: issue the step's transforms on their own context WHILE the 13 commitments run on the two commitment contexts, instead "
                          "of one phase after the other.  Measured with the shipped library (tools/overlap_probe.py, profiles/r04_overlap_probe.txt): "
-                         "-10.6 % at 2^20 BN254, -5.6 % at 2^22 BLS12-381, -1.9 % at 2^24 BN254.  'auto' = on up to 2^22 gates (launch gaps and wave "
+                         "-10.6 %% at 2^20 BN254, -5.6 %% at 2^22 BLS12-381, -1.9 %% at 2^24 BN254.  'auto' = on up to 2^22 gates (launch gaps and wave "
                          "tails are a tenth of such a step), off above (the 2^24 line keeps per-launch NTT timings that a concurrent accumulation would "
                          "stretch: they are what `roofline` is computed from).  N > 1 (and --simulate-ranks / --multi-path): only 'on' has an effect — "
                          "the two transform lanes get contexts and communicators of their own and the commitment threads run beside the distributed "
