@@ -162,3 +162,11 @@ def test_committed_pmc_profile_was_collected_from_the_shipped_sources():
     pmc, note = bench.load_pmc("2^24@bn254@1")
     assert note is None and {"ntt_pass_kernel", "msm_accumulate_kernel"} <= set(pmc)
     assert pmc["ntt_pass_kernel"]["traffic_bytes"] > 2 ** 31 and pmc["msm_accumulate_kernel"]["SQ_INSTS_VALU"] > 10 ** 9
+
+
+def test_bench_help_renders():
+    """argparse formats help strings with `%`: a bare percent sign in one of them breaks `bench.py --help` (it did, once)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "--overlap-phases" in r.stdout, r.stderr[-1500:]
