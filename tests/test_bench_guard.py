@@ -170,3 +170,28 @@ def test_bench_help_renders():
     import sys
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "--overlap-phases" in r.stdout, r.stderr[-1500:]
+
+
+def test_other_configs_fall_back_to_the_phase_after_phase_run(monkeypatch):
+    """benchlib/other_configs.py: the configs[1] / configs[3] sub-runs overlap their phases by default, under the headline watchdog; should such a
+    run fail (exit code, time-out), the same configuration is run once more with --overlap-phases off and without the untimed proof variant,
+    and the entry records what happened — the 2^24 line never pays for it."""
+    import json
+    import types
+    import benchlib.other_configs as oc
+    calls = []
+
+    def fake_run(cmd, **kw):
+        env = kw.get("env") or {}
+        calls.append((list(cmd), env.get("PLONK_BENCH_WATCHDOG"), env.get("PLONK_BENCH_NO_HELPER_VARIANT"), kw.get("timeout")))
+        if "--overlap-phases" not in cmd:
+            raise subprocess.CalledProcessError(4, cmd)
+        line = {"ms_per_step": 1.0, "value": 2.0, "steps": 3, "phases_ms": {"transforms": 1, "commitments": 2, "note": "x"}, "config": {"phase_overlap": False},
+                "roofline": {"kernel": "k", "frac": 0.1, "avg_launch_ms": 1}, "verified": True, "verification": {}, "proof_ms": 5, "prover_verified": True}
+        return types.SimpleNamespace(stdout=json.dumps(line).encode())
+
+    monkeypatch.setattr(oc.subprocess, "run", fake_run)
+    res = oc.other_configs(types.SimpleNamespace(bases="distinct"))
+    assert len(res) == 2 and all(r["phase_overlap"] is False and "CalledProcessError" in r["overlap_run_failed"] and r["verified"] for r in res), res
+    assert [c[1:] for c in calls] == [("1", None, 300), (None, "1", 600)] * 2
+    assert all(c[0][-2:] == ["--overlap-phases", "off"] for c in calls[1::2])
