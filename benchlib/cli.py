@@ -47,13 +47,13 @@ def parse():
                          "The other scheme is timed after the headline and reported as `other_scheme`")
     ap.add_argument("--overlap-phases", default="auto", choices=["auto", "on", "off"],
                     help="N = 1: issue the step's transforms on their own context WHILE the 13 commitments run on the two commitment contexts, instead "
-                         "of one phase after the other.  Measured with the shipped library (tools/overlap_probe.py, profiles/r04_overlap_probe.txt): "
-                         "-10.6 %% at 2^20 BN254, -5.6 %% at 2^22 BLS12-381, -1.9 %% at 2^24 BN254.  'auto' = on up to 2^22 gates (launch gaps and wave "
-                         "tails are a tenth of such a step), off above (the 2^24 line keeps per-launch NTT timings that a concurrent accumulation would "
-                         "stretch: they are what `roofline` is computed from).  N > 1 (and --simulate-ranks / --multi-path): only 'on' has an effect — "
-                         "the two transform lanes get contexts and communicators of their own and the commitment threads run beside the distributed "
-                         "transforms, so the MSMs also cover the 33 all-to-alls; every collective still comes from the main thread.  Built at the end "
-                         "of round 4 with no GPU time left: NOT measured, never chosen by 'auto'")
+                         "of one phase after the other.  Measured as whole bench steps, same lease (profiles/r05_opening_measurements.txt): "
+                         "-13.3 %% at 2^20 BN254, -3.7 %% at 2^22 BLS12-381; -1.9 %% at 2^24 BN254 (profiles/r04_overlap_probe.txt).  'auto' = on up to "
+                         "2^22 gates (launch gaps and wave tails are a tenth of such a step), off above (the 2^24 line keeps per-launch NTT timings that "
+                         "a concurrent accumulation would stretch: they are what `roofline` is computed from).  N > 1 (and --simulate-ranks / "
+                         "--multi-path): 'auto' = on — the two transform lanes get contexts and communicators of their own and the commitment threads "
+                         "run beside the distributed transforms, so the MSMs also cover the 33 all-to-alls; every collective still comes from the "
+                         "main thread (rank 0 of 8 simulated: 101.6 -> 96.2 ms per step)")
     ap.add_argument("--dry-run", action="store_true",
                     help="no GPU: validate the arguments for this --gpus (divisibility of r and n, class count, buffer sizes per rank) and print the plan")
     ap.add_argument("--multi-path", action="store_true",

@@ -59,11 +59,11 @@ class Bench:
         # N = 1 only: the transforms on a context of their own, issued while the commitment threads run (--overlap-phases; cli.py has the numbers)
         self.overlap = (not self.multi and self.S == 1 and self.nbig > 0 and
                         (args.overlap_phases == "on" or (args.overlap_phases == "auto" and args.log_n <= 22)))
-        # N > 1 (and its one-GPU diagnostics): only on request, never by 'auto' — built at the end of round 4 without a GPU minute left, so
-        # NOT measured.  The two transform lanes get contexts (and communicators) of their own; the commitment threads run on the two commitment
-        # contexts while the main thread issues the distributed transforms, so the 33 all-to-alls are also covered by the MSMs of the step.
-        # Every collective still comes from the main thread, in the same order on every rank (all-to-alls, then the point all-gather).
-        self.overlap_multi = (self.multi and self.nbig > 0 and args.overlap_phases == "on" and (args.transport == "rccl" or bool(self.sim)))
+        # N > 1 (and its one-GPU diagnostics): on unless 'off' (profiles/r05_opening_measurements.txt: rank 0 of 8 simulated, 101.6 -> 96.2 ms per
+        # step in one lease).  The two transform lanes get contexts (and communicators) of their own; the commitment threads run on the two
+        # commitment contexts while the main thread issues the distributed transforms, so the 33 all-to-alls are also covered by the MSMs of the
+        # step.  Every collective still comes from the main thread, in the same order on every rank (all-to-alls, then the point all-gather).
+        self.overlap_multi = (self.multi and self.nbig > 0 and args.overlap_phases != "off" and (args.transport == "rccl" or bool(self.sim)))
         self._contexts()
         self._inputs()
         self._class_scheme_inputs()

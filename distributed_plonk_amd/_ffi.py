@@ -97,6 +97,9 @@ SIGNATURES = {
     "plonk_debug_field_op": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plonk_quotient_evals_dev": (C.c_int, [C.c_void_p, C.POINTER(QuotientInputs), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plonk_perm_product_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p * 5), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "plonk_perm_product_range_dev": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p * 5), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t,
+                                               C.c_size_t, C.c_void_p]),
+    "plonk_class_interleave_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int, C.c_void_p, C.c_void_p]),
     "plonk_poly_eval_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "plonk_poly_lincomb_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "plonk_poly_div_linear_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),

@@ -243,13 +243,13 @@ static int get_shift_set(NttTables& T, const Fr& h, int L, uint64_t B, int w0, i
                           T.plane_bytes, T.plane_budget);
     const Fr wB = host_pow2k(T.h_root[0], T.two_adicity - (L + logB), P);          // primitive (M*B)-th root of unity
     std::vector<F29> h_row, h_fold;
-    h_row.reserve(B * R1); h_fold.reserve(B * 4);
+    h_row.reserve(B * R1); h_fold.reserve(B * NTT_MAX_FOLD);
     std::vector<Fr> hq(B);
     Fr acc = h;
     for (uint64_t q = 0; q < B; q++) { hq[q] = acc; acc = fp_mul(acc, wB, P); }
     for (uint64_t q = 0; q < B; q++) {
         host_powers_const(h_row, host_pow2k(hq[q], L - w0, P), R1, P);             // (h_q^r_1)^a
-        host_powers_const(h_fold, host_pow2k(hq[q], L, P), 4, P);                  // (h_q^M)^u
+        host_powers_const(h_fold, host_pow2k(hq[q], L, P), NTT_MAX_FOLD, P);                  // (h_q^M)^u
     }
     struct Guard {                 // frees whatever has been allocated unless the set is handed over
         NttTables::ShiftSet* s; F29* extra = nullptr; bool armed = true;
@@ -416,9 +416,9 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
     const NttTables::ShiftSet* sset = nullptr;
     if (c.shared_in) {
         const bool epi_ok = c.epi.kind == 0 || ((c.epi.kind == 3 || c.epi.kind == 4) && c.epi.bq == 1 && c.epi.b0 == 0 && c.epi.aq == 0 && c.epi.a0 == 0);
-        if (interleaved || c.inverse || c.pro.kind || !epi_ok || c.in_len == 0 || c.in_len > 4 * M || c.in_rows == 0 || Bt % c.in_rows ||
+        if (interleaved || c.inverse || c.pro.kind || !epi_ok || c.in_len == 0 || c.in_len > NTT_MAX_FOLD * M || c.in_rows == 0 || Bt % c.in_rows ||
             (c.row_coset_const && c.epi.kind == 0))
-            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, 1 <= len <= 4M, batch = rows * classes");
+            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, 1 <= len <= 8M, batch = rows * classes");
         if (NP > 1 && (c.work == nullptr || (const void*)c.work == (const void*)c.out || (const void*)c.work == (const void*)c.in))
             return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation needs a separate work buffer");
         if (NP == 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation cannot run in place");
@@ -478,7 +478,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
             P.in_row_pitch = c.in_pitch;
             P.in_len = c.in_len;
             P.fold_m = M;
-            P.nfold = (uint32_t)std::min<uint64_t>(4, (c.in_len + M - 1) / M);
+            P.nfold = (uint32_t)std::min<uint64_t>(NTT_MAX_FOLD, (c.in_len + M - 1) / M);
             P.fold_c = sset->foldc;
             P.pro_rowtab = sset->rowtabs;
             P.rowtab_qstride = (uint64_t)1 << widths[0];

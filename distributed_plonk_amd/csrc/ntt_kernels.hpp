@@ -32,6 +32,9 @@ typedef FpParams<8> FrParams;
 
 #define NTT_LOG_RMAX 9    // largest in-LDS transform (2^9 elements: 4096-element tile x 36 B = 144 KiB)
 #define NTT_MAX_PASSES 4
+// coefficients beyond the size M of a shared-input evaluation fold back onto it: at most this many pieces of M (8: the class-local size-n iNTT of
+// an 8-rank prover reads n evaluations as the coefficients of an (n/8)-point evaluation, class_prover.py)
+#define NTT_MAX_FOLD 8
 
 // exponent = idx * (bq*q + b0) + (aq*q + a0); value = lo[e & mask] * hi[e >> lt]   (constants: c*2^261 mod p)
 struct TwoLevelScale {
@@ -86,7 +89,7 @@ struct NttPassParams {
     uint64_t in_len;                      // 0: dense per-array input
     uint64_t fold_m;
     uint32_t nfold;
-    const F29* fold_c;                    // [class][4], constant form
+    const F29* fold_c;                    // [class][NTT_MAX_FOLD], constant form
     // Arrays = rows x classes, array A = row << cls_log | class: the classes of a row read that row's coefficients
     // (in + row * in_row_pitch) and share the per-class tables; in the last pass the classes of a row interleave into that row's
     // natural order: output index k' = k << cls_log | class, output array = row.  cls_log = 0: every array is its own row (the
@@ -361,12 +364,13 @@ __global__ void __launch_bounds__(EPT_REQ <= 4 ? 1024 : 512) ntt_pass_kernel(con
                 for (int l = 0; l < 9; l++) v.l[l] = 0;
             }
             if (P.nfold > 1 && pos + P.fold_m < P.in_len) {       // a handful of elements per transform (n + 3 coefficients on n points)
-                const F29* fc = P.fold_c + 4 * cls;
+                const F29* fc = P.fold_c + NTT_MAX_FOLD * cls;
                 for (uint32_t uu = 1; uu < P.nfold; uu++) {
                     const uint64_t j = pos + (uint64_t)uu * P.fold_m;
                     if (j < P.in_len) v = f29_add(v, f29_mul(f29_from_sat(load_fr(src + j)), load_f29(fc + uu), P.fp));
+                    if (uu == 3) f29_norm(v);                     // limbs: at most four normalised values summed between normalisations
                 }
-                f29_norm(v);                                      // < p + 3 * 1.36 p
+                f29_norm(v);                                      // < p + 7 * 1.36 p = 10.6 p: inside the row product's operand range (2^261 > 70 p)
             }
         } else {
             v = f29_from_sat(load_fr(P.in + lbase + (uint64_t)a * P.l_astride + (uint64_t)t * P.l_tstride));

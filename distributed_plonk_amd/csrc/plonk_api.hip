@@ -852,10 +852,27 @@ extern "C" int plonk_perm_product_dev(plonk_ctx* ctx, const void* const d_wires[
     int rc = ensure_scratch2(ctx, perm_product_scratch_bytes(n));
     if (rc) return rc;
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    rc = perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, d_out, ctx->d_scratch2, ctx->stream);
+    rc = perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, 0, n, d_out, ctx->d_scratch2, ctx->stream);
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     return rc;
+}
+extern "C" int plonk_perm_product_range_dev(plonk_ctx* ctx, const void* const d_wires[5], const void* d_id_perm, const void* d_perm_idx,
+                                            const uint64_t* beta, const uint64_t* gamma, size_t n, size_t first, size_t count, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_wires || !d_id_perm || !d_perm_idx || !beta || !gamma || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_range_dev: null");
+    for (int j = 0; j < 5; j++) if (!d_wires[j]) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_range_dev: null wire %d", j);
+    if (n < 2 || n >= ((size_t)1 << 32)) return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_range_dev: n = %zu", n);
+    if (count == 0 || first >= n || count > n - first)
+        return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_range_dev: gates [%zu, %zu + %zu) of %zu", first, first, count, n);
+    int rc = ensure_scratch2(ctx, perm_product_scratch_bytes(count));
+    if (rc) return rc;
+    return perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, first, count, d_out, ctx->d_scratch2, ctx->stream);
+}
+extern "C" int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out) {
+    CHECK_CTX(ctx);
+    if (!d_in || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_class_interleave_dev: null");
+    return class_interleave_run(ctx->tables, d_in, classes, size, reverse, scale, d_out, ctx->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- round 4/5 polynomial ops (§8f rank 3)

@@ -94,7 +94,7 @@ struct NttTables {
     struct ShiftSet {
         Fr* planes = nullptr;       // [B][M]: w_M^(b*i) * h_q^b            (transforms of two or more passes)
         F29* rowtabs = nullptr;     // [B][R_1]: h_q^(a * r_1)
-        F29* foldc = nullptr;       // [B][4]: (h_q^M)^u
+        F29* foldc = nullptr;       // [B][NTT_MAX_FOLD]: (h_q^M)^u
         size_t bytes = 0;
     };
     std::unordered_map<std::string, ShiftSet> shift_sets;
@@ -218,7 +218,8 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
                        const uint64_t* gamma, const uint64_t* k, uint32_t cls_stride, uint32_t cls_offset, void* d_out, hipStream_t stream);
 size_t perm_product_scratch_bytes(size_t n);
 int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
-                     size_t n, void* d_out, void* scratch, hipStream_t stream);
+                     size_t n_all, size_t j0, size_t cnt, void* d_out, void* scratch, hipStream_t stream);
+int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out, hipStream_t stream);
 size_t poly_scratch_bytes(size_t len);
 int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out_host, void* scratch, hipStream_t stream);
 int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const size_t* lens, const uint64_t* coeffs, void* d_out, size_t out_len,

@@ -286,6 +286,7 @@ struct PermParams {
     Fr* num;                  // rep(A_j * 2^-25)
     Fr* den;                  // rep(B_j * 2^-25); den[n-1] = rep(1)
     uint64_t n;
+    uint64_t j0, cnt;         // the gates [j0, j0 + cnt) of this launch (a rank's slice; the whole product: 0, n); num / den are indexed by j - j0
     F29 gamma_r;              // gamma * 2^256 (plain limbs of the Montgomery form)
     F29 beta_c;               // rep(beta)
     uint32_t* flag;           // bit 0: zero denominator, bit 1: permutation index out of range
@@ -293,13 +294,14 @@ struct PermParams {
 };
 
 __global__ void __launch_bounds__(256) perm_terms_kernel(const PermParams P) {
-    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P.cnt) return;
+    const uint64_t j = P.j0 + t;
     const F29Params& fp = P.c.f29;
     if (j == P.n - 1) {                       // the reference's loop stops at n-2 (dispatcher2.rs:331)
         const Fr one = f29_to_sat(f29_canon(params_one(fp), fp));
-        store_fr(P.num + j, one);
-        store_fr(P.den + j, one);
+        store_fr(P.num + t, one);
+        store_fr(P.den + t, one);
         return;
     }
     F29 a, b;
@@ -318,8 +320,8 @@ __global__ void __launch_bounds__(256) perm_terms_kernel(const PermParams P) {
     }
     const Fr ac = f29_to_sat(f29_canon(a, fp)), bc = f29_to_sat(f29_canon(b, fp));
     if (fp_is_zero(bc)) atomicOr(P.flag, 1u);
-    store_fr(P.num + j, ac);
-    store_fr(P.den + j, bc);
+    store_fr(P.num + t, ac);
+    store_fr(P.den + t, bc);
 }
 
 // kconst = (1 / D) * 2^256 as plain limbs, D given in rep form: one lane, Fermat
@@ -353,10 +355,14 @@ static uint64_t tiles_of(uint64_t n) { return (n + PO_TILE - 1) / PO_TILE; }
 
 size_t perm_product_scratch_bytes(size_t n) { return 3 * align256(n * 32) + 2 * align256(tiles_of(n) * 32) + 1024; }
 
+// d_out[t] = prod_{j0 <= k < j0 + t} num_k / den_k, t < cnt: the product vector of dispatcher2.rs:329-344 for (j0, cnt) = (0, n); a rank's
+// slice of it up to the factor prod_{k < j0} for any other range (class_prover.py: cnt = slice + 1, so that the last value is the slice's total)
 int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
-                     size_t n, void* d_out, void* scratch, hipStream_t stream) {
+                     size_t n_all, size_t j0, size_t cnt, void* d_out, void* scratch, hipStream_t stream) {
     const FrParams& P = T.fp;
-    if (n < 2) return plonk_fail(PLONK_ERR_ARG, "perm_product: n = %zu", n);
+    if (n_all < 2) return plonk_fail(PLONK_ERR_ARG, "perm_product: n = %zu", n_all);
+    if (cnt == 0 || j0 + cnt > n_all) return plonk_fail(PLONK_ERR_ARG, "perm_product: gates [%zu, %zu) of %zu", j0, j0 + cnt, n_all);
+    const size_t n = cnt;                     // everything below the terms kernel works on the slice
     if (!fr_arg_ok(beta, P) || !fr_arg_ok(gamma, P)) return plonk_fail(PLONK_ERR_ARG, "perm_product: challenge not reduced");
     char* s = (char*)scratch;
     Fr* A = (Fr*)s; s += align256(n * 32);
@@ -373,7 +379,7 @@ int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm
     memset(&q, 0, sizeof q);
     for (int i = 0; i < 5; i++) q.wire[i] = (const Fr*)wires[i];
     q.id = (const Fr*)id_perm; q.idx = (const uint64_t*)perm_idx;
-    q.num = A; q.den = B; q.n = n;
+    q.num = A; q.den = B; q.n = n_all; q.j0 = j0; q.cnt = cnt;
     q.gamma_r = f29_from_sat(fr_arg(gamma));
     q.beta_c = host_rep(fr_arg(beta), P);
     q.flag = flag; q.c = c;
@@ -590,7 +596,7 @@ int coset_eval_run(NttTables& T, const void* d_poly, size_t len, size_t size, co
     while (((size_t)1 << log_s) < size) log_s++;
     if (((size_t)1 << log_s) != size || log_s < 1) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: size %zu is not a power of two >= 2", size);
     if (log_s > T.two_adicity) return plonk_fail(PLONK_ERR_DOMAIN, "coset_eval: 2^%d exceeds the two-adicity", log_s);
-    if (len > 4 * size) return plonk_fail(PLONK_ERR_ARG, "coset_eval: %zu coefficients for a %zu-point coset (limit 4x)", len, size);
+    if (len > NTT_MAX_FOLD * size) return plonk_fail(PLONK_ERR_ARG, "coset_eval: %zu coefficients for a %zu-point coset (limit %dx)", len, size, NTT_MAX_FOLD);
     if (!fr_arg_ok(shift, P)) return plonk_fail(PLONK_ERR_ARG, "coset_eval: shift not reduced");
     if (d_poly == d_out) return plonk_fail(PLONK_ERR_ARG, "coset_eval: d_out must not alias d_poly");
     if (len == 0) { HIP_TRY(hipMemsetAsync(d_out, 0, size * 32, stream)); return PLONK_OK; }      // the zero polynomial
@@ -639,6 +645,48 @@ int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* s
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "coset_unscale launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- classes -> natural order
+// out[t*G + s] = scale * in[s*L + (reverse ? (L - t) mod L : t)],  s < G classes of L values each: what the dispatcher does with the
+// workers' replies of a distributed transform (dispatcher2.rs:776-787: concatenate, transpose), for the class-decomposed size-n iNTT of
+// class_prover.py — rank s evaluates the n evaluations, read as coefficients, at w_n^-s * w_L^t' (plonk_coset_eval_dev, forward roots), so
+// coefficient s + G*t of the interpolant is 1/n times value (L - t) mod L of class s.  One lane per t: G coalesced (reversed) loads, one
+// contiguous G*32-byte store.
+template <int G>
+__global__ void __launch_bounds__(256) class_interleave_kernel(const Fr* __restrict__ in, uint64_t L, int reverse, int scaled, const F29 scale_c,
+                                                               Fr* __restrict__ out, const PoCtx c) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= L) return;
+    const uint64_t src = reverse ? (t == 0 ? 0 : L - t) : t;
+#pragma unroll
+    for (int s = 0; s < G; s++) {
+        Fr v = load_fr(in + (uint64_t)s * L + src);
+        if (scaled) v = f29_to_sat(f29_canon(f29_mul(f29_from_sat(v), scale_c, c.f29), c.f29));
+        store_fr(out + t * G + s, v);
+    }
+}
+int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    if (classes == 0 || (classes & (classes - 1)) || classes > 8) return plonk_fail(PLONK_ERR_ARG, "class_interleave: %zu classes (1, 2, 4 or 8)", classes);
+    if (size == 0 || size * classes >= ((size_t)1 << 32)) return plonk_fail(PLONK_ERR_ARG, "class_interleave: %zu values per class", size);
+    if (scale && !fr_arg_ok(scale, P)) return plonk_fail(PLONK_ERR_ARG, "class_interleave: scale not reduced");
+    if (d_in == d_out) return plonk_fail(PLONK_ERR_ARG, "class_interleave: in-place not supported");
+    const PoCtx c = make_ctx(T);
+    F29 sc;
+    memset(&sc, 0, sizeof sc);
+    if (scale) sc = host_rep(fr_arg(scale), P);
+    const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
+    ProfScope ps("class_interleave_kernel", stream);
+    switch (classes) {
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<1>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<2>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<4>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<8>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "class_interleave launch: %s", hipGetErrorString(e));
     return PLONK_OK;
 }
 

@@ -294,6 +294,18 @@ class PlonkWorker:
         be, ga = _u64(beta), _u64(gamma)
         check(self.lib.plonk_perm_product_dev(self.ctx, C.byref(arr), d_id_perm, d_perm_idx, _ptr(be), _ptr(ga), n, d_out))
 
+    def perm_product_range_dev(self, wires, d_id_perm: int, d_perm_idx: int, beta, gamma, n: int, first: int, count: int, d_out: int):
+        """d_out[t] = the product of the ratios of gates [first, first + t), t < count: a worker's slice of the product vector up to the
+        product of the gates before it (pointers are to the whole vectors)."""
+        arr = (C.c_void_p * 5)(*[int(w) for w in wires])
+        be, ga = _u64(beta), _u64(gamma)
+        check(self.lib.plonk_perm_product_range_dev(self.ctx, C.byref(arr), d_id_perm, d_perm_idx, _ptr(be), _ptr(ga), n, first, count, d_out))
+
+    def class_interleave_dev(self, d_in: int, classes: int, size: int, reverse: bool, scale, d_out: int):
+        """d_out[t * classes + s] = scale * d_in[s * size + (t, or (size - t) % size when reverse)]; scale None = 1."""
+        sc = None if scale is None else _u64(scale)
+        check(self.lib.plonk_class_interleave_dev(self.ctx, d_in, classes, size, 1 if reverse else 0, None if sc is None else _ptr(sc), d_out))
+
     def poly_eval_dev(self, d_poly: int, length: int, point) -> np.ndarray:
         """DensePolynomial::evaluate (dispatcher2.rs:545-555) -> Fr Montgomery limbs (4,)."""
         out = np.empty(4, dtype=np.uint64)
@@ -316,7 +328,7 @@ class PlonkWorker:
         check(self.lib.plonk_poly_div_linear_dev(self.ctx, d_poly, length, _ptr(z), d_out))
 
     def coset_eval_dev(self, d_poly: int, length: int, size: int, shift, d_out: int):
-        """d_out[k] = poly(shift * w_size^k), k < size (any shift; length <= 4*size folds back)."""
+        """d_out[k] = poly(shift * w_size^k), k < size (any shift; length <= 8*size folds back)."""
         h = _u64(shift)
         check(self.lib.plonk_coset_eval_dev(self.ctx, d_poly, length, size, _ptr(h), d_out))
 

@@ -112,6 +112,8 @@ extern "C" {
     pub fn plonk_quotient_evals_dev(ctx: *mut plonk_ctx, input: *const plonk_quotient_inputs, alpha: *const u64, beta: *const u64, gamma: *const u64, k: *const u64, d_out: *mut c_void) -> c_int;
     pub fn plonk_quotient_evals_class_dev(ctx: *mut plonk_ctx, input: *const plonk_quotient_inputs, alpha: *const u64, beta: *const u64, gamma: *const u64, k: *const u64, class_stride: u32, class_offset: u32, d_out: *mut c_void) -> c_int;
     pub fn plonk_perm_product_dev(ctx: *mut plonk_ctx, d_wires: *const *const c_void, d_id_perm: *const c_void, d_perm_idx: *const c_void, beta: *const u64, gamma: *const u64, n: usize, d_out: *mut c_void) -> c_int;
+    pub fn plonk_perm_product_range_dev(ctx: *mut plonk_ctx, d_wires: *const *const c_void, d_id_perm: *const c_void, d_perm_idx: *const c_void, beta: *const u64, gamma: *const u64, n: usize, first: usize, count: usize, d_out: *mut c_void) -> c_int;
+    pub fn plonk_class_interleave_dev(ctx: *mut plonk_ctx, d_in: *const c_void, classes: usize, size: usize, reverse: c_int, scale: *const u64, d_out: *mut c_void) -> c_int;
     pub fn plonk_poly_eval_dev(ctx: *mut plonk_ctx, d_poly: *const c_void, len: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn plonk_poly_lincomb_dev(ctx: *mut plonk_ctx, k: usize, d_polys: *const *const c_void, lens: *const usize, coeffs: *const u64, d_out: *mut c_void, out_len: usize) -> c_int;
     pub fn plonk_poly_div_linear_dev(ctx: *mut plonk_ctx, d_poly: *const c_void, len: usize, point: *const u64, d_out: *mut c_void) -> c_int;

@@ -207,6 +207,13 @@ int plonk_quotient_evals_class_dev(plonk_ctx* ctx, const plonk_quotient_inputs* 
  * is zero (the reference panics: Fp division unwraps the inverse).  Synchronises the context's stream. */
 int plonk_perm_product_dev(plonk_ctx* ctx, const void* const d_wires[5], const void* d_id_perm, const void* d_perm_idx,
                            const uint64_t* beta, const uint64_t* gamma, size_t n, void* d_out);
+/* A worker's slice of that vector, up to the product of the gates before it: d_out[t] = prod over gates first <= j < first + t of the
+ * same ratio, t < count (first + count <= n; gate n-1 contributes 1 as in the reference's loop, which stops at n-2).  With
+ * count = slice + 1 the last value is the slice's total: G workers exchange those 32-byte totals, and worker s multiplies its slice by the
+ * totals of the workers before it (class_prover.py) — the reference's serial dispatcher loop distributed like its FFTs
+ * (dispatcher2.rs:329-344 next to :732-787).  The pointers are to the WHOLE vectors (n / 5n entries).  Same errors; synchronises. */
+int plonk_perm_product_range_dev(plonk_ctx* ctx, const void* const d_wires[5], const void* d_id_perm, const void* d_perm_idx,
+                                 const uint64_t* beta, const uint64_t* gamma, size_t n, size_t first, size_t count, void* d_out);
 
 /* ---- next row: round 4/5 polynomial operations — dispatcher2.rs:545-555,566-633,646-688 ------
  * Coefficient vectors are device pointers to Fr (Montgomery); scalars (points, coefficients, blinders) are host Fr. */
@@ -227,7 +234,7 @@ int plonk_poly_degree_dev(plonk_ctx* ctx, const void* d_poly, size_t len, int64_
 int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uint64_t* blinders, size_t k);
 
 /* ---- evaluation on / interpolation from an ARBITRARY coset (building block of coset-class parallelism) ------
- * d_out[k] = poly(shift * w_size^k), k < size; size a power of two, len <= 4*size (coefficients beyond `size` fold back, since
+ * d_out[k] = poly(shift * w_size^k), k < size; size a power of two, len <= 8*size (coefficients beyond `size` fold back, since
  * X^size = shift^size on the coset).  shift = Fr::multiplicative_generator(), size = m: quot_domain.coset_fft (dispatcher2.rs:387-424)
  * of the zero-padded vector.  shift = g * w_m^s, size = m/G: the evaluations at the points of index s, s+G, s+2G, ... of that
  * same coset FFT — rank s's share of every round-3 vector with no communication.
@@ -241,6 +248,14 @@ int plonk_coset_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, size_t 
  * the sum over s < G of these vectors is coefficient i0+t of the polynomial interpolating all G cosets. */
 int plonk_coset_interp_dev(plonk_ctx* ctx, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count,
                            void* d_out);
+
+/* `classes` vectors of `size` values (d_in: class-major) -> natural order: d_out[t * classes + s] = scale * d_in[s * size + t'],
+ * t' = t, or (size - t) mod size with reverse != 0; scale = NULL: 1.  classes in {1, 2, 4, 8}; not in place.  What the dispatcher does
+ * with the column replies of a distributed transform (dispatcher2.rs:776-787: concatenate + transpose), for transforms split by
+ * residue class: a size-n iFFT over G workers is, on worker s, plonk_coset_eval_dev(evaluations, n, n / G, shift = w_n^-s) — the
+ * evaluations read as coefficients, folded G-fold onto n / G points — then an all-gather, then this call with reverse = 1,
+ * scale = 1 / n: coefficient s + G t of the interpolant is 1/n times value (n/G - t) mod n/G of class s. */
+int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out);
 
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
