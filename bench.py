@@ -65,8 +65,9 @@ def _proof_fields(out, next_rows, class_row):
         out["prover_verified"] = pr.get("prover_verified")
         names = {"resident_key_cosets": "8n_route_key_coset_vectors_resident_in_HBM", "six_cosets": "six_coset_quotient_key_not_resident",
                  "six_cosets_resident_key": "six_coset_quotient_key_resident",
-                 "key_coset_ffts_beside_rounds_1_2": "8n_route_key_not_resident_key_coset_ffts_on_a_third_context_beside_rounds_1_2"}
-        out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms)": pr["ms"]},
+                 "key_coset_ffts_beside_rounds_1_2": "8n_route_key_not_resident_key_coset_ffts_on_a_third_context_beside_rounds_1_2",
+                 "key_coset_ffts_inside_round_3": "8n_route_key_not_resident_key_coset_ffts_inside_round_3"}
+        out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms; key coset FFTs %s)" % pr.get("key_coset_ffts", "inside round 3"): pr["ms"]},
                                         **{names[k_]: v_.get("ms") for k_, v_ in (pr.get("variants") or {}).items()})
     if class_row and "ms" in class_row:
         out["proof_ms_class_prover_all_ranks"] = class_row["ms"]

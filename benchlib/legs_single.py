@@ -5,6 +5,8 @@ import time
 from .common import HBM_PEAK_GBS
 from .legs_multi import TAU_SEED
 
+HELPER_MAX_LOG_N = 22          # largest size at which the proof's key coset FFTs go to a third context by default (proof_helper_wanted)
+
 
 def verify_single(b):
     """-> the `verification` dict (every value must be True).  The oracle is used here and only here: as the checker."""
@@ -175,13 +177,37 @@ def _small_rows(b, inst, fs, consts):
     return small
 
 
+def proof_helper_wanted(args) -> bool:
+    """Prover(fft_helper=...): the 18 proving-key coset FFTs of round 3 on a third context beside rounds 1 and 2 (same proof bytes).  Same-lease
+    A/Bs (profiles/r05_opening_measurements.txt, r05_helper_2p24.txt): 2^20 BN254 63.3 -> 57.6 ms per proof, 2^22 BLS12-381 291.6 -> 282.0 ms.
+    PLONK_BENCH_PROOF_HELPER=0 / 1 overrides (A/B runs)."""
+    import os
+    return os.environ.get("PLONK_BENCH_PROOF_HELPER", "1" if args.log_n <= HELPER_MAX_LOG_N else "0") == "1"
+
+
+class _Helper:
+    """the third context: the step's transform context when the run has one (--overlap-phases), else a temporary one"""
+
+    def __init__(self, b, inst):
+        from distributed_plonk_amd.worker import PlonkWorker
+        self.own = None
+        if b.wt is not b.w:
+            self.ctx = b.wt
+            return
+        self.own = self.ctx = PlonkWorker(me=b.rank, device=b.local_rank, curve=b.args.curve)
+        self.ctx.init_dev(inst.d_ck.ptr, inst.key_size, b.n, 8 * b.n)
+        self.ctx.sync()
+
+    def close(self):
+        if self.own is not None:
+            self.own.close()
+
+
 def _variants(b, inst, vk, pub, bl, proof, full=True):
-    """variants of the same rounds (identical proofs).  In the sub-runs: the reference's work with the 18 proving-key coset FFTs issued on a
-    third context beside rounds 1 and 2 (Prover(fft_helper=...): built at the end of round 4 without a GPU — this entry is its measurement).
-    `full`: the quotient from 6 cosets of H_n instead of the 8n-point domain, and/or the 18 proving-key evaluation vectors kept resident
-    across proofs (72 / 54 GiB at 2^24)"""
+    """variants of the same rounds (identical proofs).  `full`: the quotient from 6 cosets of H_n instead of the 8n-point domain, and/or the 18
+    proving-key evaluation vectors kept resident across proofs (72 / 54 GiB at 2^24).  PLONK_BENCH_HELPER_AB=1 adds the headline's rounds with the
+    third context switched the other way (A/B runs of proof_helper_wanted's choice)."""
     from distributed_plonk_amd.prover import Prover
-    from distributed_plonk_amd.worker import PlonkWorker
     np, w, n = b.np, b.w, b.n
     variants = {}
     same_as_headline_proof = lambda pr: bool(all(np.array_equal(pr[k_][0], proof[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof"))
@@ -189,21 +215,15 @@ def _variants(b, inst, vk, pub, bl, proof, full=True):
     helper = None
 
     def fft_helper():
-        """the third context: the step's transform context when the run has one (--overlap-phases), else a temporary one"""
         nonlocal helper
-        if b.wt is not b.w:
-            return b.wt
-        helper = PlonkWorker(me=b.rank, device=b.local_rank, curve=b.args.curve)
-        helper.init_dev(inst.d_ck.ptr, inst.key_size, n, 8 * n)
-        helper.sync()
-        return helper
+        helper = _Helper(b, inst)
+        return helper.ctx
 
     import os
-    # Where the untimed variant runs: in the `--next-rows proof` runs (the configs[1] / configs[3] sub-runs, own processes: whatever happened there
-    # could not cost the 2^24 line), not in the process that carries the headline unless PLONK_BENCH_HELPER_VARIANT=1 asks for it; never in
-    # the fall-back run of benchlib/other_configs.py.
-    want = (not full or os.environ.get("PLONK_BENCH_HELPER_VARIANT") == "1") and not os.environ.get("PLONK_BENCH_NO_HELPER_VARIANT")
-    todo = [("key_coset_ffts_beside_rounds_1_2", lambda: dict(fft_helper=fft_helper()))] if want else []
+    todo = []
+    if os.environ.get("PLONK_BENCH_HELPER_AB") == "1":
+        todo.append(("key_coset_ffts_inside_round_3", lambda: {}) if proof_helper_wanted(b.args) else
+                    ("key_coset_ffts_beside_rounds_1_2", lambda: dict(fft_helper=fft_helper())))
     if full:
         todo += [("resident_key_cosets", lambda: dict(cache_key_cosets=True)),
                  ("six_cosets", lambda: dict(quotient_mode="classes6")),
@@ -247,7 +267,8 @@ def prover_rounds(b, with_small_rows=True, with_variants=True):
     t_gen = (time.perf_counter() - t0) * 1e3
     consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
     bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-    pv = Prover(w, args.log_n, commit_helper=workers[1])
+    helper = _Helper(b, inst) if proof_helper_wanted(args) else None
+    pv = Prover(w, args.log_n, commit_helper=workers[1], fft_helper=helper.ctx if helper else None)
     pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
     pub = inst.public_inputs()
     t0 = time.perf_counter()
@@ -269,11 +290,14 @@ def prover_rounds(b, with_small_rows=True, with_variants=True):
     prover_verified = (bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s")) if not args.no_verify else None
     small = _small_rows(b, inst, fs, consts) if with_small_rows else {}
     pv.close()
+    if helper is not None:
+        helper.close()
     variants = _variants(b, inst, vk, pub, bl, proof, full=with_variants)
     row = {
         "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
         "rounds_ms": rounds,
         "prover_verified": prover_verified, "prover_verification": pver,
+        "key_coset_ffts": "on a third context beside rounds 1 and 2" if helper is not None else "inside round 3",
         "setup_ms": {"circuit_key_and_trapdoor_srs_generation": round(t_gen, 1), "verifying_key_18_commitments": round(t_vk, 1)},
         "variants": variants,
         "reference": "dispatcher2.rs:296-712 (rounds 1-5: 13 commitments, 7 NTT(n), 26 NTT(8n), permutation product, quotient, "

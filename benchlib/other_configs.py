@@ -12,8 +12,13 @@ CONFIGS = (("configs[1]: 2^20-gate BN254, 1 GPU", ["--log-n", "20", "--curve", "
            ("configs[3]: 2^22-gate BLS12-381, 1 GPU", ["--log-n", "22", "--curve", "bls12_381"]))
 
 
+BUDGET_S = 240.0     # for BOTH sub-runs together (each takes ~25 s): the headline line is only written after this leg returns
+
+
 def other_configs(args):
+    import time
     other = []
+    t_end = time.monotonic() + BUDGET_S
     for label, extra in CONFIGS:
         cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bases", args.bases,
                "--no-cpu-baseline", "--next-rows", "proof", "--no-other-configs"] + extra
@@ -23,11 +28,14 @@ def other_configs(args):
                 # under the headline watchdog (benchlib/line.py): were the overlapped warm-up / timed steps ever to hang, the sub-run ends itself
                 # after a minute with exit code 4 instead of sitting out the timeout below
                 env = dict(os.environ, PLONK_BENCH_WATCHDOG="1", PLONK_BENCH_HEADLINE_BUDGET_S="60")
-                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=300, check=True, env=env)
+                res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=max(20.0, min(150.0, t_end - time.monotonic())), check=True,
+                                     env=env)
             except Exception as ex:         # noqa: BLE001 - these sizes overlap their two phases by default (--overlap-phases auto): if that run fails,
                 fallback = repr(ex)         # the phase-after-phase form of rounds 1-3 still gives the line, and the failure is recorded beside it
-                res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=600, check=True,
-                                     env=dict(os.environ, PLONK_BENCH_NO_HELPER_VARIANT="1"))      # nothing of what round 4 built untimed
+                if t_end - time.monotonic() < 45.0:
+                    raise TimeoutError(f"no time left for the phase-after-phase fall-back after {fallback}")
+                res = subprocess.run(cmd + ["--overlap-phases", "off"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL,
+                                     timeout=min(150.0, t_end - time.monotonic()), check=True, env=dict(os.environ, PLONK_BENCH_PROOF_HELPER="0"))
             d_ = json.loads(res.stdout.decode().strip().splitlines()[-1])
             rf = d_.get("roofline") or {}
             other.append({"config": label, "ms_per_step": d_["ms_per_step"], "constraints_per_s": d_["value"], "steps": d_["steps"],

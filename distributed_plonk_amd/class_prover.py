@@ -15,9 +15,20 @@ j = s (mod G), and class s is itself a coset  {(g * w_m^s) * w_(m/G)^k}.  Rank s
     partial points of a round (96/144 bytes each) travel in ONE all-gather and are added on the host.
 
 Of the O(n) rounds, the evaluations at zeta, the linearisation / batch polynomial, the two synthetic divisions and the quotient's
-degree check are sharded by coefficient index (round 3: `_evaluate_many`, `_openings`, `_degree` — 32-byte partials travel); the
-seven size-n iNTTs and the grand product still run on every rank (2.6 ms each: the class evaluations need the whole coefficient
-vectors on every rank anyway, and gathering 512 MiB costs what computing it does).
+degree check are sharded by coefficient index (round 3: `_evaluate_many`, `_openings`, `_degree` — 32-byte partials travel).
+Round 5 of the build distributed what rounds 1 and 2 still replicated (the reference distributes every FFT, dispatcher2.rs:294-351):
+
+  * the seven size-n iFFTs, by RESIDUE CLASS of the coefficient index (`_interpolate_many`): coefficient s + G t of the interpolant is
+    1/n * E(w_n^-(s + G t)) with E the polynomial whose coefficients are the n evaluations, so rank s needs E on the n/G points
+    w_n^-s * <w_(n/G)> — `plonk_coset_eval_dev(evaluations, n, n/G, shift = w_n^-s)`, one fold of n values onto n/G (7/8 n products)
+    and an (n/G)-point transform instead of an n-point one; ONE all-gather per round (the round's polynomials together,
+    n/G * 32 bytes per rank and polynomial, every pair over its own xGMI link) and `plonk_class_interleave_dev` (reverse, * 1/n)
+    give every rank the natural-order coefficient vector its class evaluations of round 3 read;
+  * the permutation grand product, by gate range (`_perm_product`): rank s runs `plonk_perm_product_range_dev` over its n/G gates
+    (+ 1: the last value is the slice's total), the 32-byte totals travel, rank s multiplies its slice by the totals before it and
+    ONE all-gather (n/G * 32 bytes per rank) replicates the product vector for the iFFT above.
+
+PLONK_CLASS_REPLICATED_R12=1 keeps rounds 1-2 replicated (A/B runs).
 Results are bit-identical to the single-GPU `Prover` (and the oracle): tests/test_gpu_class_prover.py runs G = 2, 4, 8 ranks as
 threads sharing one GPU; tests/test_gloo_multirank.py covers the torch.distributed transport on CPU tensors.
 """
@@ -187,6 +198,43 @@ class ClassProver(Prover):
         self.inv_G = f.to_limbs(f.inv(G))
         # A/B knob (bench.py --simulate-ranks): 1 = rounds 4 / 5 and the degree check computed redundantly on every rank as in round 2
         self.replicated_rounds = os.environ.get("PLONK_CLASS_REPLICATED_ROUNDS") == "1"
+        # A/B knob: 1 = the size-n iFFTs and the grand product of rounds 1-3 on every rank, as before round 5
+        self.replicated_r12 = os.environ.get("PLONK_CLASS_REPLICATED_R12") == "1" or G == 1 or self.n < 8 * G
+        self.shift_n = f.to_limbs(pow(f.root_of_unity(self.n), (self.n - self.s) % self.n, f.p))      # w_n^-s
+        self.inv_n = f.to_limbs(f.inv(self.n))
+
+    # ---- rounds 1-3: the size-n iFFTs by residue class, the grand product by gate range (module docstring)
+    def _interpolate_many(self, alloc, pairs):
+        if self.replicated_r12:
+            return super()._interpolate_many(alloc, pairs)
+        w, n, G, s = self.w, self.n, self.G, self.s
+        L, K = n // G, len(pairs)
+        d_mine = alloc(K * L)                        # [polynomial][L]: this class's values of every polynomial of the round
+        d_all = alloc(G * K * L)                     # [class][polynomial][L] after the all-gather
+        for k, (src, _) in enumerate(pairs):
+            w.coset_eval_dev(src, n, L, self.shift_n, d_mine.ptr + k * L * 32)
+        self.comm.all_gather_dev(d_mine.ptr, d_all.ptr, K * L * 32)
+        for k, (_, dst) in enumerate(pairs):
+            w.class_interleave_dev(d_all.ptr + k * L * 32, G, L, True, self.inv_n, dst, in_stride=K * L)
+
+    def _perm_product(self, alloc, wev, d_id: int, d_idx: int, beta, gamma) -> int:
+        if self.replicated_r12:
+            return super()._perm_product(alloc, wev, d_id, d_idx, beta, gamma)
+        w, f, n, G, s = self.w, self.f, self.n, self.G, self.s
+        lo, hi = shard_range(n, s, G)
+        cnt = hi - lo
+        last = hi == n                               # nobody multiplies by the last slice's total
+        d_loc = alloc(cnt + 1)
+        w.perm_product_range_dev(wev, d_id, d_idx, beta, gamma, n, lo, cnt + (0 if last else 1), d_loc.ptr)
+        total = self.f.to_limbs(1) if last else w.read_bytes(d_loc.ptr + cnt * 32, 32).view(np.uint64).copy()
+        pre = 1
+        for part in self.comm.all_gather_host(np.ascontiguousarray(total, dtype=np.uint64).reshape(1, 4))[:s]:
+            pre = pre * f.from_limbs(np.asarray(part).reshape(-1)[:4]) % f.p
+        d_send = alloc(cnt)
+        w.poly_lincomb_dev([(d_loc.ptr, cnt)], f.vec_to_limbs([pre]), d_send.ptr, cnt)
+        d_prod = alloc(n)
+        self.comm.all_gather_dev(d_send.ptr, d_prod.ptr, cnt * 32)
+        return d_prod.ptr
 
     # ---- commitments: index-sharded MSMs, ONE all-gather of the round's partial points (dispatcher2.rs:870-892)
     def _commit(self, d_poly: int, length: int):

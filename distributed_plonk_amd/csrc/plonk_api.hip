@@ -625,6 +625,17 @@ extern "C" int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world, int* rccl_
     if (rccl_version) *rccl_version = comm_rccl_version();
     return PLONK_OK;
 }
+// A stand-in for the exchange of an n_ranks job when only ONE GPU is there to run one rank's share (bench.py --simulate-ranks): the blocks
+// that would leave for / arrive from the n_ranks - 1 peers are moved send -> recv on the same stream, device to device — the same bytes
+// through the same buffers at HBM speed, so the two-lane overlap of the distributed transform meets a non-zero exchange.  Not a transport.
+extern "C" int plonk_exchange_standin(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream) {
+    (void)user;
+    if (!send || !recv || n_ranks < 1) return plonk_fail(PLONK_ERR_ARG, "plonk_exchange_standin: null / no ranks");
+    if (n_ranks > 1)
+        HIP_TRY(hipMemcpyAsync((char*)recv + bytes_per_peer, (const char*)send + bytes_per_peer, bytes_per_peer * (size_t)(n_ranks - 1), hipMemcpyDeviceToDevice,
+                               (hipStream_t)stream));
+    return PLONK_OK;
+}
 extern "C" int plonk_exchange_rccl(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream) {
     plonk_ctx* ctx = (plonk_ctx*)user;
     if (!ctx || !ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_exchange_rccl: no communicator (plonk_comm_init)");
@@ -869,10 +880,11 @@ extern "C" int plonk_perm_product_range_dev(plonk_ctx* ctx, const void* const d_
     if (rc) return rc;
     return perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, first, count, d_out, ctx->d_scratch2, ctx->stream);
 }
-extern "C" int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out) {
+extern "C" int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, size_t in_stride, int reverse, const uint64_t* scale,
+                                          void* d_out) {
     CHECK_CTX(ctx);
     if (!d_in || !d_out) return plonk_fail(PLONK_ERR_ARG, "plonk_class_interleave_dev: null");
-    return class_interleave_run(ctx->tables, d_in, classes, size, reverse, scale, d_out, ctx->stream);
+    return class_interleave_run(ctx->tables, d_in, classes, size, in_stride, reverse, scale, d_out, ctx->stream);
 }
 
 // ---------------------------------------------------------------------------------------------- round 4/5 polynomial ops (§8f rank 3)
@@ -960,6 +972,11 @@ extern "C" int plonk_memcpy_d2d(plonk_ctx* ctx, void* dst, const void* src, size
     CHECK_CTX(ctx);
     HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return PLONK_OK;
+}
+extern "C" int plonk_memcpy_d2d_async(plonk_ctx* ctx, void* dst, const void* src, size_t bytes) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
     return PLONK_OK;
 }
 extern "C" int plonk_profile_enable(plonk_ctx* ctx, int on) {

@@ -219,7 +219,8 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
 size_t perm_product_scratch_bytes(size_t n);
 int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm, const void* perm_idx, const uint64_t* beta, const uint64_t* gamma,
                      size_t n_all, size_t j0, size_t cnt, void* d_out, void* scratch, hipStream_t stream);
-int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out, hipStream_t stream);
+int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, size_t in_stride, int reverse, const uint64_t* scale, void* d_out,
+                         hipStream_t stream);
 size_t poly_scratch_bytes(size_t len);
 int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out_host, void* scratch, hipStream_t stream);
 int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const size_t* lens, const uint64_t* coeffs, void* d_out, size_t out_len,

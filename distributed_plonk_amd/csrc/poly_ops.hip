@@ -655,22 +655,25 @@ int coset_interp_run(NttTables& T, void* d_evals, size_t size, const uint64_t* s
 // coefficient s + G*t of the interpolant is 1/n times value (L - t) mod L of class s.  One lane per t: G coalesced (reversed) loads, one
 // contiguous G*32-byte store.
 template <int G>
-__global__ void __launch_bounds__(256) class_interleave_kernel(const Fr* __restrict__ in, uint64_t L, int reverse, int scaled, const F29 scale_c,
-                                                               Fr* __restrict__ out, const PoCtx c) {
+__global__ void __launch_bounds__(256) class_interleave_kernel(const Fr* __restrict__ in, uint64_t L, uint64_t stride, int reverse, int scaled,
+                                                               const F29 scale_c, Fr* __restrict__ out, const PoCtx c) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= L) return;
     const uint64_t src = reverse ? (t == 0 ? 0 : L - t) : t;
 #pragma unroll
     for (int s = 0; s < G; s++) {
-        Fr v = load_fr(in + (uint64_t)s * L + src);
+        Fr v = load_fr(in + (uint64_t)s * stride + src);
         if (scaled) v = f29_to_sat(f29_canon(f29_mul(f29_from_sat(v), scale_c, c.f29), c.f29));
         store_fr(out + t * G + s, v);
     }
 }
-int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out, hipStream_t stream) {
+int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t size, size_t in_stride, int reverse, const uint64_t* scale, void* d_out,
+                         hipStream_t stream) {
     const FrParams& P = T.fp;
     if (classes == 0 || (classes & (classes - 1)) || classes > 8) return plonk_fail(PLONK_ERR_ARG, "class_interleave: %zu classes (1, 2, 4 or 8)", classes);
     if (size == 0 || size * classes >= ((size_t)1 << 32)) return plonk_fail(PLONK_ERR_ARG, "class_interleave: %zu values per class", size);
+    if (in_stride == 0) in_stride = size;
+    if (in_stride < size) return plonk_fail(PLONK_ERR_ARG, "class_interleave: class stride %zu below the class size %zu", in_stride, size);
     if (scale && !fr_arg_ok(scale, P)) return plonk_fail(PLONK_ERR_ARG, "class_interleave: scale not reduced");
     if (d_in == d_out) return plonk_fail(PLONK_ERR_ARG, "class_interleave: in-place not supported");
     const PoCtx c = make_ctx(T);
@@ -680,10 +683,10 @@ int class_interleave_run(NttTables& T, const void* d_in, size_t classes, size_t 
     const dim3 grid((uint32_t)((size + 255) / 256)), block(256);
     ProfScope ps("class_interleave_kernel", stream);
     switch (classes) {
-    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<1>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
-    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<2>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
-    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<4>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
-    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<8>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    case 1: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<1>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, (uint64_t)in_stride, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    case 2: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<2>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, (uint64_t)in_stride, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    case 4: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<4>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, (uint64_t)in_stride, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
+    default: hipLaunchKernelGGL(HIP_KERNEL_NAME(class_interleave_kernel<8>), grid, block, 0, stream, (const Fr*)d_in, (uint64_t)size, (uint64_t)in_stride, reverse, scale ? 1 : 0, sc, (Fr*)d_out, c); break;
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "class_interleave launch: %s", hipGetErrorString(e));

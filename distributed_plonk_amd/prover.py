@@ -67,9 +67,10 @@ class Prover:
         fft_helper (quotient_mode "coset8n" without cache_key_cosets only): another context on the same GPU, `init`-ed for the same
         domains.  18 of round 3's 25 coset FFTs are of proving-key polynomials and depend on nothing a proof draws; with a helper
         they are issued on its stream by a host thread of their own at the START of the proof, beside the transforms and
-        commitments of rounds 1 and 2, and round 3 only joins them.  Same proof bytes.  What it is worth is the phase overlap
-        measured for the op mix (profiles/r04_overlap_probe.txt: -10.6 % at 2^20, -1.9 % at 2^24); unmeasured for the proof itself
-        (built when round 4's GPU time was spent): off unless a helper is passed.
+        commitments of rounds 1 and 2, and round 3 only joins them.  Same proof bytes.  Measured per proof, same lease
+        (profiles/r05_opening_measurements.txt): 63.3 -> 57.6 ms at 2^20 BN254, 291.6 -> 282.0 ms at 2^22 BLS12-381.  The 18 * 8n
+        evaluation vector (77 GB at 2^24) is then live from the START of the proof, beside the buffers of rounds 1 and 2, instead of
+        from round 3 on: the peak of a proof does not change (round 3 holds it either way), only when it is reached.
         quotient_mode "coset8n": round 3 exactly as the reference does it (25 coset FFTs over the 8n-point domain, one coset
         iFFT).  "classes6": the same quotient polynomial from 6n evaluations — see _quotient_poly_classes."""
         self.w = worker
@@ -209,6 +210,21 @@ class Prover:
     def _degree(self, d_poly: int, length: int) -> int:
         return self.w.poly_degree_dev(d_poly, length)
 
+    def _interpolate_many(self, alloc, pairs):
+        """domain.ifft of rounds 1-3 (dispatcher2.rs:300-309, 345-346, 426): pairs [(d_evals, d_coeffs)], n evaluations -> n coefficients
+        each; the evaluations are not modified (ntt_dev consumes its input, hence the copy)."""
+        n = self.n
+        d_tmp = alloc(n)
+        for src, dst in pairs:
+            self.w.memcpy_d2d(d_tmp.ptr, src, n * 32)
+            self.w.ntt_dev(d_tmp.ptr, dst, n, True, False)
+
+    def _perm_product(self, alloc, wev, d_id: int, d_idx: int, beta, gamma) -> int:
+        """the product vector of dispatcher2.rs:329-344 -> device pointer to its n values"""
+        d_prod = alloc(self.n)
+        self.w.perm_product_dev(wev, d_id, d_idx, beta, gamma, self.n, d_prod.ptr)
+        return d_prod.ptr
+
     def _download(self, d_ptr: int, n_fr: int) -> np.ndarray:
         out = np.empty((n_fr, 4), dtype=np.uint64)
         import ctypes as C
@@ -307,7 +323,7 @@ class Prover:
             return
         import threading
         m, key, h, gen = self.m, self._key, self.fft_helper, self._gen_limbs
-        d_kc = alloc(18 * m)
+        d_kc = self._work("key_cosets", 18 * m)         # a name of its own: the numbered work buffers of the rounds do not shift with the mode
         kc = [d_kc.ptr + j * m * 32 for j in range(18)]
         self.w.sync()                                   # the helper's stream reads the key polynomials this context's stream wrote
         errs = []
@@ -418,23 +434,20 @@ class Prover:
         d_wp = alloc(5 * WP)
         wp = [d_wp.ptr + i * WP * 32 for i in range(5)]
         w.memset_dev(d_wp.ptr, 0, 5 * WP * 32)
-        d_tmp_n = alloc(n)
+        self._interpolate_many(alloc, [(wev[i], wp[i]) for i in range(5)])
         for i in range(5):
-            w.memcpy_d2d(d_tmp_n.ptr, wev[i], n * 32)
-            w.ntt_dev(d_tmp_n.ptr, wp[i], n, True, False)
             w.blind_dev(wp[i], n, blinders["wires"][i])
         proof["wires_poly_comms"] = self._commit_many([(wp[i], WP) for i in range(5)])
         tick("round1", t0)
         # ---- Round 2 (:325-357): permutation product polynomial
         t0 = time.perf_counter()
         beta, gamma = challenge("beta", proof), challenge("gamma", proof)
-        d_prod = alloc(n)
-        w.perm_product_dev(wev, d_id, d_idx, beta, gamma, n, d_prod.ptr)
-        dbg_prod = d_prod.download((n, 4)) if keep else None              # the iNTT below consumes d_prod
+        d_prod_ptr = self._perm_product(alloc, wev, d_id, d_idx, beta, gamma)
+        dbg_prod = self._download(d_prod_ptr, n) if keep else None
         PP = n + 3
         d_pp = alloc(PP)
         w.memset_dev(d_pp.ptr, 0, PP * 32)
-        w.ntt_dev(d_prod.ptr, d_pp.ptr, n, True, False)
+        self._interpolate_many(alloc, [(d_prod_ptr, d_pp.ptr)])
         w.blind_dev(d_pp.ptr, n, blinders["perm"])
         proof["prod_perm_poly_comm"] = self._commit(d_pp.ptr, PP)
         tick("round2", t0)
@@ -442,8 +455,7 @@ class Prover:
         t0 = time.perf_counter()
         alpha = challenge("alpha", proof)
         d_pi_poly = alloc(n)
-        w.memcpy_d2d(d_tmp_n.ptr, d_pi, n * 32)
-        w.ntt_dev(d_tmp_n.ptr, d_pi_poly.ptr, n, True, False)             # :426
+        self._interpolate_many(alloc, [(d_pi, d_pi_poly.ptr)])            # :426
         d_quot_ptr = self._quotient_poly(alloc, tick, [(wp[i], WP) for i in range(5)], (d_pp.ptr, PP), (d_pi_poly.ptr, n), alpha, beta, gamma)
         t0 = time.perf_counter()
         expected = NUM_WIRE_TYPES * (n + 1) + 2

@@ -201,6 +201,8 @@ class PlonkWorker:
         """exchange(send_ptr, recv_ptr, bytes_per_peer, n_ranks, stream_ptr) -> int (0 = ok)."""
         if exchange is None:
             cb = C.cast(None, _ffi.EXCHANGE_FN)
+        elif isinstance(exchange, _ffi.EXCHANGE_FN):          # a plonk_exchange_fn of the library itself (plonk_exchange_standin): no Python in the call
+            cb = exchange
         else:
             def _tramp(user, send, recv, nbytes, n_ranks, stream):
                 try:
@@ -301,10 +303,10 @@ class PlonkWorker:
         be, ga = _u64(beta), _u64(gamma)
         check(self.lib.plonk_perm_product_range_dev(self.ctx, C.byref(arr), d_id_perm, d_perm_idx, _ptr(be), _ptr(ga), n, first, count, d_out))
 
-    def class_interleave_dev(self, d_in: int, classes: int, size: int, reverse: bool, scale, d_out: int):
-        """d_out[t * classes + s] = scale * d_in[s * size + (t, or (size - t) % size when reverse)]; scale None = 1."""
+    def class_interleave_dev(self, d_in: int, classes: int, size: int, reverse: bool, scale, d_out: int, in_stride: int = 0):
+        """d_out[t * classes + s] = scale * d_in[s * in_stride + (t, or (size - t) % size when reverse)]; scale None = 1; in_stride 0 = size."""
         sc = None if scale is None else _u64(scale)
-        check(self.lib.plonk_class_interleave_dev(self.ctx, d_in, classes, size, 1 if reverse else 0, None if sc is None else _ptr(sc), d_out))
+        check(self.lib.plonk_class_interleave_dev(self.ctx, d_in, classes, size, in_stride, 1 if reverse else 0, None if sc is None else _ptr(sc), d_out))
 
     def poly_eval_dev(self, d_poly: int, length: int, point) -> np.ndarray:
         """DensePolynomial::evaluate (dispatcher2.rs:545-555) -> Fr Montgomery limbs (4,)."""
@@ -367,6 +369,10 @@ class PlonkWorker:
 
     def memcpy_d2d(self, dst: int, src: int, nbytes: int):
         check(self.lib.plonk_memcpy_d2d(self.ctx, dst, src, nbytes))
+
+    def memcpy_d2d_async(self, dst: int, src: int, nbytes: int):
+        """ordered on the context's stream, not synchronised"""
+        check(self.lib.plonk_memcpy_d2d_async(self.ctx, dst, src, nbytes))
 
     def synth_fr(self, seed: int, d_out: int, n: int):
         check(self.lib.plonk_synth_fr(self.ctx, seed, d_out, n))

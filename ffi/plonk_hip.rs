@@ -69,6 +69,7 @@ extern "C" {
     pub fn plonk_comm_destroy(ctx: *mut plonk_ctx) -> c_int;
     pub fn plonk_comm_info(ctx: *mut plonk_ctx, rank: *mut c_int, world: *mut c_int, rccl_version: *mut c_int) -> c_int;
     pub fn plonk_exchange_rccl(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_peer: usize, n_ranks: c_int, stream: *mut c_void) -> c_int;
+    pub fn plonk_exchange_standin(user: *mut c_void, send: *const c_void, recv: *mut c_void, bytes_per_peer: usize, n_ranks: c_int, stream: *mut c_void) -> c_int;
     pub fn plonk_comm_alltoall_dev(ctx: *mut plonk_ctx, d_send: *const c_void, d_recv: *mut c_void, bytes_per_peer: usize) -> c_int;
     pub fn plonk_comm_allgather_dev(ctx: *mut plonk_ctx, d_send: *const c_void, d_recv: *mut c_void, bytes: usize) -> c_int;
     pub fn plonk_comm_allgather_host(ctx: *mut plonk_ctx, input: *const c_void, bytes: usize, out: *mut c_void) -> c_int;
@@ -113,7 +114,7 @@ extern "C" {
     pub fn plonk_quotient_evals_class_dev(ctx: *mut plonk_ctx, input: *const plonk_quotient_inputs, alpha: *const u64, beta: *const u64, gamma: *const u64, k: *const u64, class_stride: u32, class_offset: u32, d_out: *mut c_void) -> c_int;
     pub fn plonk_perm_product_dev(ctx: *mut plonk_ctx, d_wires: *const *const c_void, d_id_perm: *const c_void, d_perm_idx: *const c_void, beta: *const u64, gamma: *const u64, n: usize, d_out: *mut c_void) -> c_int;
     pub fn plonk_perm_product_range_dev(ctx: *mut plonk_ctx, d_wires: *const *const c_void, d_id_perm: *const c_void, d_perm_idx: *const c_void, beta: *const u64, gamma: *const u64, n: usize, first: usize, count: usize, d_out: *mut c_void) -> c_int;
-    pub fn plonk_class_interleave_dev(ctx: *mut plonk_ctx, d_in: *const c_void, classes: usize, size: usize, reverse: c_int, scale: *const u64, d_out: *mut c_void) -> c_int;
+    pub fn plonk_class_interleave_dev(ctx: *mut plonk_ctx, d_in: *const c_void, classes: usize, size: usize, in_stride: usize, reverse: c_int, scale: *const u64, d_out: *mut c_void) -> c_int;
     pub fn plonk_poly_eval_dev(ctx: *mut plonk_ctx, d_poly: *const c_void, len: usize, point: *const u64, out: *mut u64) -> c_int;
     pub fn plonk_poly_lincomb_dev(ctx: *mut plonk_ctx, k: usize, d_polys: *const *const c_void, lens: *const usize, coeffs: *const u64, d_out: *mut c_void, out_len: usize) -> c_int;
     pub fn plonk_poly_div_linear_dev(ctx: *mut plonk_ctx, d_poly: *const c_void, len: usize, point: *const u64, d_out: *mut c_void) -> c_int;
@@ -128,6 +129,7 @@ extern "C" {
     pub fn plonk_memcpy_h2d(ctx: *mut plonk_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;
     pub fn plonk_memcpy_d2h(ctx: *mut plonk_ctx, h_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn plonk_memcpy_d2d(ctx: *mut plonk_ctx, d_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
+    pub fn plonk_memcpy_d2d_async(ctx: *mut plonk_ctx, d_dst: *mut c_void, d_src: *const c_void, bytes: usize) -> c_int;
     pub fn plonk_memset_dev(ctx: *mut plonk_ctx, d_dst: *mut c_void, byte: c_int, bytes: usize) -> c_int;
     pub fn plonk_synth_fr(ctx: *mut plonk_ctx, seed: u64, d_out: *mut c_void, n: usize) -> c_int;
     pub fn plonk_synth_bases(ctx: *mut plonk_ctx, seed: u64, unique: usize, n: usize, d_out: *mut c_void) -> c_int;

@@ -80,6 +80,10 @@ int plonk_comm_destroy(plonk_ctx* ctx);
 int plonk_comm_info(plonk_ctx* ctx, int* rank, int* world, int* rccl_version);
 /* plonk_exchange_fn backed by the context's communicator: pass as `exchange` with user = ctx (what a NULL callback selects) */
 int plonk_exchange_rccl(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream);
+/* diagnostic plonk_exchange_fn (bench.py --simulate-ranks: one rank's share of an n_ranks job on ONE GPU): blocks 1 .. n_ranks-1 of
+ * `send` are copied to the same blocks of `recv` on `stream`, device to device — the bytes a real exchange would move, through the
+ * same buffers, at HBM instead of xGMI speed.  Results are meaningless; `user` is ignored. */
+int plonk_exchange_standin(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream);
 /* device buffers, ordered on the context's stream, not synchronised: block p of d_send -> rank p / every rank's d_send -> block
  * `rank` of everybody's d_recv.  The two data-path collectives of the coset-class prover. */
 int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer);
@@ -249,13 +253,15 @@ int plonk_coset_eval_dev(plonk_ctx* ctx, const void* d_poly, size_t len, size_t 
 int plonk_coset_interp_dev(plonk_ctx* ctx, void* d_evals, size_t size, const uint64_t* shift, const uint64_t* scale, size_t i0, size_t count,
                            void* d_out);
 
-/* `classes` vectors of `size` values (d_in: class-major) -> natural order: d_out[t * classes + s] = scale * d_in[s * size + t'],
- * t' = t, or (size - t) mod size with reverse != 0; scale = NULL: 1.  classes in {1, 2, 4, 8}; not in place.  What the dispatcher does
+/* `classes` vectors of `size` values (d_in: class-major, class s at d_in + s * in_stride; in_stride = 0: size) -> natural order:
+ * d_out[t * classes + s] = scale * d_in[s * in_stride + t'], t' = t, or (size - t) mod size with reverse != 0; scale = NULL: 1.
+ * classes in {1, 2, 4, 8}; not in place.  What the dispatcher does
  * with the column replies of a distributed transform (dispatcher2.rs:776-787: concatenate + transpose), for transforms split by
  * residue class: a size-n iFFT over G workers is, on worker s, plonk_coset_eval_dev(evaluations, n, n / G, shift = w_n^-s) — the
  * evaluations read as coefficients, folded G-fold onto n / G points — then an all-gather, then this call with reverse = 1,
  * scale = 1 / n: coefficient s + G t of the interpolant is 1/n times value (n/G - t) mod n/G of class s. */
-int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, int reverse, const uint64_t* scale, void* d_out);
+int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, size_t in_stride, int reverse, const uint64_t* scale,
+                               void* d_out);
 
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
@@ -263,6 +269,7 @@ int plonk_dev_free(plonk_ctx* ctx, void* p);
 int plonk_memcpy_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
 int plonk_memcpy_d2h(plonk_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
 int plonk_memcpy_d2d(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
+int plonk_memcpy_d2d_async(plonk_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);   /* ordered on the context's stream, not synchronised */
 int plonk_memset_dev(plonk_ctx* ctx, void* d_dst, int byte, size_t bytes);
 /* n uniform Fr (Montgomery limbs drawn like ark-ff's Fp::rand: mask + rejection), element i from
  * stream (seed, i). */

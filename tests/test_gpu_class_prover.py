@@ -33,7 +33,7 @@ def _check(got, want):
     for key in ("wires_evals", "wire_sigma_evals"):
         assert np.array_equal(np.stack(got[key]), np.stack(want[key])), key
     assert np.array_equal(got["perm_next_eval"], want["perm_next_eval"])
-    for key in ("quot_poly", "lin_poly", "batch_poly"):
+    for key in ("perm_product", "perm_poly", "quot_poly", "lin_poly", "batch_poly"):       # perm_product: the all-gathered slices of the sharded grand product
         assert np.array_equal(got["_debug"][key], want[key]), key
 
 
@@ -49,6 +49,7 @@ def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
         try:
             pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
             out = None
+            assert not pv.replicated_r12                   # the size-n iFFTs by residue class, the grand product by gate range
             for _ in range(2):                             # second proof reuses the work buffers
                 out = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
             return out, dict(pv.timings)
@@ -156,6 +157,49 @@ def test_class_prover_over_rccl_single_rank(gpu_workers, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n,G", [(3, 2), (6, 4), (9, 8), (13, 8)])
+def test_size_n_ifft_by_residue_class(gpu_workers, oracle, curve, cid, log_n, G):
+    """The building blocks of ClassProver._interpolate_many on one context: for every class s, plonk_coset_eval_dev of the n EVALUATIONS
+    (read as coefficients, folded G-fold onto n/G points) at shift w_n^-s, then plonk_class_interleave_dev(reverse, 1/n) over the G
+    class vectors == domain.ifft (dispatcher2.rs:300-309) of the oracle, bit for bit; two polynomials side by side exercise the class stride."""
+    from distributed_plonk_amd import fr as _fr
+    f = _fr.FIELDS[curve]
+    w = gpu_workers(curve)
+    n = 1 << log_n
+    L, K = n // G, 2
+    ev = [oracle.rand_fr(cid, 40 + log_n + k, n) for k in range(K)]
+    d_ev = [w.alloc(n * 32).upload(e) for e in ev]
+    d_all, d_out = w.alloc(G * K * L * 32), w.alloc(n * 32)
+    for s in range(G):
+        shift = f.to_limbs(pow(f.root_of_unity(n), (n - s) % n, f.p))
+        for k in range(K):
+            w.coset_eval_dev(d_ev[k].ptr, n, L, shift, d_all.ptr + ((s * K + k) * L) * 32)
+    for k in range(K):
+        w.class_interleave_dev(d_all.ptr + k * L * 32, G, L, True, f.to_limbs(f.inv(n)), d_out.ptr, in_stride=K * L)
+        assert np.array_equal(d_out.download((n, 4)), oracle.ntt(cid, ev[k], True, False)), (k, "residue-class iFFT")
+    # without reversal / scale the call is a plain transpose of the class-major matrix
+    w.class_interleave_dev(d_all.ptr, G, L, False, None, d_out.ptr, in_stride=K * L)
+    cm = d_all.download((G, K, L, 4))[:, 0]
+    assert np.array_equal(d_out.download((L, G, 4)), cm.transpose(1, 0, 2))
+    for b in d_ev + [d_all, d_out]:
+        b.free()
+
+
+def test_class_interleave_rejects_bad_arguments(gpu_workers):
+    from distributed_plonk_amd._ffi import PlonkError
+    w = gpu_workers("bn254")
+    a, b = w.alloc(64 * 32), w.alloc(64 * 32)
+    for kw in (dict(classes=3, size=8), dict(classes=16, size=4), dict(classes=4, size=0), dict(classes=4, size=8, in_stride=4)):
+        with pytest.raises(PlonkError):
+            w.class_interleave_dev(a.ptr, kw["classes"], kw["size"], False, None, b.ptr, in_stride=kw.get("in_stride", 0))
+    with pytest.raises(PlonkError):
+        w.class_interleave_dev(a.ptr, 4, 8, False, None, a.ptr)
+    with pytest.raises(PlonkError):                                   # nine-fold: beyond NTT_MAX_FOLD
+        w.coset_eval_dev(a.ptr, 36, 4, np.array([1, 0, 0, 0], dtype=np.uint64), b.ptr)
+    a.free(); b.free()
 
 
 def test_shard_range_covers_everything():

@@ -36,6 +36,38 @@ def test_perm_product_matches_oracle(gpu_workers, oracle, curve, cid, n):
         b.free()
 
 
+@pytest.mark.parametrize("curve,cid", CURVES)
+@pytest.mark.parametrize("n,G", [(8, 2), (64, 4), (4096, 8), (5000, 8), (1 << 14, 3)])
+def test_perm_product_by_gate_range_matches_oracle(gpu_workers, oracle, curve, cid, n, G):
+    """plonk_perm_product_range_dev as G workers would call it (class_prover.py): slice s with one extra value = the slice's total; the
+    slices multiplied by the totals before them are the oracle's product vector (dispatcher2.rs:329-344), bit for bit — uneven slices and
+    slices that cross a scan tile included."""
+    w = gpu_workers(curve)
+    wires, id_perm, perm_idx, beta, gamma = _perm_inputs(oracle, cid, n, 300 + n)
+    dw = w.alloc(5 * n * 32).upload(wires)
+    di = w.alloc(5 * n * 32).upload(id_perm)
+    dp = w.alloc(5 * n * 8).upload(perm_idx)
+    want = oracle.perm_product(cid, wires, id_perm, perm_idx, beta, gamma)
+    mul = lambda a, b: oracle.field_op(cid, 0, "mul", np.ascontiguousarray(a).reshape(-1, 4), np.ascontiguousarray(b).reshape(-1, 4))
+    pre = oracle.field_const(cid, 0, 1)[:4]
+    for s in range(G):
+        lo, hi = s * n // G, (s + 1) * n // G
+        cnt, extra = hi - lo, (0 if hi == n else 1)
+        out = w.alloc((cnt + 1) * 32)
+        w.perm_product_range_dev([dw.ptr + i * n * 32 for i in range(5)], di.ptr, dp.ptr, beta, gamma, n, lo, cnt + extra, out.ptr)
+        loc = out.download((cnt + extra, 4))
+        assert np.array_equal(mul(loc[:cnt], np.tile(pre, (cnt, 1))), want[lo:hi]), (s, lo, hi)
+        if extra:
+            pre = mul(pre, loc[cnt])[0]
+        out.free()
+    with pytest.raises(PlonkError):
+        w.perm_product_range_dev([dw.ptr + i * n * 32 for i in range(5)], di.ptr, dp.ptr, beta, gamma, n, n - 2, 3, dw.ptr)
+    with pytest.raises(PlonkError):
+        w.perm_product_range_dev([dw.ptr + i * n * 32 for i in range(5)], di.ptr, dp.ptr, beta, gamma, n, 0, 0, dw.ptr)
+    for b in (dw, di, dp):
+        b.free()
+
+
 def test_perm_product_valid_permutation_closes(gpu_workers, oracle):
     """With id_perm = k_i w^j and a real copy-constraint permutation the full-cycle product is 1: z[n-1] * ratio[n-1] = 1
     (size-independent property, checked at 2^20 against the oracle's last ratio only)."""

@@ -193,17 +193,19 @@ def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
 def test_bench_program_proof_only_sub_run(emu_env):
     """`--next-rows proof` — what the configs[1] / configs[3] sub-runs of the default bench line use (benchlib/other_configs.py): the step, its
     verification and ONE verified proof, without the quotient row, the O(n) rows and the same-proof variants that do less than the
-    reference's work (the one that only re-schedules it stays: Prover(fft_helper=...))."""
+    reference's work.  At these sizes the proof runs with Prover(fft_helper=...) (round 5: measured, adopted); PLONK_BENCH_HELPER_AB=1 adds the
+    same rounds without it as a variant, which must give the same proof."""
     import json
-    e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
+    e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)), PLONK_BENCH_HELPER_AB="1")
     r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "7", "--curve", "bls12_381", "--next-rows", "proof"], cwd=ROOT, env=e,
                        capture_output=True, text=True, timeout=900)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
     d = json.loads(lines[0])
     assert d["verified"] is True and d["prover_verified"] is True and set(d["next_rows"]) == {"prover_rounds"}
-    var = d["next_rows"]["prover_rounds"]["variants"]          # only the one that does the reference's work (key coset FFTs beside rounds 1-2)
-    assert set(var) == {"key_coset_ffts_beside_rounds_1_2"} and var["key_coset_ffts_beside_rounds_1_2"]["same_proof_as_the_verified_one"] is True, var
+    assert d["next_rows"]["prover_rounds"]["key_coset_ffts"].startswith("on a third context")
+    var = d["next_rows"]["prover_rounds"]["variants"]          # only the A/B partner: the same rounds with the key coset FFTs inside round 3
+    assert set(var) == {"key_coset_ffts_inside_round_3"} and var["key_coset_ffts_inside_round_3"]["same_proof_as_the_verified_one"] is True, var
 
 
 def test_differential_fuzz_slice(emu_env):
