@@ -27,12 +27,20 @@ def parse():
     ap.add_argument("--no-next-rows", action="store_true", help="same as --next-rows none")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="default run only: skip the compact re-runs at BASELINE.json's configs[1] (2^20 BN254) and configs[3] (2^22 BLS12-381)")
-    ap.add_argument("--cpu-sample-log-n", type=int, default=20)
+    ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="cpu_baseline: log2 of the first measured sample (every op of the step once)")
+    ap.add_argument("--cpu-sample-log-n2", type=int, default=22,
+                    help="cpu_baseline: log2 of the second, larger measured sample (the single-threaded transforms and the commitment once each, ~25 s); "
+                         "the two give the fitted exponent behind `value_at_bench_size`.  0 = one sample only")
     ap.add_argument("--no-poly-parallel", action="store_true",
                     help="N > 1: skip the polynomial-level-parallel leg (whole operations per rank, no data-path collective; SURVEY §8e's alternative)")
     ap.add_argument("--simulate-ranks", type=int, default=0,
-                    help="diagnostic: run rank 0's share of an S-rank job on ONE GPU with a no-op exchange (results are garbage, "
-                         "timings are one rank's compute without communication)")
+                    help="diagnostic: run rank 0's share of an S-rank job on ONE GPU with a stand-in for the exchange (--sim-exchange; results are "
+                         "garbage, timings are one rank's compute plus device-to-device copies of the bytes it would exchange)")
+    ap.add_argument("--sim-exchange", default="standin", choices=["standin", "none"],
+                    help="--simulate-ranks: what stands in for the collectives.  'standin' (default): the bytes a collective would move through this "
+                         "rank's send / receive buffers are copied device to device on the issuing stream ((S-1)/S of an all-to-all's block set, "
+                         "the S-1 foreign blocks of an all-gather) — HBM speed, not xGMI speed, but the lanes' overlap meets a non-zero exchange and "
+                         "`sim_exchange` prices the same bytes at the xGMI link rate; 'none': collectives return at once (compute only)")
     ap.add_argument("--class-prover", action="store_true",
                     help="also time the five prover rounds with the multi-rank coset-class prover (class_prover.py) on all ranks; "
                          "on by default for N > 1, reported under next_rows, never part of `value`")
@@ -41,7 +49,8 @@ def parse():
                     help="N > 1: how the step's transforms are distributed.  'classes': rank s evaluates every polynomial on ITS coset "
                          "class (the points j = s mod N of the 8n-point coset) with a local zero-padding-aware (8n/N)-point transform - no "
                          "exchange for the 25 forward coset FFTs; the quotient's coset iFFT is one class-local inverse transform + ONE all-to-all "
-                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs run on every rank.  'reference2d' (default): every one "
+                         "(sum of the classes' contributions) + one all-gather; the 7 size-n iNTTs by residue class (an n/N-point class transform, one all-gather, an "
+                         "interleave).  'reference2d' (default): every one "
                          "of the 33 transforms as the reference's 2-D distributed transform (row pass, RCCL all-to-all, column pass), the 25 forward "
                          "coset FFTs from zero-padded rows (plonk_fft1_dev_compact), two lanes so that exchanges overlap the next transform's passes.  "
                          "The other scheme is timed after the headline and reported as `other_scheme`")

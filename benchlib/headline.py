@@ -86,6 +86,15 @@ def _valu_entry(pmc, name, avg_ms):
             "source": "profiles/pmc_current.json (source- or machine-code-hash checked), profiles/r01_valu_microbench.txt"}
 
 
+def pmc_config_key(b):
+    """the workload name profiles/pmc_current.json must carry for its counters to be quoted: size @ curve @ ranks, and — VERDICT r4 weak 6 — what
+    the run really is when it is NOT the plain N-rank job: a simulated rank's launches (1/S of the work each) or the multi-rank code path on
+    one rank must never be priced with the single-GPU collection's counters (a `valu_issue.frac_of_launch` of 4.3 was the result)."""
+    args = b.args
+    tail = f"sim{b.sim}" if b.sim else (f"{b.world}-multipath" if (b.multi and b.world == 1) else str(b.world))
+    return f"2^{args.log_n}@{args.curve}@{tail}"
+
+
 def rooflines(b, kernels, ms_per_step):
     """-> (roofline of the dominant kernel, [the others]).  PMC-derived numbers (HBM traffic, VALU instruction counts) come from separate
     rocprofv3 counter runs of this same command, committed as profiles/pmc_current.json (tools/pmc_collect.py).  They are quoted ONLY when
@@ -93,7 +102,7 @@ def rooflines(b, kernels, ms_per_step):
     machine code — and for this workload; otherwise the fields stay null."""
     args = b.args
     roof = _algorithmic_bytes(b, kernels)
-    pmc, pmc_note = load_pmc(f"2^{args.log_n}@{args.curve}@{b.world}", args.dense_coset)
+    pmc, pmc_note = load_pmc(pmc_config_key(b), args.dense_coset)
 
     def entry(name):
         r = roof[name]
@@ -117,10 +126,10 @@ def rooflines(b, kernels, ms_per_step):
 def _config(b):
     args, sim, multi, scheme, world, transport = b.args, b.sim, b.multi, b.scheme, b.world, b.transport
     if world == 1:
-        parallelism = (f"SIMULATED rank 0 of {sim} on one GPU, no exchange (diagnostic), scheme {scheme}" if sim else
+        parallelism = (f"SIMULATED rank 0 of {sim} on one GPU, {b.sim_exchange_note} (diagnostic), scheme {scheme}" if sim else
                        ("single GPU" if not multi else f"the N > 1 code path on ONE rank (diagnostic), scheme {scheme}"))
     else:
-        how = ("7 iNTT(n) on every rank, 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local inverse + 1 all-to-all + "
+        how = ("7 iNTT(n) by residue class (n/N-point class transform + all-gather + interleave), 25 class-local zero-padding-aware coset FFTs of 8n/N points, quotient iFFT = class-local inverse + 1 all-to-all + "
                "1 all-gather" if scheme == "classes" else
                "33 x 2-D NTT with an RCCL all-to-all each" + (", dense inputs" if args.dense_coset else ", zero-padded rows for the 25 forward coset FFTs"))
         parallelism = (f"{world} ranks, scheme {scheme}: {how}; index-sharded MSM + 1 point all-gather; transport "
@@ -175,6 +184,8 @@ def result_line(b, dt, phases_ms):
     }
     if b.multi and b.transport == "rccl":
         out["exchange"] = _exchange(b, kernels, phases_ms)
+    if b.sim:
+        out["sim_exchange"] = b.sim_exchange_report()
     if b.emulated:
         # a dry run of the control flow on the host emulation: whatever the clock said is not a measurement of anything
         out.update(metric="EMULATED DRY RUN of bench.py's control flow (tests/hostemu, no GPU): NOT a measurement", value=None, ms_per_step=None,

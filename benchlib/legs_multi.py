@@ -290,20 +290,25 @@ def verify_multi(b):
 
 
 class _SimComm:
-    """rank 0 of `size` ranks with nobody else there: collectives return at once (diagnostic timing only)"""
+    """rank 0 of `size` ranks with nobody else there (diagnostic timing only): host objects come back `size` times; device collectives are the
+    bench's stand-ins (Bench.sim_alltoall / sim_allgather: the bytes they would move, copied device to device on the worker's stream; nothing
+    with --sim-exchange none)"""
     rank = 0
 
-    def __init__(self, size):
-        self.size = size
+    def __init__(self, size, b, w):
+        self.size, self.b, self.w = size, b, w
+        self.bytes_out = 0
 
     def all_gather_host(self, obj):
         return [obj] * self.size
 
     def all_to_all_dev(self, d_send, d_recv, nbytes):
-        pass
+        self.bytes_out += (self.size - 1) * nbytes
+        self.b.sim_alltoall(self.w, d_send, d_recv, nbytes)
 
     def all_gather_dev(self, d_send, d_recv, nbytes):
-        pass
+        self.bytes_out += (self.size - 1) * nbytes
+        self.b.sim_allgather(self.w, d_send, d_recv, nbytes)
 
 
 def class_prover(b):
@@ -330,7 +335,7 @@ def class_prover(b):
     consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
     bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
     if sim:
-        comm = _SimComm(G_)
+        comm = _SimComm(G_, b, w)
     elif b.transport == "rccl" and b.multi:
         def _boot(obj):
             out_ = [None] * world
@@ -364,8 +369,12 @@ def class_prover(b):
            "rounds_ms_rank0": {k_: round(v_, 2) for k_, v_ in cp.timings.items()},
            "accepted_by_verifier": cverified,
            "simulated": bool(sim),
-           "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 5 all-gathers of partial commitment points (one per round), "
-                                    "4 all-gathers of 32-byte partials (evaluations, degree, two openings)",
+           **({"sim_exchange": {"mode": args.sim_exchange, "device_bytes_out_per_proof": comm.bytes_out // 2,
+                                "xgmi_model_ms_per_proof_at_153_GBps_per_link": round(comm.bytes_out / 2 / (G_ - 1) / 153e9 * 1e3, 2)}} if sim else {}),
+           "rounds_1_2": "replicated (PLONK_CLASS_REPLICATED_R12=1)" if cp.replicated_r12 else "size-n iFFTs by residue class, grand product by gate range",
+           "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 3 all-gathers of class values (the size-n iFFTs of rounds 1, 2, 3), "
+                                    "1 all-gather of the product vector, 5 all-gathers of partial commitment points (one per round), "
+                                    "5 all-gathers of 32-byte partials (slice totals, evaluations, degree, two openings)",
            "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
     cp.close()
     inst.close()

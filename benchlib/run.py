@@ -96,7 +96,16 @@ class Bench:
             self.experiment_opts[k_.strip()] = int(v_)
             for x in self.workers:
                 x.set_option(k_.strip(), int(v_))
-        self.noop_exchange = (lambda send, recv, nbytes, n_ranks, stream: 0) if self.sim else None
+        # --simulate-ranks: the exchange of a distributed transform is the library's stand-in (device-to-device copies of the foreign blocks on the
+        # transform's stream, no Python in the call) or, with --sim-exchange none, nothing
+        self.sim_standin = bool(self.sim) and args.sim_exchange == "standin"
+        self.sim_bytes = {"alltoall": 0, "allgather": 0, "calls": 0}       # what rank 0 would send per call, summed (sim_exchange_report)
+        self.noop_exchange = None
+        if self.sim:
+            import ctypes as C_
+            from distributed_plonk_amd import _ffi
+            self.noop_exchange = (C_.cast(_ffi.lib().plonk_exchange_standin, _ffi.EXCHANGE_FN) if self.sim_standin else
+                                  (lambda send, recv, nbytes, n_ranks, stream: 0))
         self.transport = args.transport if (self.world > 1 or args.multi_path) else "torch"
         self.rccl_info = None
         if args.multi_path and self.world == 1 and not dist.is_initialized():
@@ -178,7 +187,7 @@ class Bench:
 
     def _class_scheme_inputs(self):
         """N > 1, scheme "classes": the step with the coset-class decomposition.  Every rank holds the coefficient
-        vectors (the size-n iNTTs that produce them run on every rank: 2.6 ms each, cheaper than gathering them), evaluates all 25
+        vectors (the size-n iNTTs that produce them run by residue class: an n/N-point class transform, one all-gather, one interleave), evaluates all 25
         polynomials on its OWN class of the 8n-point coset with a local zero-padding-aware (8n/N)-point transform, and the quotient's
         coset iFFT is the class-local inverse + one all-to-all (sum) + one all-gather.  Same work as the reference's 33 distributed
         transforms, two data-path collectives instead of 33."""
@@ -194,12 +203,47 @@ class Bench:
             bn=[[w.alloc(n * 32), w.alloc(n * 32)] for _ in range(self.n_small_bufs)], polys=[w.alloc(self.poly_len * 32) for _ in range(self.n_polys)],
             out=w.alloc(mL * 32), contrib=w.alloc(m * 32), recv=w.alloc(m * 32), mine=w.alloc(mL * 32), quot=w.alloc(m * 32),
             shift=f_.to_limbs(f_.generator * pow(f_.root_of_unity(m), rank, f_.p) % f_.p), inv_g=f_.to_limbs(pow(G, -1, f_.p)),
+            cls_mine=w.alloc((n // G) * 32), cls_all=w.alloc(n * 32), inv_n=f_.to_limbs(pow(n, -1, f_.p)),
+            shift_n=f_.to_limbs(pow(f_.root_of_unity(n), (n - rank) % n, f_.p)),
             ones=np.tile(f_.to_limbs(1), (G, 1)))
         for i, pair in enumerate(self.cls["bn"]):                     # the same vectors on every rank
             w.synth_fr(0xD15EA5E + i, pair[0].ptr, n)
         for i, b in enumerate(self.cls["polys"]):
             w.synth_fr(0xC0EFF + i, b.ptr, self.poly_len)
         w.synth_fr(0x5EC7, self.cls["recv"].ptr, m)                  # (--simulate-ranks skips the exchange: keep the operands valid)
+
+    # ------------------------------------------------------------------------------------------------ --simulate-ranks: the exchange stand-in
+    @property
+    def sim_exchange_note(self):
+        return ("collectives replaced by device-to-device copies of the bytes they would move" if self.sim_standin else "no exchange")
+
+    def sim_alltoall(self, w, d_send, d_recv, nbytes):
+        """blocks 1 .. S-1 of d_send -> d_recv on w's stream (what leaves for / arrives from the S - 1 peers)"""
+        if self.sim_standin and self.S > 1:
+            w.memcpy_d2d_async(d_recv + nbytes, d_send + nbytes, (self.S - 1) * nbytes)
+
+    def sim_allgather(self, w, d_send, d_recv, nbytes):
+        """d_send -> the S - 1 foreign blocks of d_recv (the bytes that would arrive), and the rank's own block"""
+        if self.sim_standin:
+            for p_ in range(self.S):
+                w.memcpy_d2d_async(d_recv + p_ * nbytes, d_send, nbytes)
+
+    def sim_exchange_report(self):
+        """what the stand-in moved per step and what those bytes cost on the fabric: MI355X xGMI is point-to-point, 7 links per GPU at
+        ~153 GB/s peak per direction (MI355X_MICROARCH.md); in an all-to-all / all-gather over 8 GPUs every pair has its own link, so the
+        collective's floor is bytes_per_peer / link rate — quoted at 100 % and at 60 % of the link peak.  A MODEL beside a measurement."""
+        S, n, m = self.S, self.n, self.m
+        per_peer = {"ntt_n": (n // S // S) * 32, "ntt_8n": (m // S // S) * 32 if self.nbig else 0}
+        colls = {"ntt_n": 7, "ntt_8n": 26 if self.nbig else 0}
+        floor = lambda rate: sum(colls[k_] * per_peer[k_] / rate for k_ in colls) * 1e3
+        return {"mode": "standin" if self.sim_standin else "none",
+                "what": self.sim_exchange_note,
+                "reference2d_bytes_per_peer_and_collective": per_peer, "collectives_per_step": colls,
+                "bytes_out_per_rank_and_step": sum(colls[k_] * per_peer[k_] * (S - 1) for k_ in colls),
+                "xgmi_model_ms_per_step": {"at_153_GBps_per_link": round(floor(153e9), 2), "at_92_GBps_per_link": round(floor(92e9), 2),
+                                           "note": "serial sum of the 33 all-to-alls at a per-link rate, every pair on its own link; with two lanes (and "
+                                                   "--overlap-phases) they overlap the other lane's passes and the commitments, so this is an upper "
+                                                   "bound of what can be exposed, not an addend"}}
 
     def _extra_contexts(self):
         """the contexts --overlap-phases adds to the two commitment contexts"""
@@ -326,26 +370,34 @@ class Bench:
         c, w, n, m, sim, transport = self.cls, self.w, self.n, self.m, self.sim, self.transport
         G = self.S
         mL = m // G
-        for i in range(N_NTT_SMALL):
+        L = n // G
+        for i in range(N_NTT_SMALL):       # size-n iFFT by residue class (class_prover.py): n values folded onto n/G points, all-gather, interleave
             pair = c["bn"][i % len(c["bn"])]
-            w.ntt_dev(pair[0].ptr, pair[1].ptr, n, True, False)
+            w.coset_eval_dev(pair[0].ptr, n, L, c["shift_n"], c["cls_mine"].ptr)
+            self._allgather(w, c["cls_mine"].ptr, c["cls_all"].ptr, L * 32)
+            w.class_interleave_dev(c["cls_all"].ptr, G, L, True, c["inv_n"], pair[1].ptr)
             pair[0], pair[1] = pair[1], pair[0]
         for i in range(N_NTT_BIG - 1):
             w.coset_eval_dev(c["polys"][i % len(c["polys"])].ptr, self.poly_len, mL, c["shift"], c["out"].ptr)
         # quotient coefficients: this class's additive share of every coefficient, summed across ranks, then replicated
         w.coset_interp_dev(c["out"].ptr, mL, c["shift"], c["inv_g"], 0, m, c["contrib"].ptr)
-        if not sim:
-            if transport == "rccl":
-                w.comm_alltoall_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
-            else:
-                self.torch_comm.all_to_all_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
+        if sim:
+            self.sim_alltoall(w, c["contrib"].ptr, c["recv"].ptr, mL * 32)
+        elif transport == "rccl":
+            w.comm_alltoall_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
+        else:
+            self.torch_comm.all_to_all_dev(c["contrib"].ptr, c["recv"].ptr, mL * 32)
         w.poly_lincomb_dev([(c["recv"].ptr + p_ * mL * 32, mL) for p_ in range(G)], c["ones"], c["mine"].ptr, mL)
-        if not sim:
-            if transport == "rccl":
-                w.comm_allgather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
-            else:
-                self.torch_comm.all_gather_dev(c["mine"].ptr, c["quot"].ptr, mL * 32)
+        self._allgather(w, c["mine"].ptr, c["quot"].ptr, mL * 32)
         return self._commit_phase(t_in)
+
+    def _allgather(self, w, d_send, d_recv, nbytes):
+        if self.sim:
+            self.sim_allgather(w, d_send, d_recv, nbytes)
+        elif self.transport == "rccl":
+            w.comm_allgather_dev(d_send, d_recv, nbytes)
+        else:
+            self.torch_comm.all_gather_dev(d_send, d_recv, nbytes)
 
     # ------------------------------------------------------------------------------------------------ helpers of the legs
     def dev_sync(self):
@@ -382,7 +434,7 @@ class Bench:
             b.free()
         cls = self.cls
         if cls is not None:
-            for k_ in ("out", "contrib", "recv", "mine", "quot"):
+            for k_ in ("out", "contrib", "recv", "mine", "quot", "cls_mine", "cls_all"):
                 if cls[k_] is not None:
                     cls[k_].free()
                     cls[k_] = None

@@ -202,3 +202,71 @@ def test_other_configs_fall_back_to_the_phase_after_phase_run(monkeypatch):
     calls.clear()
     res = oc.other_configs(types.SimpleNamespace(bases="distinct"))
     assert len(calls) == 2 and all(c[3] == 20.0 for c in calls) and all("no time left" in r["error"] for r in res), (calls, res)
+
+
+def test_simulated_and_multipath_runs_never_quote_the_single_gpu_counters():
+    """a --simulate-ranks / --multi-path line is a different workload from the N = 1 collection; its PMC key says so, so
+    `traffic` and `valu_issue` stay null instead of pricing a 0.84 ms launch with the counters of a 4.2 ms one."""
+    import types
+    sys.path.insert(0, ROOT)
+    from benchlib.headline import pmc_config_key
+    import bench
+    a = types.SimpleNamespace(log_n=24, curve="bn254")
+    key = lambda **kw: pmc_config_key(types.SimpleNamespace(args=a, **kw))
+    assert key(sim=0, multi=False, world=1) == "2^24@bn254@1"
+    assert key(sim=8, multi=True, world=1) == "2^24@bn254@sim8"
+    assert key(sim=0, multi=True, world=1) == "2^24@bn254@1-multipath"
+    assert key(sim=0, multi=True, world=8) == "2^24@bn254@8"
+    for k in ("2^24@bn254@sim8", "2^24@bn254@1-multipath"):
+        pmc, note = bench.load_pmc(k)
+        assert pmc == {} and "not this workload" in note
+
+
+def test_no_committed_result_line_claims_more_valu_issue_than_time():
+    """every bench line committed under profiles/ (and the driver's BENCH_r*.json): a kernel cannot issue for longer than it runs — a
+    `valu_issue.frac_of_launch` above 1.2 (the 4.5-clk model's own slack) means the counters of another workload were quoted.  (The simulated /
+    multi-path lines of rounds 3-4 that did — 4.3 and 6.0 — had those fields removed in round 5, with a note in the file.)"""
+    import glob
+    known = set()
+    bad = []
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*.json")) + glob.glob(os.path.join(ROOT, "BENCH_r*.json"))):
+        try:
+            d = json.load(open(f))
+        except Exception:       # noqa: BLE001 - multi-line logs
+            continue
+        d = d.get("parsed", d) if isinstance(d, dict) else {}
+        if not isinstance(d, dict):
+            continue
+        for r in [d.get("roofline")] + list(d.get("roofline_other") or []):
+            frac = ((r or {}).get("valu_issue") or {}).get("frac_of_launch")
+            if frac is not None and frac > 1.2 and os.path.basename(f) not in known:
+                bad.append((os.path.basename(f), r.get("kernel"), frac))
+    assert not bad, bad
+
+
+def test_cpu_baseline_reports_two_samples_a_fitted_exponent_and_the_bench_size_figure():
+    """`cpu_baseline.value` is the largest MEASURED sample, `samples` holds both, `fitted_exponent` is what they give and
+    `value_at_bench_size` (with `extrapolated: true`) is the figure that belongs beside the GPU line.  Tiny sizes here; the oracle is the timed thing."""
+    import types
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from benchlib.cpu_baseline import cpu_baseline
+    from oracle import oracle as O
+    bases = O.gen_bases(O.BN254, 3, 64, 1 << 10)
+
+    def d2h(ctx, dst, src, nbytes):
+        import ctypes as C
+        C.memmove(dst, bases.ctypes.data, nbytes)
+        return 0
+
+    b = types.SimpleNamespace(args=types.SimpleNamespace(curve="bn254", log_n=12, cpu_sample_log_n=8, cpu_sample_log_n2=10), np=np, n=1 << 12, q64=4,
+                              w=types.SimpleNamespace(lib=types.SimpleNamespace(plonk_memcpy_d2h=d2h), ctx=None), bases=types.SimpleNamespace(ptr=0))
+    c = cpu_baseline(b)
+    assert c["kind"] == "port" and c["extrapolated"] is True and [s["log_n"] for s in c["samples"]] == [8, 10]
+    assert c["value"] == c["samples"][1]["constraints_per_s"] and "2^10" in c["sample"]
+    assert 0.3 < c["fitted_exponent"] < 2.5 and c["value_at_bench_size"] == c["extrapolated_to_bench_size"]["by_fitted_exponent"]["value"]
+    assert c["extrapolated_to_bench_size"]["by_operation_counts"]["value"] > 0
+    # one sample only, at the bench size: nothing is extrapolated
+    b.args.cpu_sample_log_n2, b.args.log_n, b.n = 0, 8, 1 << 8
+    c = cpu_baseline(b)
+    assert c["extrapolated"] is False and c["value_at_bench_size"] == c["value"] and len(c["samples"]) == 1 and "extrapolated_to_bench_size" not in c

@@ -153,3 +153,46 @@ def test_prover_six_coset_quotient_matches_oracle(gpu_workers, oracle, curve, ci
         pv.close()
         if helper is not None:
             helper.close()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+@pytest.mark.parametrize("log_n", [5, 11])
+def test_prover_key_coset_ffts_on_a_third_context_match_oracle(gpu_workers, oracle, curve, cid, log_n):
+    """Prover(fft_helper=...) — what bench.py's proof runs with up to 2^22 gates since round 5 (profiles/r05_opening_measurements.txt): the 18
+    proving-key coset FFTs of round 3 issued on a third context by a thread of their own beside rounds 1 and 2.  Same outputs as the oracle's
+    restatement of dispatcher2.rs:296-712, bit for bit, twice in a row (work buffers reused); an unsatisfied witness still raises and
+    leaves no thread behind."""
+    import threading
+    from distributed_plonk_amd.worker import PlonkWorker
+    P, circ, ck, inf, bl, ch = _instance(oracle, cid, log_n, 1300 + log_n)
+    n = 1 << log_n
+    w = gpu_workers(curve)
+    w.init(ck, n, 8 * n)
+    c2, h = PlonkWorker(curve=curve), PlonkWorker(curve=curve)
+    for x in (c2, h):
+        x.init(ck, n, 8 * n)
+    pv = Prover(w, log_n, commit_helper=c2, fft_helper=h)
+    try:
+        pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+        for _ in range(2):
+            got = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+            assert pv._key_ffts is None
+        want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=16)
+        for key in ("wires_poly_comms", "split_quot_poly_comms"):
+            for g, x in zip(got[key], want[key]):
+                assert _same_point(g, x), key
+        for key in ("prod_perm_poly_comm", "opening_proof", "shifted_opening_proof"):
+            assert _same_point(got[key], want[key]), key
+        assert np.array_equal(np.stack(got["wires_evals"]), np.stack(want["wires_evals"]))
+        for key in ("perm_product", "perm_poly", "quot_poly", "lin_poly", "batch_poly"):
+            assert np.array_equal(got["_debug"][key], want[key]), key
+        bad = circ["wires"].copy()
+        bad[4, 1] = oracle.rand_fr(cid, 4321, 1)[0]
+        before = threading.active_count()
+        with pytest.raises(WrongQuotientPolyDegree):
+            pv.prove(bad, circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
+        assert pv._key_ffts is None and threading.active_count() == before
+    finally:
+        pv.close()
+        c2.close()
+        h.close()

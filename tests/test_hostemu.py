@@ -155,8 +155,29 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
 
 
+@pytest.mark.parametrize("extra", [("--sim-exchange", "standin"), ("--sim-exchange", "none", "--scheme", "classes")])
+def test_bench_program_simulated_ranks(emu_env, extra):
+    """`bench.py --simulate-ranks 4`: rank 0's share of a 4-rank job on one (emulated) device — the reference2d / classes step with the library's
+    exchange stand-in (device-to-device copies of the foreign blocks) or none, phases overlapped (auto), the polynomial-parallel leg's busiest
+    rank and the class prover with rounds 1-2 distributed, against the stand-in communicator.  Results are garbage by construction; what is
+    checked is that every leg runs and that the line says what it is (and quotes nobody else's counters)."""
+    import json
+    e = dict(emu_env, HIPEMU_DEVICES="4", HIPEMU_THREADS=str(min(8, os.cpu_count() or 1)))
+    r = subprocess.run([sys.executable, "bench.py", "--steps", "1", "--warmup", "1", "--log-n", "9", "--simulate-ranks", "4", *extra], cwd=ROOT, env=e,
+                       capture_output=True, text=True, timeout=900)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
+    d = json.loads(lines[0])
+    assert d["emulated"] is True and d["sim_exchange"]["mode"] == extra[1] and d["config"]["phase_overlap"] is True
+    assert "SIMULATED rank 0 of 4" in d["config"]["parallelism"] and ("device-to-device" in d["config"]["parallelism"]) == (extra[1] == "standin")
+    assert d["sim_exchange"]["bytes_out_per_rank_and_step"] == 3 * (7 * (512 // 16) * 32 + 26 * (4096 // 16) * 32)
+    cp = d["next_rows"]["class_prover"]
+    assert cp["simulated"] is True and cp["ranks"] == 4 and cp["rounds_1_2"].startswith("size-n iFFTs by residue class"), cp
+    assert (cp["sim_exchange"]["device_bytes_out_per_proof"] > 0) and "error" not in (d.get("polynomial_parallel") or {}), d
+
+
 def test_bench_program_multi_rank_with_phases_overlapped(emu_env):
-    """`--overlap-phases on` at N > 1 (never chosen by 'auto'; built without a GPU at the end of round 4): the two transform lanes on contexts and
+    """`--overlap-phases on` at N > 1 ('auto' chooses it since round 5's measurement): the two transform lanes on contexts and
     communicators of their own, the distributed transforms issued from the main thread while the commitment threads run, the point all-gather
     after the last all-to-all — same order of collectives on every rank, or this run would hang in the shared-memory communicator."""
     from conftest import free_port

@@ -20,5 +20,5 @@ for oc in d.get("other_configs") or []:
     print({k: oc.get(k) for k in ("config", "ms_per_step", "phases_ms", "verified", "proof_ms", "prover_verified", "error")})
 print("next rows", {k: (v.get("ms"), v.get("frac")) for k, v in (d.get("next_rows") or {}).items() if isinstance(v, dict) and "ms" in v})
 print("rounds", d["next_rows"]["prover_rounds"]["rounds_ms"])
-print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"]["extrapolated_to_bench_size"]["value"])
+print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("fitted_exponent"), d["cpu_baseline"].get("value_at_bench_size"), d["cpu_baseline"].get("samples"))
 PY
