@@ -170,13 +170,13 @@ struct CollectiveScope {
         if (dev < 0 || dev >= 64) { rc = PLONK_ERR_ARG; what = "device index outside 0..63"; device = -1; return; }
         static const bool any_thread = getenv("PLONK_COMM_ANY_THREAD") != nullptr;
         const std::thread::id me = std::this_thread::get_id();
-        if (!g_order.owned[dev]) { g_order.owner[dev] = me; g_order.owned[dev] = true; }
-        else if (g_order.owner[dev] != me && !any_thread) {
+        if (g_order.owned[dev] && g_order.owner[dev] != me && !any_thread) {
             rc = PLONK_ERR_STATE; what = "collectives of one device must be issued from one host thread (same order on every rank)"; device = -1; return;
         }
         hipEvent_t& e = g_order.last[dev];
         hipError_t he = e ? hipStreamWaitEvent(stream, e, 0) : hipEventCreateWithFlags(&e, hipEventDisableTiming);
-        if (he != hipSuccess) { rc = PLONK_ERR_HIP; what = "collective ordering event"; device = -1; }
+        if (he != hipSuccess) { rc = PLONK_ERR_HIP; what = "collective ordering event"; device = -1; return; }
+        if (!g_order.owned[dev]) { g_order.owner[dev] = me; g_order.owned[dev] = true; }      // only a collective that really gets issued takes the device
     }
     // record the ordering point behind the collective; a failure here would silently drop the ordering, so it is reported
     int finish() {

@@ -14,8 +14,8 @@
 // so  mont261(x, c*2^261) = x*c  keeps x's 2^256 factor untouched.  Values are canonicalised
 // (conditional subtraction) before the final store, so results are bit-identical to ark-ff's.
 //
-// Bounds (p < 2^255, R = 2^261):  f29_mul accepts x < 2^259.4 with limbs < 2^31 and a normalised
-// constant w < p, and returns a normalised value < 1.36 p.  x + C - t with C = "2p in borrow form"
+// Bounds (p < 2^255, R = 2^261):  f29_mul accepts x < 2^261 (170 p on BN254, 70 p on BLS12-381's Fr) with limbs < 2^31 and a
+// normalised constant w < p, and returns a normalised value < x*p/2^261 + p (< 1.36 p for x < 2^259.4, < 2 p at the limit).  x + C - t with C = "2p in borrow form"
 // needs t normalised (a product).  Decimation-in-time butterflies grow the bound by at most 2p per
 // stage, so up to ~20 stages run between canonicalisations.
 #pragma once
@@ -127,7 +127,8 @@ FP_HD F29 f29_sub4p(const F29& a, const F29& t, const F29Params& P) {
 }
 
 // Montgomery product x*w/2^261 mod p, product scanning with one 64-bit accumulator.
-// x: limbs < 2^31, value < 2^259.4 ; w: normalised, < p.  Result normalised, < 1.36 p.
+// x: limbs < 2^31, value < 2^261 ; w: normalised, < p.  Result normalised, < x*p/2^261 + p (< 1.36 p for x < 2^259.4; tests/test_fp29_host.py
+// checks the host build against Python integers up to 40 p).
 FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
     uint64_t acc = 0;
     uint32_t m[9];
@@ -162,7 +163,7 @@ FP_HD F29 f29_mul(const F29& x, const F29& w, const F29Params& P) {
 //     r = x*c - q*p  in [0, 3p)  and only its low 261 bits are needed:  r = (x*c + q*pbar) mod 2^261,  pbar = 2^261 - p
 // Cost: columns 7..16 of x*cq (53 limb products) + columns 0..8 of x*c and of q*pbar (45 + 45) = 143 limb products and no v_mul_lo,
 // against 171 for the Montgomery product above (profiles/r02_multiplier_variants_static.txt: 213 -> 188 VALU instructions).
-// x: limbs < 2^31, value < 2^259.4 (f29_mul's contract); result normalised, value < 3p — butterflies subtract it from 4p (c4p).
+// x: limbs < 2^31, value < 2^261 (f29_mul's contract); result normalised, value < 3p — butterflies subtract it from 4p (c4p).
 FP_HD F29 f29_mul_shoup(const F29& x, const uint32_t* c, const uint32_t* cq, const F29Params& P) {
     uint64_t acc = 0;
     uint32_t q[9];

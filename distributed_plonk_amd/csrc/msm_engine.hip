@@ -34,6 +34,9 @@
 #include "ec_lazy.hpp"
 #include "plonk_internal.hpp"
 
+#define BASES_BAD_CURVE 1u
+#define BASES_BAD_RANGE 2u
+#define BASES_BAD_FLAG 4u
 template <int NQ> static const FpParams<NQ>& fq_params(int curve);
 template <> const FpParams<8>& fq_params<8>(int) { return BN254_FQ_PARAMS; }
 template <> const FpParams<12>& fq_params<12>(int) { return BLS12_381_FQ_PARAMS; }
@@ -939,27 +942,82 @@ __global__ void __launch_bounds__(256) msm_bit_sums_kernel(const XyzzL<LimbGeom<
 // ---------------------------------------------------------------------------------------------- ark layout -> compact
 // arkworks GroupAffine { x, y, infinity: bool } padded to 8 bytes: stride 16*Q64 + 8 bytes.
 template <int NQ>
-__global__ void __launch_bounds__(256) bases_convert_kernel(const uint32_t* __restrict__ raw, uint64_t n, AffPt<NQ>* __restrict__ out) {
+__global__ void __launch_bounds__(256) bases_convert_kernel(const uint32_t* __restrict__ raw, uint64_t n, AffPt<NQ>* __restrict__ out,
+                                                            unsigned long long* __restrict__ bad /* [0]: first offending index, [1]: reasons */) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t* s = raw + i * (2 * NQ + 2);
     AffPt<NQ> p;
     const bool inf = (s[2 * NQ] & 0xff) != 0;
+    if (bad != nullptr && (s[2 * NQ] & 0xff) > 1) {            // `infinity: bool` is 0 or 1 in Rust: anything else is not a GroupAffine at this stride
+        atomicMin(bad, (unsigned long long)i);
+        atomicOr(bad + 1, (unsigned long long)BASES_BAD_FLAG);
+    }
 #pragma unroll
     for (int k = 0; k < NQ; k++) { p.x.l[k] = inf ? 0 : s[k]; p.y.l[k] = inf ? 0 : s[NQ + k]; }
     store16(out + i, p);
 }
 
-int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream) {
+int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, unsigned long long* d_bad, hipStream_t stream) {
     if (n == 0) return PLONK_OK;
     const uint32_t grid = (uint32_t)((n + 255) / 256);
     if (curve == PLONK_BN254)
-        hipLaunchKernelGGL(bases_convert_kernel<8>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<8>*)d_compact);
+        hipLaunchKernelGGL(bases_convert_kernel<8>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<8>*)d_compact, d_bad);
     else
-        hipLaunchKernelGGL(bases_convert_kernel<12>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<12>*)d_compact);
+        hipLaunchKernelGGL(bases_convert_kernel<12>, dim3(grid), dim3(256), 0, stream, (const uint32_t*)d_raw, (uint64_t)n, (AffPt<12>*)d_compact, d_bad);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "bases_convert launch: %s", hipGetErrorString(e));
     return PLONK_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- the SRS, checked at the boundary
+// Every base must be a point of the curve: coordinates reduced, y^2 = x^3 + b, or the (0, 0) this library reads as infinity.  The Rust
+// side hands over `[G1Affine]` by reinterpreting memory (utils.rs:27-43, worker.rs:136-141) and `GroupAffine {x, y, infinity}` has no
+// guaranteed field order: swapped coordinates, a shifted stride or a different padding would otherwise give commitments that are
+// garbage with PLONK_OK.  One lane per point, 3 saturated Montgomery products: ~1 ms at 2^24 points, once per init.
+template <int NQ>
+__global__ void __launch_bounds__(256) bases_check_kernel(const AffPt<NQ>* __restrict__ pts, uint64_t n, const FpParams<NQ> P, const Fp<NQ> b_mont,
+                                                          unsigned long long* __restrict__ bad) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const AffPt<NQ> a = load16(pts + i);
+    if (aff_is_inf(a)) return;
+    uint32_t why = 0;
+    bool xr = false, yr = false;                               // < p ?
+    for (int k = NQ - 1; k >= 0; k--) { if (a.x.l[k] != P.p[k]) { xr = a.x.l[k] < P.p[k]; break; } }
+    for (int k = NQ - 1; k >= 0; k--) { if (a.y.l[k] != P.p[k]) { yr = a.y.l[k] < P.p[k]; break; } }
+    if (!xr || !yr) why = BASES_BAD_RANGE;
+    else if (!fp_eq(fp_sqr(a.y, P), fp_add(fp_mul(fp_sqr(a.x, P), a.x, P), b_mont, P))) why = BASES_BAD_CURVE;
+    if (why) {
+        atomicMin(bad, (unsigned long long)i);
+        atomicOr(bad + 1, (unsigned long long)why);
+    }
+}
+
+// d_bad: two device words, zeroed to {~0, 0} here unless `keep` (the ark conversion has already written its findings)
+template <int NQ> static int bases_check_t(int curve, const void* d_xy, size_t n, unsigned long long* d_bad, bool keep, const char* who, hipStream_t stream) {
+    const FpParams<NQ>& P = fq_params<NQ>(curve);
+    if (!keep) {
+        static const unsigned long long init[2] = {~0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(d_bad, init, sizeof init, hipMemcpyHostToDevice, stream));
+    }
+    Fp<NQ> b = fp_zero<NQ>(), one;
+    for (int k = 0; k < NQ; k++) one.l[k] = P.one[k];
+    for (int k = 0; k < (curve == PLONK_BN254 ? 3 : 4); k++) b = fp_add(b, one, P);          // y^2 = x^3 + 3 (BN254) / + 4 (BLS12-381), Montgomery form
+    if (n) hipLaunchKernelGGL(bases_check_kernel<NQ>, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, (const AffPt<NQ>*)d_xy, (uint64_t)n, P, b, d_bad);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "bases_check launch: %s", hipGetErrorString(e));
+    unsigned long long h[2] = {~0ull, 0ull};
+    HIP_TRY(hipMemcpyAsync(h, d_bad, sizeof h, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (h[1] == 0) return PLONK_OK;
+    return plonk_fail(PLONK_ERR_ARG, "%s: base %llu of %zu is not a curve point (%s%s%s) — wrong layout, field order or stride?  (PLONK_BASES_XY: x||y, "
+                      "PLONK_BASES_ARK: x, y, infinity byte; Montgomery limbs; plonk_set_option(\"check_bases\", 0) skips this check)", who, h[0], n,
+                      (h[1] & BASES_BAD_FLAG) ? "infinity flag byte is neither 0 nor 1; " : "", (h[1] & BASES_BAD_RANGE) ? "coordinate not below the modulus; " : "",
+                      (h[1] & BASES_BAD_CURVE) ? "y^2 != x^3 + b" : "");
+}
+int bases_check(int curve, const void* d_xy, size_t n, unsigned long long* d_bad, bool keep, const char* who, hipStream_t stream) {
+    return curve == PLONK_BN254 ? bases_check_t<8>(curve, d_xy, n, d_bad, keep, who, stream) : bases_check_t<12>(curve, d_xy, n, d_bad, keep, who, stream);
 }
 
 template <int NQ> static const FLParams<LimbGeom<NQ>::NL, LimbGeom<NQ>::B>& fl_params(int curve) {

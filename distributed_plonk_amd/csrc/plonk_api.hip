@@ -84,6 +84,8 @@ struct plonk_ctx {
     // small free-list of exchange buffers so that back-to-back transforms do not hipMalloc/hipFree
     std::vector<std::pair<size_t, void*>> pool;
     PlonkComm* comm = nullptr;                  // RCCL communicator (plonk_comm_init), owned
+    int check_bases = 1;                        // init: every base must be a curve point (option "check_bases")
+    unsigned long long* d_bad = nullptr;        // two words for that check's verdict
 };
 
 static int pool_get(plonk_ctx* ctx, size_t bytes, void** out) {
@@ -187,6 +189,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases) (void)hipFree(ctx->d_bases);
     if (ctx->d_wire) (void)hipFree(ctx->d_wire);
+    if (ctx->d_bad) (void)hipFree(ctx->d_bad);
     if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
     if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
     msm_ws_release(ctx->msm_ws);
@@ -206,6 +209,7 @@ extern "C" int plonk_sync(plonk_ctx* ctx) {
 extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
+    if (!strcmp(key, "check_bases")) { ctx->check_bases = value ? 1 : 0; return PLONK_OK; }            // default 1; takes effect at the next init
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_c")) {                                                                // takes effect at the next init
         // 0 = the plan's choice; a pinned width must be one the table plan considers (msm_engine.hip: MSM_TABLE_MAX_C = 21).  A width that is valid
@@ -266,7 +270,22 @@ static int set_domains(plonk_ctx* ctx, size_t domain_size, size_t quot_domain_si
 }
 
 // SRS -> resident limb form, plus the fixed-base window table when it pays off (one-time work per `init`)
-static int install_bases(plonk_ctx* ctx, const void* d_xy, size_t n_bases) {
+static int bad_words(plonk_ctx* ctx, bool reset) {
+    if (!ctx->d_bad) HIP_TRY(hipMalloc((void**)&ctx->d_bad, 16));
+    if (reset) {
+        static const unsigned long long init[2] = {~0ull, 0ull};
+        HIP_TRY(hipMemcpyAsync(ctx->d_bad, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+    }
+    return PLONK_OK;
+}
+
+// `flags_seen`: the ark conversion has already left its findings (bad infinity bytes) in ctx->d_bad
+static int install_bases(plonk_ctx* ctx, const void* d_xy, size_t n_bases, const char* who, bool flags_seen = false) {
+    if (ctx->check_bases) {                     // before anything is installed: a refused SRS leaves the context without bases
+        int rc = bad_words(ctx, false);
+        if (!rc) rc = bases_check(ctx->curve, d_xy, n_bases, ctx->d_bad, flags_seen, who, ctx->stream);
+        if (rc) return rc;
+    }
     int W = 1, G = 1, T = 1;
     const int c = msm_table_plan(ctx->curve, n_bases, ctx->msm_precompute, ctx->msm_table_budget, ctx->msm_table_c, ctx->msm_table_sets, &W, &G, &T);
     const size_t pb = msm_limb_base_bytes(ctx->curve);
@@ -309,9 +328,10 @@ extern "C" int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int
             const size_t rb = ark_aff_bytes(ctx->curve) * n_bases;
             if ((rc = ensure_scratch(ctx, rb))) return rc;
             HIP_TRY(hipMemcpyAsync(ctx->d_scratch, bases, rb, hipMemcpyHostToDevice, ctx->stream));
-            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy.p, ctx->stream))) return rc;
+            if (ctx->check_bases && (rc = bad_words(ctx, true))) return rc;
+            if ((rc = bases_convert_ark(ctx->curve, ctx->d_scratch, n_bases, d_xy.p, ctx->check_bases ? ctx->d_bad : nullptr, ctx->stream))) return rc;
         }
-        if ((rc = install_bases(ctx, d_xy.p, n_bases))) return rc;
+        if ((rc = install_bases(ctx, d_xy.p, n_bases, "plonk_init", base_layout == PLONK_BASES_ARK))) return rc;
     }
     return PLONK_OK;
 }
@@ -324,7 +344,7 @@ extern "C" int plonk_init_dev(plonk_ctx* ctx, const void* d_bases_xy, size_t n_b
     if (ctx->d_bases) (void)hipFree(ctx->d_bases);
     ctx->d_bases = nullptr; ctx->n_bases = 0; ctx->msm_table = MsmTable();
     if (n_bases) {
-        if ((rc = install_bases(ctx, d_bases_xy, n_bases))) return rc;
+        if ((rc = install_bases(ctx, d_bases_xy, n_bases, "plonk_init_dev"))) return rc;
     }
     return PLONK_OK;
 }

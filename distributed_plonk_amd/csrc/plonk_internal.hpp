@@ -197,7 +197,10 @@ int msm_table_plan(int curve, size_t n, int mode, size_t budget_bytes, int force
 int msm_table_build(int curve, void* d_table, size_t n, size_t stride, int shift, int T, hipStream_t stream);
 int msm_jac_add_host(int curve, const uint32_t* a, const uint32_t* b, uint32_t* out);
 int msm_jac_to_affine_host(int curve, const uint32_t* jac, uint32_t* out_xy, int* is_inf);
-int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, hipStream_t stream);
+int bases_convert_ark(int curve, const void* d_raw, size_t n, void* d_compact, unsigned long long* d_bad, hipStream_t stream);
+// every base a curve point (or the (0, 0) read as infinity)?  PLONK_ERR_ARG naming the first offender otherwise.  d_bad: two device words
+// {first offending index, reasons}; keep = they already hold the ark conversion's findings
+int bases_check(int curve, const void* d_xy, size_t n, unsigned long long* d_bad, bool keep, const char* who, hipStream_t stream);
 int bases_to_limbs(int curve, const void* d_xy, size_t n, void* d_out, hipStream_t stream);
 size_t msm_limb_base_bytes(int curve);
 

@@ -85,7 +85,12 @@ int plonk_exchange_rccl(void* user, const void* send, void* recv, size_t bytes_p
  * same buffers, at HBM instead of xGMI speed.  Results are meaningless; `user` is ignored. */
 int plonk_exchange_standin(void* user, const void* send, void* recv, size_t bytes_per_peer, int n_ranks, void* stream);
 /* device buffers, ordered on the context's stream, not synchronised: block p of d_send -> rank p / every rank's d_send -> block
- * `rank` of everybody's d_recv.  The two data-path collectives of the coset-class prover. */
+ * `rank` of everybody's d_recv.  The two data-path collectives of the coset-class prover.
+ * THREAD RULE (all collectives of this library, plonk_fft2_prepare's exchange included): the collectives of one DEVICE must come from
+ * ONE host thread — the first that issues one on that device owns it until the device's last communicator is destroyed; a call from
+ * another thread returns PLONK_ERR_STATE instead of risking a cross-rank deadlock (two threads cannot promise the same issue order on
+ * every rank).  A host whose runtime migrates one logical task between OS threads sets the environment variable
+ * PLONK_COMM_ANY_THREAD=1 and serialises its collectives itself. */
 int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer);
 int plonk_comm_allgather_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 /* host buffers (partial commitment points, 96 / 144 B each): out receives world * bytes.  Synchronises. */
@@ -102,7 +107,13 @@ int plonk_sync(plonk_ctx* ctx);
 
 /* ---- PlonkSlave @0 init — worker.rs:126-157, client dispatcher.rs:50-68 ----------------------
  * Stores the SRS bases on the device and fixes the two evaluation domains (n and the quotient
- * domain m); either size may be 0 (dispatcher.rs:215 passes 0,0 for the MSM test). */
+ * domain m); either size may be 0 (dispatcher.rs:215 passes 0,0 for the MSM test).
+ * The bases are CHECKED: every one must be a point of the curve (coordinates below the modulus, y^2 = x^3 + b), the infinity this
+ * layout encodes ((0, 0) in PLONK_BASES_XY; any x, y with the flag byte = 1 in PLONK_BASES_ARK), and an ark flag byte must be 0 or 1 —
+ * else PLONK_ERR_ARG naming the first offending index, and the context is left WITHOUT bases.  The reference reinterprets
+ * `[G1Affine]` memory (utils.rs:27-43, worker.rs:136-141) and `GroupAffine {x, y, infinity}` is a default-repr Rust struct whose field
+ * order is not guaranteed: swapped coordinates, a shifted stride or different padding fail here instead of yielding commitments that are
+ * garbage with PLONK_OK.  ~1 ms per 2^24 points; plonk_set_option(ctx, "check_bases", 0) skips it. */
 int plonk_init(plonk_ctx* ctx, const void* bases, size_t n_bases, int base_layout,
                size_t domain_size, size_t quot_domain_size);
 
@@ -308,8 +319,8 @@ int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, c
  * "msm_table_c" (0 or 4..21) / "msm_table_sets" / "msm_table_budget_mib" (the table's window width, bucket sets per scalar and memory budget;
  * 0 = the plan's choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_reduce_grid" (default 0: the window
  * reduction as tree sums over the bucket grid instead of the running-sum pyramid — faster for one small MSM alone, not beside another context's
- * accumulation: profiles/r04_pin_nop_experiment.txt), "msm_fused_y3", "ntt_shoup" (BN254 only, default 1: precomputed-quotient butterflies in
- * the NTT passes; 0 = Montgomery butterflies), "quotient_fuse" (6 = default: the compact kernel; 0-5, 7: other formulations).
+ * accumulation: profiles/r04_pin_nop_experiment.txt), "msm_fused_y3", "ntt_shoup" (both curves, default 1: precomputed-quotient butterflies in
+ * the NTT passes; 0 = Montgomery butterflies), "check_bases" (default 1: plonk_init* verifies that every base is a curve point), "quotient_fuse" (6 = default: the compact kernel; 0-5, 7: other formulations).
  * INTEGRATION.md §6 has the table. */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);
 /* Timing of the kernels launched by the last plonk_*_dev call on this context, measured with HIP
