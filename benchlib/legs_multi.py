@@ -298,17 +298,21 @@ class _SimComm:
     def __init__(self, size, b, w):
         self.size, self.b, self.w = size, b, w
         self.bytes_out = 0
+        # --sim-exchange none: the UNTIMED first proof still moves the stand-in's bytes, so that the receive buffers (named work buffers, reused
+        # by the timed proof) hold field elements and not the zeros of a fresh allocation — round 4's 125.3 ms "rank 0 of 8" proof had committed
+        # an all-zero quotient (4.3 ms for five 2^21-point commitments that cost 16.8 ms on data) and is void for that reason
+        self.fill = True
 
     def all_gather_host(self, obj):
         return [obj] * self.size
 
     def all_to_all_dev(self, d_send, d_recv, nbytes):
         self.bytes_out += (self.size - 1) * nbytes
-        self.b.sim_alltoall(self.w, d_send, d_recv, nbytes)
+        self.b.sim_alltoall(self.w, d_send, d_recv, nbytes, force=self.fill)
 
     def all_gather_dev(self, d_send, d_recv, nbytes):
         self.bytes_out += (self.size - 1) * nbytes
-        self.b.sim_allgather(self.w, d_send, d_recv, nbytes)
+        self.b.sim_allgather(self.w, d_send, d_recv, nbytes, force=self.fill)
 
 
 def class_prover(b):
@@ -351,6 +355,8 @@ def class_prover(b):
     t_cls, proof_c = None, None
     for it in range(2):
         fs = cp.fiat_shamir(pub)
+        if sim:
+            comm.fill = it == 0
         b.full_sync()
         t0 = time.perf_counter()
         proof_c = cp.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=not sim)

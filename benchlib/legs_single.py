@@ -170,7 +170,7 @@ def _small_rows(b, inst, fs, consts):
         "perm_product": row(["perm_terms_kernel", "perm_scan_num", "perm_scan_den_final"], n * (16 * 32 + 5 * 8.0), "dispatcher2.rs:329-344"),
         "poly_eval": row(["poly_eval_kernel"], n * 32.0, "dispatcher2.rs:545-555"),
         "poly_lincomb_20_terms": row(["poly_lincomb_kernel"], n * 21 * 32.0, "dispatcher2.rs:566-633"),
-        "poly_div_linear": row(["poly_scale_kernel", "poly_div_scan"], n * 64.0, "dispatcher2.rs:651-666"),
+        "poly_div_linear": row(["poly_div_kernels"], n * 64.0, "dispatcher2.rs:651-666"),
     }
     w.profile_enable(False)
     out_n.free()

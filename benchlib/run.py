@@ -217,14 +217,14 @@ class Bench:
     def sim_exchange_note(self):
         return ("collectives replaced by device-to-device copies of the bytes they would move" if self.sim_standin else "no exchange")
 
-    def sim_alltoall(self, w, d_send, d_recv, nbytes):
+    def sim_alltoall(self, w, d_send, d_recv, nbytes, force=False):
         """blocks 1 .. S-1 of d_send -> d_recv on w's stream (what leaves for / arrives from the S - 1 peers)"""
-        if self.sim_standin and self.S > 1:
+        if (self.sim_standin or force) and self.S > 1:
             w.memcpy_d2d_async(d_recv + nbytes, d_send + nbytes, (self.S - 1) * nbytes)
 
-    def sim_allgather(self, w, d_send, d_recv, nbytes):
+    def sim_allgather(self, w, d_send, d_recv, nbytes, force=False):
         """d_send -> the S - 1 foreign blocks of d_recv (the bytes that would arrive), and the rank's own block"""
-        if self.sim_standin:
+        if self.sim_standin or force:
             for p_ in range(self.S):
                 w.memcpy_d2d_async(d_recv + p_ * nbytes, d_send, nbytes)
 

@@ -415,23 +415,32 @@ int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm
 }
 
 // ---------------------------------------------------------------------------------------------- rank 3: evaluate
-__global__ void __launch_bounds__(PO_LANES) poly_eval_kernel(const Fr* __restrict__ poly, uint64_t len, const PowTab pw, Fr* __restrict__ partial, const PoCtx c) {
+// Round 5: Horner per lane over elements PO_LANES apart (coalesced 256-bit loads), ONE product per coefficient:
+//   poly(z) = sum_L z^(base + L) * H_L,   H_L = sum_k c[base + L + 256 k] * (z^256)^k   (Horner in z^256, a constant shared by all lanes)
+// EV_K coefficients per lane, then one product by z^(base + L) from the power table and the block's additive tree.  (Rounds 2-4 multiplied
+// every coefficient by z^i from the three-level table: 3 products per coefficient, 12.7 % of the HBM peak.)
+#define EV_K 32
+#define EV_TILE (PO_LANES * EV_K)
+__global__ void __launch_bounds__(PO_LANES) poly_eval_kernel(const Fr* __restrict__ poly, uint64_t len, const F29 z256 /* rep(z^256) */, const PowTab pw,
+                                                             Fr* __restrict__ partial, const PoCtx c) {
     __shared__ uint32_t sh[PO_LANES][9];
     const F29Params& fp = c.f29;
-    const uint64_t base = (uint64_t)blockIdx.x * PO_TILE + threadIdx.x;
-    F29 sum;
+    const uint64_t base = (uint64_t)blockIdx.x * EV_TILE + threadIdx.x;
+    F29 acc;
 #pragma unroll
-    for (int l = 0; l < 9; l++) sum.l[l] = 0;
-#pragma unroll
-    for (int k = 0; k < PO_CH; k++) {
-        const uint64_t i = base + (uint64_t)k * PO_LANES;        // coalesced
+    for (int l = 0; l < 9; l++) acc.l[l] = 0;
+    bool any = false;
+#pragma unroll 4
+    for (int k = EV_K - 1; k >= 0; k--) {
+        const uint64_t i = base + (uint64_t)k * PO_LANES;
         if (i < len) {
-            sum = f29_add(sum, f29_mul(f29_from_sat(load_fr(poly + i)), pow_at(pw, i, fp), fp));   // c_i z^i, R form
-            if ((k & 1) == 1) f29_norm(sum);
+            const F29 ci = f29_from_sat(load_fr(poly + i));
+            acc = any ? f29_add(f29_mul(acc, z256, fp), ci) : ci;       // < 1.36 p + p, limbs < 2^30: inside f29_mul's operand range
+            any = true;
         }
     }
-    f29_norm(sum);                                                // < 11 p
-    const Fr mine = f29_to_sat(f29_canon(f29_mul(sum, params_one(fp), fp), fp));
+    Fr mine = fp_zero<8>();
+    if (any) mine = f29_to_sat(f29_canon(f29_mul(acc, pow_at(pw, base, fp), fp), fp));        // * z^(base + L), R form, canonical
     const Fr tot = block_total<OpAdd, PO_LANES>(mine, sh, c);
     if (threadIdx.x == 0) store_fr(partial + blockIdx.x, tot);
 }
@@ -443,7 +452,13 @@ __global__ void __launch_bounds__(PO_LANES) fr_sum_kernel(const Fr* __restrict__
     if (threadIdx.x == 0) store_fr(out, tot);
 }
 
-size_t poly_scratch_bytes(size_t len) { return align256(len * 32) + 2 * align256(tiles_of(len) * 32) + 2 * align256(POWTAB_BYTES) + 1024; }
+size_t poly_scratch_bytes(size_t len) { return 3 * align256((len / 1024 + 2) * 32) + 1024; }      // tile aggregates / carries of the division, partial sums of the evaluation
+
+// rep(b^(2^k))
+static F29 host_rep_pow2k(Fr b, int k, const FrParams& P) {
+    for (int i = 0; i < k; i++) b = fp_mul(b, b, P);
+    return host_rep(b, P);
+}
 
 int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* point, uint64_t* out_host, void* scratch, hipStream_t stream) {
     const FrParams& P = T.fp;
@@ -457,10 +472,11 @@ int poly_eval_run(NttTables& T, const void* d_poly, size_t len, const uint64_t* 
     int rc = build_pow_tab(T, fr_arg(point), len, &pw, stream);
     if (rc) return rc;
     const PoCtx c = make_ctx(T);
-    const uint64_t nb = tiles_of(len);
+    const uint64_t nb = (len + EV_TILE - 1) / EV_TILE;
     {
         ProfScope ps("poly_eval_kernel", stream);
-        hipLaunchKernelGGL(poly_eval_kernel, dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)d_poly, (uint64_t)len, pw, partial, c);
+        hipLaunchKernelGGL(poly_eval_kernel, dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)d_poly, (uint64_t)len, host_rep_pow2k(fr_arg(point), 8, P), pw,
+                           partial, c);
         hipLaunchKernelGGL(fr_sum_kernel, dim3(1), dim3(PO_LANES), 0, stream, (const Fr*)partial, nb, res, c);
     }
     hipError_t e = hipGetLastError();
@@ -525,19 +541,230 @@ int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const siz
 }
 
 // ---------------------------------------------------------------------------------------------- rank 3: division by (X - z)
-__global__ void __launch_bounds__(256) poly_scale_kernel(const Fr* __restrict__ poly, uint64_t len, const PowTab pw, Fr* __restrict__ out, const PoCtx c) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    store_fr(out + i, f29_to_sat(f29_canon(f29_mul(f29_from_sat(load_fr(poly + i)), pow_at(pw, i, c.f29), c.f29), c.f29)));     // c_i z^i
-}
-struct EpiDivFinal {         // q[i-1] = z^-i * s_i
-    PowTab zinv;
-    Fr* out;
-    __device__ __forceinline__ void operator()(const Fr& s, uint64_t i, const PoCtx& c) const {
-        if (i == 0) return;                                       // s_0 = poly(z): the dropped remainder
-        store_fr(out + i - 1, f29_to_sat(f29_canon(f29_mul(f29_from_sat(s), pow_at(zinv, i, c.f29), c.f29), c.f29)));
+// q_j = sum_{k > j} c_k z^(k-j-1)  (the quotient of dispatcher2.rs:651-666; q_j = c_(j+1) + z q_(j+1) from the top).
+// Round 5: reduce-then-scan over tiles of DV_TILE coefficients, the coefficients read twice and the quotient written once
+// (96 B per coefficient; rounds 2-4: scale / three-phase additive scan / unscale, 160 B and 6 products per coefficient, 8.3 % of HBM peak):
+//   D1  tile t (coefficients k = 1 + t*DV_TILE + e):  A_t = sum_e c_k z^e      — lane-strided Horner as in poly_eval, one product per coefficient
+//   D2  one workgroup:  X_t = sum_{u > t} A_u (z^DV_TILE)^(u-t-1) = q at the first index above tile t
+//   D3  tile t: the coefficients go through LDS so that lane L owns DV_CH CONSECUTIVE ones (the recurrence is serial in j):
+//       lane aggregate (DV_CH products) -> scaled by z^(DV_CH*L) (1) -> ADDITIVE suffix scan over the lanes (no products) -> unscaled by
+//       z^-(DV_CH*(L+1)) with the tile's carry folded in (2) -> the recurrence down the lane's chunk (DV_CH) -> LDS -> coalesced stores.
+//       2 + 3/DV_CH products per coefficient.
+#define DV_LANES 128
+#define DV_CH 8
+#define DV_TILE (DV_LANES * DV_CH)
+#define DV_TOP 1024
+// per-point constants (cached like the power tables): [0, DV_LANES) rep(z^(DV_CH*L)); [DV_LANES, 2*DV_LANES) rep(z^-(DV_CH*(L+1)));
+// then rep(z), rep(z^DV_LANES), rep(z^DV_TILE)
+#define DVT_Z (2 * DV_LANES)
+#define DVT_ZL (2 * DV_LANES + 1)
+#define DVT_ZT (2 * DV_LANES + 2)
+#define DVT_N (2 * DV_LANES + 3)
+static int build_div_tab(NttTables& T, const Fr& z_mont, const F29** out, hipStream_t stream) {
+    const FrParams& P = T.fp;
+    std::string key((const char*)z_mont.l, 32);
+    key.push_back('D');
+    auto it = T.pow_tabs.find(key);
+    if (it != T.pow_tabs.end()) {
+        auto pos = std::find(T.pow_order.begin(), T.pow_order.end(), key);
+        if (pos != T.pow_order.end()) { T.pow_order.erase(pos); T.pow_order.push_back(key); }
+        *out = it->second;
+        return PLONK_OK;
     }
+    std::vector<F29> h(DVT_N);
+    Fr zc = z_mont;
+    for (int i = 1; i < DV_CH; i <<= 1) zc = fp_mul(zc, zc, P);                  // z^DV_CH (DV_CH is a power of two)
+    const Fr zci = fp_inv(zc, P);
+    Fr up = fp_one(P), dn = zci;
+    for (int L = 0; L < DV_LANES; L++) {
+        h[L] = host_rep(up, P);
+        h[DV_LANES + L] = host_rep(dn, P);
+        up = fp_mul(up, zc, P);
+        dn = fp_mul(dn, zci, P);
+    }
+    Fr zl = z_mont;
+    for (int i = 1; i < DV_LANES; i <<= 1) zl = fp_mul(zl, zl, P);
+    h[DVT_Z] = host_rep(z_mont, P);
+    h[DVT_ZL] = host_rep(zl, P);
+    h[DVT_ZT] = host_rep(up, P);                                                  // (z^DV_CH)^DV_LANES
+    if (T.pow_order.size() >= POWTAB_CACHE_MAX) {
+        HIP_TRY(hipStreamSynchronize(stream));
+        (void)hipFree(T.pow_tabs[T.pow_order.front()]);
+        T.pow_tabs.erase(T.pow_order.front());
+        T.pow_order.erase(T.pow_order.begin());
+    }
+    F29* d_tab = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_tab, DVT_N * sizeof(F29)));
+    HIP_TRY(hipMemcpyAsync(d_tab, h.data(), h.size() * sizeof(F29), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    T.pow_tabs[key] = d_tab;
+    T.pow_order.push_back(key);
+    *out = d_tab;
+    return PLONK_OK;
+}
+
+// D1: A_t = sum_e c[1 + t*DV_TILE + e] z^e  (canonical Fr, R form)
+__global__ void __launch_bounds__(DV_LANES) poly_div_agg_kernel(const Fr* __restrict__ poly, uint64_t len, const F29* __restrict__ tab, const PowTab pw,
+                                                                Fr* __restrict__ agg, const PoCtx c) {
+    __shared__ uint32_t sh[DV_LANES][9];
+    const F29Params& fp = c.f29;
+    const F29 zl = load_f29(tab + DVT_ZL);
+    const uint64_t base = 1 + (uint64_t)blockIdx.x * DV_TILE + threadIdx.x;
+    F29 acc;
+#pragma unroll
+    for (int l = 0; l < 9; l++) acc.l[l] = 0;
+    bool any = false;
+#pragma unroll
+    for (int k = DV_CH - 1; k >= 0; k--) {
+        const uint64_t i = base + (uint64_t)k * DV_LANES;
+        if (i < len) {
+            const F29 ci = f29_from_sat(load_fr(poly + i));
+            acc = any ? f29_add(f29_mul(acc, zl, fp), ci) : ci;
+            any = true;
+        }
+    }
+    Fr mine = fp_zero<8>();
+    if (any) mine = f29_to_sat(f29_canon(f29_mul(acc, load_f29(pw.t0 + threadIdx.x), fp), fp));       // * z^L (level 0 of the power table: L < 1024)
+    const Fr tot = block_total<OpAdd, DV_LANES>(mine, sh, c);
+    if (threadIdx.x == 0) store_fr(agg + blockIdx.x, tot);
+}
+
+// D2: X_t = A_(t+1) + W X_(t+1), X_(nt-1) = 0, W = z^DV_TILE.  One workgroup; lane l owns the `per` tiles [l*per, (l+1)*per).
+struct DivTopParams {
+    F29 w;             // rep(W)
+    F29 wstep[10];     // rep(W^(per * 2^s)): the lane-level suffix scan's multipliers
 };
+__global__ void __launch_bounds__(DV_TOP) poly_div_top_kernel(const Fr* __restrict__ agg, Fr* __restrict__ carry, uint64_t nt, uint64_t per, const DivTopParams q,
+                                                              const PoCtx c) {
+    __shared__ uint32_t sh[DV_TOP][9];
+    const F29Params& fp = c.f29;
+    const int t = threadIdx.x;
+    const uint64_t lo = (uint64_t)t * per, hi = lo + per < nt ? lo + per : nt;
+    // G_l = sum_{u in run} A_u W^(u - lo)
+    F29 g;
+#pragma unroll
+    for (int l = 0; l < 9; l++) g.l[l] = 0;
+    for (uint64_t u = hi; u > lo; u--) {
+        const F29 a = f29_from_sat(load_fr(agg + u - 1));
+        g = (u == hi) ? a : f29_add(f29_mul(g, q.w, fp), a);
+    }
+    if (hi > lo) { g = f29_mul(g, params_one(fp), fp); }                      // normalised, < 1.36 p
+    // inclusive suffix windows: V_l <- V_l + W^(per*d) V_(l+d)
+    OpMul::to_words(sh[t], g);
+    __syncthreads();
+    int s = 0;
+    for (int d = 1; d < DV_TOP; d <<= 1, s++) {
+        F29 o;
+        const bool on = t + d < DV_TOP;
+        if (on) o = OpMul::from_words(sh[t + d]);
+        __syncthreads();
+        if (on) {
+            g = f29_add(g, f29_mul(o, q.wstep[s], fp));
+            g = f29_mul(g, params_one(fp), fp);                               // keep the window sums normalised
+            OpMul::to_words(sh[t], g);
+        }
+        __syncthreads();
+    }
+    // Y_l = V_(l+1): q just above this lane's run; then down the run
+    F29 x;
+#pragma unroll
+    for (int l = 0; l < 9; l++) x.l[l] = 0;
+    if (t + 1 < DV_TOP) x = OpMul::from_words(sh[t + 1]);
+    for (uint64_t u = hi; u > lo; u--) {                                       // X_(u-1) from X_u ... stored for tile u-1
+        store_fr(carry + u - 1, f29_to_sat(f29_canon(x, fp)));
+        x = f29_mul(f29_add(f29_mul(x, q.w, fp), f29_from_sat(load_fr(agg + u - 1))), params_one(fp), fp);
+    }
+}
+
+// LDS layout of a tile: element e at word e*8 + (e >> 3) — one pad word per DV_CH elements makes both the coalesced (lane = e mod DV_LANES)
+// and the chunked (lane = e / DV_CH) accesses 2 lanes per bank
+__device__ __forceinline__ uint32_t dv_word(uint32_t e) { return e * 8 + (e >> 3); }
+#define DV_LDS_WORDS (DV_TILE * 8 + DV_TILE / 8)
+// D3
+__global__ void __launch_bounds__(DV_LANES) poly_div_apply_kernel(const Fr* __restrict__ poly, uint64_t len, const F29* __restrict__ tab,
+                                                                  const Fr* __restrict__ carry, Fr* __restrict__ out, const PoCtx c) {
+    __shared__ uint32_t tile[DV_LDS_WORDS];
+    __shared__ uint32_t sh[DV_LANES][9];
+    const F29Params& fp = c.f29;
+    const uint32_t L = threadIdx.x;
+    const uint64_t j0 = (uint64_t)blockIdx.x * DV_TILE;                       // outputs j0 + e, coefficients j0 + 1 + e
+    // coalesced loads -> LDS
+#pragma unroll
+    for (int m = 0; m < DV_CH; m++) {
+        const uint32_t e = m * DV_LANES + L;
+        const uint64_t k = j0 + 1 + e;
+        Fr v = fp_zero<8>();
+        if (k < len) v = load_fr(poly + k);
+        uint32_t* w = tile + dv_word(e);
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = v.l[i];
+    }
+    __syncthreads();
+    // this lane's DV_CH consecutive coefficients
+    F29 x[DV_CH];
+#pragma unroll
+    for (int i = 0; i < DV_CH; i++) {
+        const uint32_t* w = tile + dv_word(L * DV_CH + i);
+        Fr v;
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = w[k];
+        x[i] = f29_from_sat(v);
+    }
+    const F29 z = load_f29(tab + DVT_Z);
+    // lane aggregate sum_i x[i] z^i, scaled by z^(DV_CH*L)
+    F29 a = x[DV_CH - 1];
+#pragma unroll
+    for (int i = DV_CH - 2; i >= 0; i--) a = f29_add(f29_mul(a, z, fp), x[i]);
+    const Fr bl = f29_to_sat(f29_canon(f29_mul(a, load_f29(tab + L), fp), fp));
+    // exclusive additive suffix scan over the lanes: S_L = sum_{L' > L} B_L'
+    {
+        const uint32_t r = DV_LANES - 1 - L;                                   // position in the reversed order: a prefix scan there
+        Fr v = bl;
+        OpAdd::to_words(sh[r], v);
+        __syncthreads();
+        for (uint32_t d = 1; d < DV_LANES; d <<= 1) {
+            Fr o;
+            const bool on = r >= d;
+            if (on) o = OpAdd::from_words(sh[r - d]);
+            __syncthreads();
+            if (on) {
+                v = fp_add(o, v, c.fp);
+                OpAdd::to_words(sh[r], v);
+            }
+            __syncthreads();
+        }
+    }
+    const uint32_t r = DV_LANES - 1 - L;
+    F29 u = f29_from_sat(r > 0 ? OpAdd::from_words(sh[r - 1]) : fp_zero<8>());
+    // + z^DV_TILE * X_t, then * z^-(DV_CH*(L+1)):  q at the first index above this lane's chunk
+    u = f29_add(u, f29_mul(f29_from_sat(load_fr(carry + blockIdx.x)), load_f29(tab + DVT_ZT), fp));
+    F29 q = f29_mul(u, load_f29(tab + DV_LANES + L), fp);
+    __syncthreads();                                                          // every lane has read its coefficients: the tile becomes the output
+    // the recurrence down the chunk: q_(j0 + L*DV_CH + i) = x[i] + z * q_(that + 1)
+#pragma unroll
+    for (int i = DV_CH - 1; i >= 0; i--) {
+        q = f29_add(f29_mul(q, z, fp), x[i]);                                  // < 2.4 p, limbs < 2^30
+        F29 qn = q;
+        f29_norm(qn);
+        const Fr v = f29_to_sat(f29_canon_lazy(qn, fp));                       // canonical without a product
+        uint32_t* w = tile + dv_word(L * DV_CH + i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = v.l[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DV_CH; m++) {
+        const uint32_t e = m * DV_LANES + L;
+        const uint64_t j = j0 + e;
+        if (j + 1 < len) {
+            const uint32_t* w = tile + dv_word(e);
+            Fr v;
+#pragma unroll
+            for (int k = 0; k < 8; k++) v.l[k] = w[k];
+            store_fr(out + j, v);
+        }
+    }
+}
 __global__ void __launch_bounds__(256) poly_shift_down_kernel(const Fr* __restrict__ poly, uint64_t len, Fr* __restrict__ out) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i + 1 < len) store_fr(out + i, load_fr(poly + i + 1));
@@ -554,20 +781,33 @@ int poly_div_linear_run(NttTables& T, const void* d_poly, size_t len, const uint
         hipLaunchKernelGGL(poly_shift_down_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, (Fr*)d_out);
         return PLONK_OK;
     }
+    const uint64_t nt = (len - 1 + DV_TILE - 1) / DV_TILE;       // tiles of the len - 1 quotient coefficients
     char* s = (char*)scratch;
-    Fr* S = (Fr*)s; s += align256(len * 32);
-    Fr* btot = (Fr*)s; s += align256(tiles_of(len) * 32);
-    Fr* boff = (Fr*)s;
-    PowTab pz, pzi;
-    int rc = build_pow_tab(T, z, len, &pz, stream);
-    if (!rc) rc = build_pow_tab(T, fp_inv(z, P), len, &pzi, stream);
+    Fr* agg = (Fr*)s; s += align256(nt * 32);
+    Fr* carry = (Fr*)s;
+    const F29* tab = nullptr;
+    PowTab pz;
+    int rc = build_div_tab(T, z, &tab, stream);
+    if (!rc) rc = build_pow_tab(T, z, 1024, &pz, stream);        // level 0 only: z^L, L < DV_LANES
     if (rc) return rc;
     const PoCtx c = make_ctx(T);
+    DivTopParams q;
+    const uint64_t per = (nt + DV_TOP - 1) / DV_TOP;
+    Fr w = z;
+    for (int i = 1; i < DV_TILE; i <<= 1) w = fp_mul(w, w, P);   // z^DV_TILE
+    q.w = host_rep(w, P);
+    Fr ws = fp_one(P), b = w;                                     // W^per by square and multiply
+    for (uint64_t e = per; e; e >>= 1) { if (e & 1) ws = fp_mul(ws, b, P); b = fp_mul(b, b, P); }
+    for (int i = 0; i < 10; i++) { q.wstep[i] = host_rep(ws, P); ws = fp_mul(ws, ws, P); }
     {
-        ProfScope ps("poly_scale_kernel", stream);
-        hipLaunchKernelGGL(poly_scale_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, pz, S, c);
+        ProfScope ps("poly_div_kernels", stream);
+        hipLaunchKernelGGL(poly_div_agg_kernel, dim3((uint32_t)nt), dim3(DV_LANES), 0, stream, (const Fr*)d_poly, (uint64_t)len, tab, pz, agg, c);
+        hipLaunchKernelGGL(poly_div_top_kernel, dim3(1), dim3(DV_TOP), 0, stream, (const Fr*)agg, carry, nt, per, q, c);
+        hipLaunchKernelGGL(poly_div_apply_kernel, dim3((uint32_t)nt), dim3(DV_LANES), 0, stream, (const Fr*)d_poly, (uint64_t)len, tab, (const Fr*)carry, (Fr*)d_out, c);
     }
-    return scan_run<OpAdd>(S, len, true, true, btot, boff, (Fr*)nullptr, c, EpiDivFinal{pzi, (Fr*)d_out}, "poly_div_scan", stream);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "poly_div_linear launch: %s", hipGetErrorString(e));
+    return PLONK_OK;
 }
 
 // ---------------------------------------------------------------------------------------------- arbitrary cosets

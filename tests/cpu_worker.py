@@ -212,6 +212,29 @@ class CpuWorker:
         idx = self.read_bytes(d_idx, 5 * n * 8).view(np.uint64)
         self._fr(d_out, n)[:] = O.perm_product(self.curve, w5, self._fr(d_id, 5 * n).copy(), idx, beta, gamma)
 
+    def perm_product_range_dev(self, wires, d_id, d_idx, beta, gamma, n, first, count, d_out):
+        """out[t] = prod over gates [first, first + t) of the oracle's ratios: the slice of the product vector divided by its first value"""
+        w5 = np.stack([self._fr(p, n).copy() for p in wires])
+        idx = self.read_bytes(d_idx, 5 * n * 8).view(np.uint64)
+        z = O.perm_product(self.curve, w5, self._fr(d_id, 5 * n).copy(), idx, beta, gamma)
+        if first + count > n:
+            raise ValueError("gate range")
+        ext = z[first:first + count]
+        inv0 = self._op("inv", z[first:first + 1])
+        self._fr(d_out, count)[:] = self._op("mul", ext, np.tile(inv0, (count, 1)))
+
+    def class_interleave_dev(self, d_in, classes, size, reverse, scale, d_out, in_stride=0):
+        stride = in_stride or size
+        src = (size - np.arange(size)) % size if reverse else np.arange(size)
+        cols = [self._fr(d_in + s * stride * 32, size)[src] for s in range(classes)]
+        v = np.stack(cols, axis=1).reshape(size * classes, 4)
+        if scale is not None:
+            v = self._op("mul", v, np.tile(np.ascontiguousarray(scale, dtype=np.uint64).reshape(1, 4), (size * classes, 1)))
+        self._fr(d_out, size * classes)[:] = v
+
+    def memcpy_d2d_async(self, dst, src, nbytes):
+        self.memcpy_d2d(dst, src, nbytes)
+
     def poly_eval_dev(self, d_poly, length, point):
         return O.poly_eval(self.curve, self._fr(d_poly, length).copy(), point)
 
