@@ -121,7 +121,17 @@ class Bench:
             for x, uid in zip(with_comm, ids):
                 x.comm_init(uid, self.rank, self.world)
             r_, w_, v_ = self.w.comm_info()
-            self.rccl_info = {"rank0_reports_world": w_, "rccl_version": v_, "communicators_per_rank": len(with_comm)}
+            # what EVERY rank's communicator reports (plonk_comm_info = ncclCommUserRank / ncclCommCount), gathered once through the launcher: the first
+            # run on more than one GPU shows at a glance whether each process got its own device and the communicator spans them all
+            seen = [None] * self.world
+            if self.world > 1:
+                dist.all_gather_object(seen, (self.rank, r_, w_, self.local_rank))
+            else:
+                seen = [(self.rank, r_, w_, self.local_rank)]
+            self.rccl_info = {"rank0_reports_world": w_, "rccl_version": v_, "communicators_per_rank": len(with_comm),
+                              "ranks_seen": sorted(s_[1] for s_ in seen), "world_seen_by_every_rank": sorted({s_[2] for s_ in seen}),
+                              "devices": [s_[3] for s_ in sorted(seen)],
+                              "order_check": os.environ.get("PLONK_COMM_CHECK_ORDER", "0") not in ("", "0")}
         self.provers = [RankProver(x, self.rank, self.S, exchange=self.noop_exchange, transport=self.transport) for x in self.workers[:self.n_lanes]]
         # the provers of the STEP: their own contexts under --overlap-phases on, else the two above (the legs after the headline always use those)
         self.step_provers = ([RankProver(x, self.rank, self.S, exchange=self.noop_exchange, transport=self.transport) for x in self.step_workers]

@@ -4,6 +4,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <vector>
 
 #include "constants.h"
 #include "ec.hpp"
@@ -84,9 +86,28 @@ struct plonk_ctx {
     // small free-list of exchange buffers so that back-to-back transforms do not hipMalloc/hipFree
     std::vector<std::pair<size_t, void*>> pool;
     PlonkComm* comm = nullptr;                  // RCCL communicator (plonk_comm_init), owned
+    int comm_ordinal = 0;                       // this communicator's place among the device's communicators, in creation order (comm_order_check)
     int check_bases = 1;                        // init: every base must be a curve point (option "check_bases")
     unsigned long long* d_bad = nullptr;        // two words for that check's verdict
 };
+
+// state of the collective order check (comm_order_check, further down)
+namespace {
+struct DeviceCollectives {
+    plonk_ctx* control = nullptr;        // the context whose communicator carries the tags (the first created on this device)
+    int created = 0;                     // communicators created so far = the next one's ordinal
+    uint64_t seq = 0;                    // collectives entered
+};
+std::mutex g_coll_mu;
+DeviceCollectives g_coll[64];
+int g_comm_check = -1;                   // -1: not read yet (PLONK_COMM_CHECK_ORDER)
+bool comm_check_on() {
+    if (g_comm_check < 0) { const char* e = getenv("PLONK_COMM_CHECK_ORDER"); g_comm_check = (e && *e && *e != '0') ? 1 : 0; }
+    return g_comm_check == 1;
+}
+const char* coll_name(uint64_t k) { return k == 1 ? "all-to-all" : k == 2 ? "all-gather" : k == 3 ? "all-gather (host)" : "?"; }
+}  // namespace
+static void comm_forget(plonk_ctx* ctx);
 
 static int pool_get(plonk_ctx* ctx, size_t bytes, void** out) {
     for (size_t i = 0; i < ctx->pool.size(); i++)
@@ -185,6 +206,7 @@ extern "C" void plonk_destroy(plonk_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (auto& kv : ctx->tasks) free_task(ctx, kv.second);
     for (auto& pb : ctx->pool) (void)hipFree(pb.second);
+    comm_forget(ctx);
     comm_destroy(ctx->comm);
     ntt_tables_destroy(ctx->tables);
     if (ctx->d_bases) (void)hipFree(ctx->d_bases);
@@ -209,6 +231,7 @@ extern "C" int plonk_sync(plonk_ctx* ctx) {
 extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) {
     if (!ctx || !key) return plonk_fail(PLONK_ERR_ARG, "plonk_set_option: null");
     if (!strcmp(key, "msm_window")) { ctx->msm_window = (int)value; return PLONK_OK; }
+    if (!strcmp(key, "comm_check_order")) { g_comm_check = value ? 1 : 0; return PLONK_OK; }          // PROCESS-wide (every rank must agree); env PLONK_COMM_CHECK_ORDER
     if (!strcmp(key, "check_bases")) { ctx->check_bases = value ? 1 : 0; return PLONK_OK; }            // default 1; takes effect at the next init
     if (!strcmp(key, "msm_precompute")) { ctx->msm_precompute = (int)value; return PLONK_OK; }      // takes effect at the next init
     if (!strcmp(key, "msm_table_c")) {                                                                // takes effect at the next init
@@ -624,15 +647,64 @@ extern "C" int plonk_comm_unique_id(void* out_id) {
     if (!out_id) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_unique_id: null");
     return comm_unique_id(out_id);
 }
+// ---- the ranks must enter their collectives in the SAME ORDER (comm_rccl.hip: one total order per device).  A host that does not — two tasks
+// finished in different orders on two ranks, a lane taken from a different queue — deadlocks inside RCCL, every GPU at 100 %, no message.
+// PLONK_COMM_CHECK_ORDER=1 (every rank; or option "comm_check_order") makes that an error instead: before each collective the ranks
+// all-gather a 24-byte tag — (ordinal of the communicator among the device's communicators in creation order, kind, bytes, the device's
+// collective count) — over the device's FIRST communicator, which every rank creates first and which therefore always lines up, compare
+// on the host, and every rank returns PLONK_ERR_STATE when the tags differ.  A host round trip per collective: a diagnostic for the first
+// runs on a new machine (tests/test_gpu_multirank.py), not a production setting.
+static int comm_order_check(plonk_ctx* ctx, uint64_t kind, uint64_t bytes) {
+    if (!comm_check_on() || ctx->device < 0 || ctx->device >= 64) return PLONK_OK;
+    plonk_ctx* control;
+    uint64_t tag[3];
+    {
+        std::lock_guard<std::mutex> g(g_coll_mu);
+        DeviceCollectives& d = g_coll[ctx->device];
+        control = d.control;
+        tag[0] = ((uint64_t)(uint32_t)ctx->comm_ordinal << 8) | kind;
+        tag[1] = bytes;
+        tag[2] = d.seq++;
+    }
+    if (!control || !control->comm) return plonk_fail(PLONK_ERR_STATE, "collective order check: the device's first communicator is gone");
+    const int world = comm_world(control->comm);
+    if (comm_world(ctx->comm) != world) return PLONK_OK;          // communicators of different sizes: nothing to line up against
+    std::vector<uint64_t> all((size_t)3 * world);
+    int rc = comm_allgather_host(control->comm, tag, sizeof tag, all.data(), control->stream);
+    if (rc) return rc;
+    for (int r = 0; r < world; r++)
+        if (memcmp(&all[(size_t)3 * r], tag, sizeof tag) != 0)
+            return plonk_fail(PLONK_ERR_STATE, "collective #%llu of device %d: this rank enters an %s of its communicator %llu (%llu bytes), rank %d an %s of its "
+                              "communicator %llu (%llu bytes, its collective #%llu): the ranks issue their collectives in different orders — refused instead of "
+                              "deadlocking inside RCCL", (unsigned long long)tag[2], ctx->device, coll_name(tag[0] & 0xff), (unsigned long long)(tag[0] >> 8),
+                              (unsigned long long)tag[1], r, coll_name(all[(size_t)3 * r] & 0xff), (unsigned long long)(all[(size_t)3 * r] >> 8),
+                              (unsigned long long)all[(size_t)3 * r + 1], (unsigned long long)all[(size_t)3 * r + 2]);
+    return PLONK_OK;
+}
+
 extern "C" int plonk_comm_init(plonk_ctx* ctx, const void* id, int rank, int world) {
     CHECK_CTX(ctx);
     if (!id) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_init: null id");
     if (ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_init: the context already has a communicator");
-    return comm_create(&ctx->comm, id, rank, world, ctx->device);
+    int rc = comm_create(&ctx->comm, id, rank, world, ctx->device);
+    if (!rc && ctx->device >= 0 && ctx->device < 64) {
+        std::lock_guard<std::mutex> g(g_coll_mu);
+        DeviceCollectives& d = g_coll[ctx->device];
+        ctx->comm_ordinal = d.created++;
+        if (!d.control) d.control = ctx;
+    }
+    return rc;
+}
+static void comm_forget(plonk_ctx* ctx) {
+    if (ctx->device < 0 || ctx->device >= 64) return;
+    std::lock_guard<std::mutex> g(g_coll_mu);
+    DeviceCollectives& d = g_coll[ctx->device];
+    if (d.control == ctx) d.control = nullptr;
 }
 extern "C" int plonk_comm_destroy(plonk_ctx* ctx) {
     CHECK_CTX(ctx);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    comm_forget(ctx);
     comm_destroy(ctx->comm);
     ctx->comm = nullptr;
     return PLONK_OK;
@@ -660,24 +732,28 @@ extern "C" int plonk_exchange_rccl(void* user, const void* send, void* recv, siz
     plonk_ctx* ctx = (plonk_ctx*)user;
     if (!ctx || !ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_exchange_rccl: no communicator (plonk_comm_init)");
     if (n_ranks != comm_world(ctx->comm)) return plonk_fail(PLONK_ERR_ARG, "plonk_exchange_rccl: %d blocks for %d ranks", n_ranks, comm_world(ctx->comm));
+    if (int rc = comm_order_check(ctx, 1, bytes_per_peer)) return rc;
     return comm_alltoall(ctx->comm, send, recv, bytes_per_peer, (hipStream_t)stream);
 }
 extern "C" int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer) {
     CHECK_CTX(ctx);
     if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_alltoall_dev: no communicator (plonk_comm_init)");
     if (!d_send || !d_recv) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_alltoall_dev: null");
+    if (int rc = comm_order_check(ctx, 1, bytes_per_peer)) return rc;
     return comm_alltoall(ctx->comm, d_send, d_recv, bytes_per_peer, ctx->stream);
 }
 extern "C" int plonk_comm_allgather_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes) {
     CHECK_CTX(ctx);
     if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_allgather_dev: no communicator (plonk_comm_init)");
     if (!d_send || !d_recv) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_allgather_dev: null");
+    if (int rc = comm_order_check(ctx, 2, bytes)) return rc;
     return comm_allgather(ctx->comm, d_send, d_recv, bytes, ctx->stream);
 }
 extern "C" int plonk_comm_allgather_host(plonk_ctx* ctx, const void* in, size_t bytes, void* out) {
     CHECK_CTX(ctx);
     if (!ctx->comm) return plonk_fail(PLONK_ERR_STATE, "plonk_comm_allgather_host: no communicator (plonk_comm_init)");
     if (!in || !out || !bytes) return plonk_fail(PLONK_ERR_ARG, "plonk_comm_allgather_host: null / empty");
+    if (int rc = comm_order_check(ctx, 3, bytes)) return rc;
     return comm_allgather_host(ctx->comm, in, bytes, out, ctx->stream);
 }
 

@@ -90,7 +90,13 @@ int plonk_exchange_standin(void* user, const void* send, void* recv, size_t byte
  * ONE host thread — the first that issues one on that device owns it until the device's last communicator is destroyed; a call from
  * another thread returns PLONK_ERR_STATE instead of risking a cross-rank deadlock (two threads cannot promise the same issue order on
  * every rank).  A host whose runtime migrates one logical task between OS threads sets the environment variable
- * PLONK_COMM_ANY_THREAD=1 and serialises its collectives itself. */
+ * PLONK_COMM_ANY_THREAD=1 and serialises its collectives itself.
+ * ORDER CHECK (diagnostic): with PLONK_COMM_CHECK_ORDER=1 in every rank's environment (or plonk_set_option(ctx, "comm_check_order", 1) on
+ * every rank: the switch is process-wide) each collective is preceded by an all-gather of a 24-byte tag — the communicator's ordinal among
+ * the device's communicators in creation order, the kind of collective, its byte count, the device's collective count — over the device's
+ * FIRST communicator, and every rank returns PLONK_ERR_STATE when the tags differ: ranks that enter their collectives in different orders
+ * (two tasks finished in different orders, a different kind or size on one rank) get an error naming both sides instead of a silent
+ * deadlock inside RCCL.  Costs a host round trip per collective: for the first runs on a new machine, not for production. */
 int plonk_comm_alltoall_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes_per_peer);
 int plonk_comm_allgather_dev(plonk_ctx* ctx, const void* d_send, void* d_recv, size_t bytes);
 /* host buffers (partial commitment points, 96 / 144 B each): out receives world * bytes.  Synchronises. */

@@ -61,13 +61,22 @@ def test_coset_eval_argument_checks(gpu_workers, oracle):
     from distributed_plonk_amd._ffi import PlonkError
     w = gpu_workers("bn254")
     P, f, g, _ = _consts(oracle, 0, 5)
-    d = w.alloc(64 * 32)
+    d = w.alloc(80 * 32)
     o = w.alloc(64 * 32)
     one = P.fr_to_limbs(f, 1)
     with pytest.raises(PlonkError):
         w.coset_eval_dev(d.ptr, 8, 24, one, o.ptr)              # not a power of two
     with pytest.raises(PlonkError):
-        w.coset_eval_dev(d.ptr, 64, 8, one, o.ptr)              # more than 4x folding
+        w.coset_eval_dev(d.ptr, 65, 8, one, o.ptr)              # more than 8x folding (NTT_MAX_FOLD)
+    # exactly 8x is what the residue-class iFFT of an 8-rank prover needs: 64 coefficients on an 8-point coset = the oracle's value of the folded polynomial
+    h = 3 * g % f.p
+    coeffs = oracle.rand_fr(0, 91, 64)
+    d.upload(coeffs)
+    w.coset_eval_dev(d.ptr, 64, 8, P.fr_to_limbs(f, h), o.ptr)
+    w8 = f.root_of_unity(8)
+    for k in (0, 3, 7):
+        want = oracle.poly_eval(0, coeffs, P.fr_to_limbs(f, h * pow(w8, k, f.p) % f.p))
+        assert np.array_equal(o.download((8, 4))[k], want), k
     with pytest.raises(PlonkError):
         w.coset_interp_dev(d.ptr, 16, np.zeros(4, dtype=np.uint64), one, 0, 16, o.ptr)      # zero shift
     d.free(); o.free()

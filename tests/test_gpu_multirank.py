@@ -250,3 +250,66 @@ def _class_rank(rank, world, port, q, curve, cid, log_n):
 @pytest.mark.parametrize("curve,cid,log_n", [("bn254", 0, 8), ("bls12_381", 1, 6)])
 def test_class_prover_with_sharded_key_over_rccl(world, curve, cid, log_n):
     _spawn(_class_rank, world, curve, cid, log_n)
+
+
+# ------------------------------------------------------------------------------------------------ collectives entered in different orders
+def _order_rank(rank, world, port, q):
+    """Two contexts (two communicators, created in the same order everywhere) per rank.  With the order check on, a collective that the ranks
+    enter on DIFFERENT communicators — the cross-communicator deadlock of comm_rccl.hip's header — is PLONK_ERR_STATE on every rank."""
+    try:
+        dist = _setup(rank, world, port)
+        from distributed_plonk_amd._ffi import PlonkError
+        from distributed_plonk_amd.worker import PlonkWorker
+        a, b = (PlonkWorker(me=rank, device=rank, curve="bn254") for _ in range(2))
+        try:
+            _join(dist, [a, b], rank, world)
+            a.set_option("comm_check_order", 1)                       # process-wide; every rank sets it
+            msgs = []
+            x = np.arange(12, dtype=np.uint64) + 100 * rank
+
+            def gathered_ok(w):
+                got = w.comm_allgather_host(x, world)
+                return all(np.array_equal(got[r], np.arange(12, dtype=np.uint64) + 100 * r) for r in range(world))
+
+            if not (gathered_ok(a) and gathered_ok(b)):               # same order everywhere: the check is transparent
+                msgs.append("ordered collectives")
+            if world > 1:
+                first = a if rank % 2 == 0 else b                     # even ranks enter A's collective, odd ranks B's
+                try:
+                    first.comm_allgather_host(x, world)
+                    msgs.append("collectives in different orders were not refused")
+                except PlonkError as ex:
+                    if ex.code != -4 or "different orders" not in str(ex):
+                        msgs.append(f"wrong error: {ex}")
+                # a device all-gather against a host one on the SAME communicator is a mismatch too (kind and bytes are part of the tag)
+                d_s, d_r = a.alloc(64), a.alloc(64 * world)
+                try:
+                    if rank == 0:
+                        a.comm_allgather_dev(d_s.ptr, d_r.ptr, 64)
+                    else:
+                        a.comm_allgather_host(x, world)
+                    msgs.append("different collectives on one communicator were not refused")
+                except PlonkError as ex:
+                    if ex.code != -4:
+                        msgs.append(f"wrong error: {ex}")
+                d_s.free(); d_r.free()
+                dist.barrier()
+                if not (gathered_ok(a) and gathered_ok(b)):           # nothing was left half-issued: the communicators still work
+                    msgs.append("collectives after a refusal")
+            q.put((rank, not msgs, "; ".join(msgs)))
+        finally:
+            for w in (a, b):
+                w.comm_destroy()
+                w.close()
+            dist.destroy_process_group()
+    except BaseException:      # noqa: BLE001
+        import traceback
+        q.put((rank, False, traceback.format_exc()[-1500:]))
+        raise
+
+
+@pytest.mark.parametrize("world", _world_sizes())
+def test_collectives_entered_in_different_orders_are_refused_not_deadlocked(world):
+    """the first run on more than one GPU must diagnose itself.  PLONK_COMM_CHECK_ORDER=1 / option "comm_check_order":
+    before every collective the ranks compare (communicator ordinal, kind, bytes, count) over the device's first communicator."""
+    _spawn(_order_rank, world, timeout=300)

@@ -90,6 +90,9 @@ def test_rank_programs_as_processes_world_2_and_4(emu_env):
     on every rank and the verifier on rank 0 — one process per rank through plonk_comm_*."""
     out = _pytest(emu_env, ["tests/test_gpu_multirank.py"], k="bn254 and (2] or 9-4])", extra_env={"HIPEMU_THREADS": "2"})
     assert "3 passed" in out, out
+    # collectives entered on different communicators / of different kinds on different ranks: refused on every rank, nothing hangs (world 2 and 4)
+    out = _pytest(emu_env, ["tests/test_gpu_multirank.py"], k="different_orders and (2] or 4])", extra_env={"HIPEMU_THREADS": "2"}, timeout=600)
+    assert "2 passed" in out, out
 
 
 def test_distributed_transform_steps_and_coset_classes(emu_env):
@@ -183,6 +186,7 @@ def test_bench_program_multi_rank_with_phases_overlapped(emu_env):
     from conftest import free_port
     d = _bench_dry_run(emu_env, 2, free_port(), ("--overlap-phases", "on", "--no-class-prover", "--no-poly-parallel"))
     assert d["emulated"] is True and d["config"]["phase_overlap"] is True and d["config"]["rccl"]["communicators_per_rank"] == 4
+    assert d["config"]["rccl"]["ranks_seen"] == [0, 1] and d["config"]["rccl"]["world_seen_by_every_rank"] == [2], d["config"]["rccl"]
     assert d["verified"] is True and all(d["verification"].values()), d["verification"]
     assert d.get("aborted_optional_leg") is None and "error" not in (d["other_scheme"] or {}), d
 
