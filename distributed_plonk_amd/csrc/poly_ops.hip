@@ -648,7 +648,7 @@ __global__ void __launch_bounds__(DV_TOP) poly_div_top_kernel(const Fr* __restri
         const F29 a = f29_from_sat(load_fr(agg + u - 1));
         g = (u == hi) ? a : f29_add(f29_mul(g, q.w, fp), a);
     }
-    if (hi > lo) { g = f29_mul(g, params_one(fp), fp); }                      // normalised, < 1.36 p
+    f29_norm(g);                                                              // < 2.4 p
     // inclusive suffix windows: V_l <- V_l + W^(per*d) V_(l+d)
     OpMul::to_words(sh[t], g);
     __syncthreads();
@@ -659,8 +659,8 @@ __global__ void __launch_bounds__(DV_TOP) poly_div_top_kernel(const Fr* __restri
         if (on) o = OpMul::from_words(sh[t + d]);
         __syncthreads();
         if (on) {
-            g = f29_add(g, f29_mul(o, q.wstep[s], fp));
-            g = f29_mul(g, params_one(fp), fp);                               // keep the window sums normalised
+            g = f29_add(g, f29_mul(o, q.wstep[s], fp));                       // + < 1.36 p per step: < 16 p after the ten steps, inside f29_mul's range
+            f29_norm(g);
             OpMul::to_words(sh[t], g);
         }
         __syncthreads();
@@ -671,8 +671,9 @@ __global__ void __launch_bounds__(DV_TOP) poly_div_top_kernel(const Fr* __restri
     for (int l = 0; l < 9; l++) x.l[l] = 0;
     if (t + 1 < DV_TOP) x = OpMul::from_words(sh[t + 1]);
     for (uint64_t u = hi; u > lo; u--) {                                       // X_(u-1) from X_u ... stored for tile u-1
-        store_fr(carry + u - 1, f29_to_sat(f29_canon(x, fp)));
-        x = f29_mul(f29_add(f29_mul(x, q.w, fp), f29_from_sat(load_fr(agg + u - 1))), params_one(fp), fp);
+        store_fr(carry + u - 1, f29_to_sat(f29_canon_lazy(x, fp)));           // x normalised, < 16 p
+        x = f29_add(f29_mul(x, q.w, fp), f29_from_sat(load_fr(agg + u - 1)));  // < 2.4 p
+        f29_norm(x);
     }
 }
 

@@ -282,6 +282,137 @@ __device__ __forceinline__ void quotient_point_compact(const QuotParams& P, cons
 #undef QFENCE
 }
 
+// The SPLIT formulation (round 5; option quotient_fuse = 8): the compact point cut in two kernels of about half the code
+// each (llvm-readelf: see profiles/r05_quotient_split.txt), so that either fits the 64 KiB instruction cache two CUs share with room to
+// spare: quotient_gate_kernel (13 selectors, 5 wires, pub_input -> gate / Z_H, 32 products, stored to `out`) and quotient_perm_kernel (5 wires,
+// 5 sigmas, z, z(wx), 1/(x-1), the partial -> out in place, 24 products).  Same products, same lazy classes, same result bits; the price is the
+// partial's round trip and a second read of the wires: 34 instead of 28 32-byte accesses per point.
+__device__ __forceinline__ void quotient_point_gate(const QuotParams& P, const uint64_t i) {
+    // Operand loads are issued ONE PRODUCT AHEAD of their use (raw 256-bit values, 8 VGPRs each, converted at the use) with a scheduling
+    // barrier behind every batch of loads, so that no product waits for the load in front of it.  The kernel is bound by VALU issue either way
+    // (round 4 counters: 12.5 k VALU instructions per point = 98-100 % of the launch's busy cycles): the prefetch is worth what the lost
+    // scratch traffic is, no more.
+    const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
+    const F29Params& fp = P.fp;
+#define QLOAD(ptr) load_fr((ptr) + i)
+#define QFENCE() __builtin_amdgcn_sched_barrier(0)
+    Fr ra = QLOAD(P.wire[0]), rb = QLOAD(P.wire[1]), rs0 = QLOAD(P.sel[0]), rs1 = QLOAD(P.sel[1]);
+    QFENCE();
+    F29 abcde;
+    LazySum g;
+    {
+        const F29 a = f29_from_sat(ra), b = f29_from_sat(rb);
+        Fr rc = QLOAD(P.wire[2]), rs2 = QLOAD(P.sel[2]);
+        QFENCE();
+        LazySum t1;                                                          // depth 1: * R * 2^-5
+        t1.init(f29_mul(f29_from_sat(rs0), a, fp));
+        Fr rd = QLOAD(P.wire[3]), rs3 = QLOAD(P.sel[3]);
+        QFENCE();
+        t1.add(f29_mul(f29_from_sat(rs1), b, fp));
+        const F29 c = f29_from_sat(rc);
+        Fr re = QLOAD(P.wire[4]), rs10 = QLOAD(P.sel[10]);
+        QFENCE();
+        t1.add(f29_mul(f29_from_sat(rs2), c, fp));
+        const F29 d = f29_from_sat(rd);
+        Fr rs4 = QLOAD(P.sel[4]);
+        QFENCE();
+        t1.add(f29_mul(f29_from_sat(rs3), d, fp));
+        const F29 e = f29_from_sat(re);
+        Fr rs5 = QLOAD(P.sel[5]);
+        QFENCE();
+        F29 s1 = f29_sub2p(t1.get(), f29_mul(f29_from_sat(rs10), e, fp), fp);  // - q_o * e
+        f29_norm(s1);
+        Fr rs11 = QLOAD(P.sel[11]), rpi = QLOAD(P.pi);
+        QFENCE();
+        const F29 g1 = f29_mul(s1, P.fix5, fp);
+        g.init(f29_from_sat(rs11));                                          // q_c
+        g.add(f29_from_sat(rpi));                                            // + pub_input
+        g.add(g1);
+        QFENCE();
+        const F29 ab = f29_mul(a, b, fp), cd = f29_mul(c, d, fp);            // * R * 2^-5
+        Fr rs12 = QLOAD(P.sel[12]);
+        QFENCE();
+        F29 s2 = f29_add(f29_mul(f29_from_sat(rs4), ab, fp), f29_mul(f29_from_sat(rs5), cd, fp));     // depth 2: * R * 2^-10
+        f29_norm(s2);
+        g.add(f29_mul(s2, P.fix10, fp));
+        QFENCE();
+        abcde = f29_mul(f29_mul(f29_mul(ab, cd, fp), e, fp), f29_from_sat(rs12), fp);       // q_ecc * ab * cd * e : depth 5, * R * 2^-25
+    }
+    QFENCE();
+    {
+        F29 t3 = abcde;
+        Fr rw = QLOAD(P.wire[0]), rs = QLOAD(P.sel[6]);
+#pragma unroll 1
+        for (int q = 0; q < 4; q++) {                                        // + q_hash[q] * w_q^5
+            const F29 w = f29_from_sat(rw), sq = f29_from_sat(rs);
+            const int qn = (q + 1) & 3;                                      // the last iteration re-reads wire 0 / q_hash[0]: harmless
+            rw = QLOAD(P.wire[qn]);
+            rs = QLOAD(P.sel[6 + qn]);
+            QFENCE();
+            t3 = f29_add(t3, f29_mul(sq, f29_mul(f29_sqr(f29_sqr(w, fp), fp), w, fp), fp));
+            f29_norm(t3);                                                    // at most five normalised values: < 6.8 p
+        }
+        g.add(f29_mul(t3, P.fix25, fp));
+    }
+    QFENCE();
+    const F29 gate = g.get();                                                // R form, < 6.2 p
+    const uint32_t ci = (uint32_t)(j & (P.ratio - 1));
+    store_fr(P.out + i, f29_to_sat(f29_canon(f29_mul(gate, P.zh_inv_rp[ci], fp), fp)));    // gate / Z_H(x): the partial the second kernel completes in place
+#undef QLOAD
+#undef QFENCE
+}
+__device__ __forceinline__ void quotient_point_perm(const QuotParams& P, const uint64_t i) {
+    // Operand loads are issued ONE PRODUCT AHEAD of their use (raw 256-bit values, 8 VGPRs each, converted at the use) with a scheduling
+    // barrier behind every batch of loads, so that no product waits for the load in front of it.  The kernel is bound by VALU issue either way
+    // (round 4 counters: 12.5 k VALU instructions per point = 98-100 % of the launch's busy cycles): the prefetch is worth what the lost
+    // scratch traffic is, no more.
+    const uint64_t j = (uint64_t)P.cls_offset + (uint64_t)P.cls_stride * i;  // global point index
+    const F29Params& fp = P.fp;
+#define QLOAD(ptr) load_fr((ptr) + i)
+#define QFENCE() __builtin_amdgcn_sched_barrier(0)
+    // ---- permutation argument (:479-495): both products carry 2^-25
+    Fr rz = QLOAD(P.z), rzn = load_fr(P.z + ((i + P.ratio / P.cls_stride) & (P.m_local - 1)));          // z(x), z(w x): point j + ratio, same class
+    Fr rw = QLOAD(P.wire[0]), rsg = QLOAD(P.sig[0]);
+    QFENCE();
+    const uint64_t E = j << P.x_shift, mask = ((uint64_t)1 << P.lt) - 1;
+    const F29 x = f29_mul(load_f29(P.x_lo + (E & mask)), load_f29(P.x_hi + ((E >> P.lt) & mask)), fp);       // x * 2^261
+    const F29 zc = f29_from_sat(rz);
+    F29 acc1 = zc, acc2 = f29_from_sat(rzn);
+#pragma unroll 1
+    for (int q = 0; q < 5; q++) {
+        const F29 t = f29_add(f29_from_sat(rw), P.gamma_r);                              // limbs < 2^30
+        const F29 sg = f29_from_sat(rsg);
+        const int qn = q < 4 ? q + 1 : 0;
+        rw = QLOAD(P.wire[qn]);
+        rsg = QLOAD(P.sig[qn]);
+        QFENCE();
+        const F29 u = f29_add(t, f29_mul(x, P.kbeta_r[q], fp));                          // w + gamma + k_j x beta   (< 3.4 p)
+        const F29 v = f29_add(t, f29_mul(sg, P.beta_c, fp));                             // w + gamma + sigma_j beta
+        acc1 = f29_mul(u, acc1, fp);
+        acc2 = f29_mul(v, acc2, fp);
+    }
+    Fr rinv = QLOAD(P.inv_xm1);
+    QFENCE();
+    F29 diff = f29_sub2p(acc1, acc2, fp);
+    f29_norm(diff);                                                                      // (acc1 - acc2) * R * 2^-25, < 3.4 p
+
+    // ---- 1/Z_H(x) * (gate + alpha * (acc1 - acc2)) + alpha^2/n * (z(x) - 1)/(x - 1)   (:497-503, :372-379)
+    F29 zm1 = f29_sub2p(zc, P.one_r, fp);
+    f29_norm(zm1);
+    const uint32_t ci = (uint32_t)(j & (P.ratio - 1));
+    Fr rpart = QLOAD(P.out);                                                             // gate / Z_H(x), written by quotient_gate_kernel
+    QFENCE();
+    LazySum r;
+    r.init(f29_from_sat(rpart));
+    r.add(f29_mul(diff, P.zh_alpha_25[ci], fp));
+    r.add(f29_mul(f29_mul(zm1, f29_from_sat(rinv), fp), P.a2n_c, fp));
+    F29 out = r.get();                                                                   // < 3.8 p
+    out = f29_canon_lazy(out, fp);
+    store_fr(P.out + i, f29_to_sat(out));
+#undef QLOAD
+#undef QFENCE
+}
+
 // FUSE = 1: one Montgomery reduction per product (60 of them).  FUSE = 2 / 3: the twelve selector * monomial terms of the gate
 // equation and the final combination are taken two / three at a time with ONE reduction per group (f29_dot2 / f29_dot3): 54 / 50
 // reductions for the same 60 limb products, at the price of 4 / 6 operands alive per group.
@@ -410,6 +541,14 @@ __global__ void __launch_bounds__(256) quotient_evals_kernel_c(const QuotParams 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) quotient_evals_kernel_c4(const QuotParams P) {    // the same at four waves per SIMD (128 VGPRs)
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < P.m_local) quotient_point_compact(P, i);
+}
+__global__ void __launch_bounds__(256) quotient_gate_kernel(const QuotParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.m_local) quotient_point_gate(P, i);
+}
+__global__ void __launch_bounds__(256) quotient_perm_kernel(const QuotParams P) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.m_local) quotient_point_perm(P, i);
 }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_f1(const QuotParams P) { quotient_evals_body<1>(P); }
 __global__ void __launch_bounds__(256) quotient_evals_kernel_f2(const QuotParams P) { quotient_evals_body<2>(P); }
@@ -561,7 +700,7 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.out = (Fr*)d_out;
     {
         ProfScope ps("quotient_evals_kernel", stream);
-        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 7) ? T.quotient_fuse : 6;
+        const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 8) ? T.quotient_fuse : 6;
         const dim3 grid((uint32_t)((m_local + 255) / 256));
         if (fuse == 1) hipLaunchKernelGGL(quotient_evals_kernel_f1, grid, dim3(256), 0, stream, q);
         else if (fuse == 2) hipLaunchKernelGGL(quotient_evals_kernel_f2, grid, dim3(256), 0, stream, q);
@@ -570,6 +709,10 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
         else if (fuse == 5) hipLaunchKernelGGL(quotient_evals_kernel_loop, dim3((uint32_t)((m_local + 256 * QUOT_LOOP_PTS - 1) / (256 * QUOT_LOOP_PTS))), dim3(256), 0, stream, q);
         else if (fuse == 6) hipLaunchKernelGGL(quotient_evals_kernel_c, grid, dim3(256), 0, stream, q);
         else if (fuse == 7) hipLaunchKernelGGL(quotient_evals_kernel_c4, grid, dim3(256), 0, stream, q);
+        else if (fuse == 8) {
+            hipLaunchKernelGGL(quotient_gate_kernel, grid, dim3(256), 0, stream, q);
+            hipLaunchKernelGGL(quotient_perm_kernel, grid, dim3(256), 0, stream, q);
+        }
         else hipLaunchKernelGGL(quotient_evals_kernel, grid, dim3(256), 0, stream, q);
     }
     hipError_t e = hipGetLastError();

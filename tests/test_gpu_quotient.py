@@ -54,7 +54,7 @@ def test_quotient_evals_structured_inputs(gpu_workers, oracle):
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 7, 8])
 def test_quotient_kernel_variants_agree_with_oracle(gpu_workers, oracle, curve, cid, variant):
     """The experimental formulations kept behind the `quotient_fuse` option (lifted wires with 1 / 2 / 3 products per Montgomery
     reduction, and the unlifted kernel at an uncapped register budget) compute the same values as the default kernel, bit for bit,
