@@ -249,10 +249,24 @@ __global__ void __launch_bounds__(SCATTER_THREADS) sort_scatter_kernel(const uin
 }
 
 // one workgroup per real partition: final order + bucket offsets
+// The bucket-size histogram of step 3b (SIZE_BINS bins, bin 0 = largest) is taken HERE when `ghist` is given (round 5: plain bucket sets, where a
+// bucket is one sorted segment and its size is the count this kernel has in its hands): one launch and one pass over the offsets less per MSM.
+#define SIZE_BINS 256
+struct SizeHist {
+    uint32_t* ghist;          // nullptr: step 3b counts the sizes itself (bucket sets merged over windows: the fixed-base table)
+    uint32_t bin_shift;
+    uint64_t nbuckets;
+};
+__device__ __forceinline__ uint32_t size_bin_of(uint32_t entries, uint32_t bin_shift) {
+    const uint32_t sz = entries >> bin_shift;
+    return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
+}
 __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
-                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+                                                             uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets, const SizeHist sz) {
     MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t lds[];
+    __shared__ uint32_t shist[SIZE_BINS];
+    if (sz.ghist) shist[threadIdx.x] = 0;
     const uint32_t nlow = 1u << g.low_bits;
     uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors
     uint32_t* run0 = lds + nlow;               // [nblk] start of every slice's run inside this partition
@@ -267,9 +281,15 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
     __syncthreads();
     if (threadIdx.x == 0) {                    // nlow <= 2048: a serial exclusive scan is negligible
         uint32_t run = pbeg;
-        for (uint32_t k = 0; k < nlow; k++) { const uint32_t v = cnt[k]; cnt[k] = run; run += v; }
+        for (uint32_t k = 0; k < nlow; k++) {
+            const uint32_t v = cnt[k];
+            cnt[k] = run;
+            run += v;
+            if (sz.ghist && (pid << g.low_bits) + k < sz.nbuckets) shist[size_bin_of(v, sz.bin_shift)]++;
+        }
     }
     __syncthreads();
+    if (sz.ghist && shist[threadIdx.x]) atomicAdd(&sz.ghist[threadIdx.x], shist[threadIdx.x]);
     for (uint32_t k = threadIdx.x; k < nlow; k += blockDim.x) offsets[(pid << g.low_bits) + k] = cnt[k];
     if (pid == g.nreal - 1 && threadIdx.x == 0) offsets[(uint64_t)g.nreal << g.low_bits] = pend;      // end sentinel
     __syncthreads();
@@ -309,9 +329,11 @@ __global__ void __launch_bounds__(256) sort_partition_kernel(const uint32_t* __r
 #define STAGE_THREADS 1024
 #define STAGE_MAX_CHUNKS 8u
 __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(const uint32_t* __restrict__ tmp, SortGeom g, const uint32_t* __restrict__ blk_off,
-                                                                              uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets) {
+                                                                              uint32_t* __restrict__ sorted, uint32_t* __restrict__ offsets, const SizeHist sz) {
     MSM_SIDE_PRIO_ENTER();
     extern __shared__ uint32_t lds[];
+    __shared__ uint32_t shist[SIZE_BINS];
+    if (sz.ghist && threadIdx.x < SIZE_BINS) shist[threadIdx.x] = 0;
     const uint32_t nlow = 1u << g.low_bits;
     uint32_t* cnt = lds;                       // [2^low_bits] counts -> cursors (relative to the partition start)
     uint32_t* run0 = lds + nlow;               // [nblk] start of every slice's run inside this partition (idx_bits == 0 only)
@@ -342,9 +364,16 @@ __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(co
     }
     uint32_t run = strip[threadIdx.x] - acc;
     __syncthreads();                           // every lane has read its strip value: the scratch may be overwritten from here on
-    for (uint32_t k = s0; k < s1; k++) { const uint32_t v = cnt[k]; cnt[k] = run; offsets[(pid << g.low_bits) + k] = pbeg + run; run += v; }
+    for (uint32_t k = s0; k < s1; k++) {
+        const uint32_t v = cnt[k];
+        cnt[k] = run;
+        offsets[(pid << g.low_bits) + k] = pbeg + run;
+        run += v;
+        if (sz.ghist && (pid << g.low_bits) + k < sz.nbuckets) atomicAdd(&shist[size_bin_of(v, sz.bin_shift)], 1u);      // (zeroed before the first barrier above)
+    }
     if (pid == g.nreal - 1 && threadIdx.x == 0) offsets[(uint64_t)g.nreal << g.low_bits] = pend;      // end sentinel
     __syncthreads();
+    if (sz.ghist && threadIdx.x < SIZE_BINS && shist[threadIdx.x]) atomicAdd(&sz.ghist[threadIdx.x], shist[threadIdx.x]);
     const uint32_t in_mask = SORT_SLICE - 1;
     const uint32_t imask = g.idx_bits ? (1u << g.idx_bits) - 1 : 0;
     // chunks of consecutive buckets: one when the partition fits the buffer, else sized for 3/4 of it (bucket sizes fluctuate)
@@ -384,7 +413,6 @@ __global__ void __launch_bounds__(STAGE_THREADS) sort_partition_staged_kernel(co
 // ---------------------------------------------------------------------------------------------- 3b: schedule buckets by size
 // One lane owns one bucket, so a wave runs as long as its fullest bucket.  A counting sort of the bucket
 // ids by (clamped) size, largest first, puts equally loaded buckets in the same wave.
-#define SIZE_BINS 256
 // Bucket sets.  Plain: one set per window.  With the fixed-base window table (msm_table_kernel): G sets per scalar vector — set s = k*G + g of
 // vector k collects the windows w = g, g + G, g + 2G, ... < W1 of that vector; the entries of (window w, bucket b) are the sorted segment
 // ((k*W1 + w) << cb) + b and their bases come from plane t = w / G of the table (2^(c*G*t) * P_i).  Plain mode is G = W1 (one segment, plane 0).
@@ -411,8 +439,7 @@ __device__ __forceinline__ uint32_t bucket_entries(const uint32_t* offsets, uint
     return sz;
 }
 __device__ __forceinline__ uint32_t size_bin(const uint32_t* offsets, uint32_t sb, const SetGeom& g) {
-    const uint32_t sz = bucket_entries(offsets, sb, g) >> g.bin_shift;   // merged buckets hold more entries: the host scales them into the 256 bins
-    return (SIZE_BINS - 1) - (sz < SIZE_BINS - 1 ? sz : SIZE_BINS - 1);      // bin 0 = largest
+    return size_bin_of(bucket_entries(offsets, sb, g), g.bin_shift);     // merged buckets hold more entries: the host scales them into the 256 bins
 }
 __global__ void __launch_bounds__(256) bucket_size_hist_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g, uint32_t* __restrict__ ghist) {
     MSM_SIDE_PRIO_ENTER();
@@ -438,18 +465,34 @@ __global__ void __launch_bounds__(SIZE_BINS) bucket_size_scan_kernel(const uint3
     }
     bin_cursor[threadIdx.x] = buf[threadIdx.x] - v;
 }
+// ghist != nullptr (round 5): bin_cursor arrives ZEROED and every workgroup scans the finished histogram itself (256 values: eight LDS steps) — the
+// one-workgroup scan launch in between is gone; ghist == nullptr: bin_cursor holds the scanned starts (bucket_size_scan_kernel).
 __global__ void __launch_bounds__(256) bucket_size_place_kernel(const uint32_t* __restrict__ offsets, uint64_t nbuckets, SetGeom g,
-                                                                uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order) {
+                                                                uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order, const uint32_t* __restrict__ ghist) {
     MSM_SIDE_PRIO_ENTER();
     __shared__ uint32_t h[SIZE_BINS];
     __shared__ uint32_t base[SIZE_BINS];
+    __shared__ uint32_t pre[SIZE_BINS];
     h[threadIdx.x] = 0;
+    uint32_t start = 0;
+    if (ghist != nullptr) {
+        const uint32_t v = ghist[threadIdx.x];
+        pre[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < SIZE_BINS; d <<= 1) {
+            const uint32_t t = (int)threadIdx.x >= d ? pre[threadIdx.x - d] : 0;
+            __syncthreads();
+            pre[threadIdx.x] += t;
+            __syncthreads();
+        }
+        start = pre[threadIdx.x] - v;
+    }
     __syncthreads();
     const uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     uint32_t bin = 0, rank = 0;
     if (b < nbuckets) { bin = size_bin(offsets, (uint32_t)b, g); rank = atomicAdd(&h[bin], 1u); }
     __syncthreads();
-    if (h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bin_cursor[threadIdx.x], h[threadIdx.x]);
+    if (h[threadIdx.x]) base[threadIdx.x] = start + atomicAdd(&bin_cursor[threadIdx.x], h[threadIdx.x]);
     __syncthreads();
     if (b < nbuckets) order[base[bin] + rank] = (uint32_t)b;
 }
@@ -1321,6 +1364,10 @@ static int msm_slice(int curve, const BaseRec<NQ>* d_bases, const uint32_t* cons
     for (int k = 0; k < K; k++)
         hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars[k], (uint64_t)n, (uint64_t)lens[k], c, W1,
                            dig + (size_t)k * W1 * n, scalars_mont ? 1 : 0, fr_params(curve)); }
+    // the bucket-size histogram rides in the level-2 sort when a bucket is one sorted segment (no fixed-base table); "msm_fused_order" = 0: round 4's three launches
+    const bool fused_order = ws.fused_order && sg.tab_stride == 0 && sg.G == sg.W1;
+    const SizeHist szh{fused_order ? ghist : nullptr, sg.bin_shift, (uint64_t)nbuckets};
+    if (fused_order) HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     { ProfScope ps("msm_sort", stream);
     hipLaunchKernelGGL(sort_hist_kernel, dim3(g.nblk, W), dim3(256), lds1, stream, dig, g, blk_hist);
     hipLaunchKernelGGL(scan_block_sums_kernel, dim3((uint32_t)nscan_blocks), dim3(SCAN_THREADS), 0, stream, blk_hist, nhist, bsums);
@@ -1340,18 +1387,22 @@ static int msm_slice(int curve, const BaseRec<NQ>* d_bases, const uint32_t* cons
     if (g.low_bits >= 8 && g.stage_cap >= STAGE_THREADS && !getenv("PLONK_MSM_NO_STAGED_SORT")) {
         static DeviceOnce attr2;
         HIP_TRY(attr2.run([] { return hipFuncSetAttribute(reinterpret_cast<const void*>(&sort_partition_staged_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); }));
-        hipLaunchKernelGGL(sort_partition_staged_kernel, dim3(g.nreal), dim3(STAGE_THREADS), lds_staged, stream, tmp, g, blk_off, sorted, offsets);
+        hipLaunchKernelGGL(sort_partition_staged_kernel, dim3(g.nreal), dim3(STAGE_THREADS), lds_staged, stream, tmp, g, blk_off, sorted, offsets, szh);
     } else {
-        hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets);
+        hipLaunchKernelGGL(sort_partition_kernel, dim3(g.nreal), dim3(256), (((size_t)1 << g.low_bits) + g.nblk) * 4, stream, tmp, g, blk_off, sorted, offsets, szh);
     } }
     { ProfScope ps("msm_bucket_order", stream);
-    HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     HIP_TRY(hipMemsetAsync(redo, 0, 4, stream));
     HIP_TRY(hipMemsetAsync(heavy, 0, 4, stream));
     const uint32_t bgrid = (uint32_t)((nbuckets + 255) / 256);
-    hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, ghist);
-    hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
-    hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, bin_cursor, order); }
+    if (fused_order) {
+        hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, bin_cursor, order, (const uint32_t*)ghist);
+    } else {
+        HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
+        hipLaunchKernelGGL(bucket_size_hist_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, ghist);
+        hipLaunchKernelGGL(bucket_size_scan_kernel, dim3(1), dim3(SIZE_BINS), 0, stream, ghist, bin_cursor);
+        hipLaunchKernelGGL(bucket_size_place_kernel, dim3(bgrid), dim3(256), 0, stream, offsets, nbuckets, sg, bin_cursor, order, (const uint32_t*)nullptr);
+    } }
     // "msm_acc_persist" (default 4): the accumulation as that many workgroups per CU of persistent waves; 0 = one lane per bucket over the whole grid
     uint32_t* work = nullptr;
     uint32_t acc_grid = (uint32_t)((nbuckets + 255) / 256);

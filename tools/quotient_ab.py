@@ -6,7 +6,7 @@ import numpy as np
 from distributed_plonk_amd.worker import PlonkWorker
 log_n, va, vb = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 reps = int(sys.argv[4]) if len(sys.argv) > 4 else 6
-w = PlonkWorker(0, 0, "bn254")
+w = PlonkWorker(0, 0, os.environ.get("QUOT_CURVE", "bn254"))
 n, m = 1 << log_n, 8 << log_n
 w.init(None, n, m)
 bufs = [w.alloc(m * 32) for _ in range(25)]
