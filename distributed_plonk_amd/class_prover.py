@@ -184,8 +184,13 @@ class ClassProver(Prover):
     and this rank commits, for every polynomial, the coefficients with index in [lo, hi): the key is sharded G ways like the
     reference's (dispatcher2.rs:260-266), 64 / 96 B per point resident."""
 
-    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None):
+    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None, cache_key_cosets: bool = False):
+        """cache_key_cosets: keep this rank's class evaluations of the 18 proving-key polynomials resident across proofs (18 * 8n/G * 32 B:
+        9.7 GB per rank at 2^24 gates and 8 ranks) — 18 of the 25 class evaluations of round 3 depend on nothing a proof draws.  Same proof;
+        NOT the reference's work (it re-transforms the key every proof, dispatcher2.rs:387-404): a labelled variant, like Prover's."""
         super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper)
+        self.cache_class_key = bool(cache_key_cosets)
+        self._class_key = None
         self.key_range = None if key_range is None else (int(key_range[0]), int(key_range[1]))
         G = comm.size
         if G & (G - 1) or G > self.m // self.n:
@@ -396,7 +401,16 @@ class ClassProver(Prover):
         d_cls = alloc(25 * mL)
         cls = [d_cls.ptr + j * mL * 32 for j in range(25)]
         srcs = [(p, n) for p in key["sel"] + key["sig"]] + list(wire_polys) + [perm_poly, pi_poly]
+        if self.cache_class_key:
+            if self._class_key is None or self._class_key[0] is not key:
+                d_key = self._work("class_key_cosets", 18 * mL)
+                for j in range(18):
+                    w.coset_eval_dev(srcs[j][0], srcs[j][1], mL, self.shift, d_key.ptr + j * mL * 32)
+                self._class_key = (key, d_key)
+            cls[:18] = [self._class_key[1].ptr + j * mL * 32 for j in range(18)]
         for j, (ptr, ln) in enumerate(srcs):
+            if self.cache_class_key and j < 18:
+                continue
             w.coset_eval_dev(ptr, ln, mL, self.shift, cls[j])             # this class's slice of the coset FFT of :387-429
         tick("round3_coset_ffts", t0)
         t0 = time.perf_counter()

@@ -1364,8 +1364,10 @@ static int msm_slice(int curve, const BaseRec<NQ>* d_bases, const uint32_t* cons
     for (int k = 0; k < K; k++)
         hipLaunchKernelGGL(msm_digits_kernel, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, stream, d_scalars[k], (uint64_t)n, (uint64_t)lens[k], c, W1,
                            dig + (size_t)k * W1 * n, scalars_mont ? 1 : 0, fr_params(curve)); }
-    // the bucket-size histogram rides in the level-2 sort when a bucket is one sorted segment (no fixed-base table); "msm_fused_order" = 0: round 4's three launches
-    const bool fused_order = ws.fused_order && sg.tab_stride == 0 && sg.G == sg.W1;
+    // the bucket-size histogram rides in the level-2 sort when a bucket is one sorted segment (no fixed-base table).  "msm_fused_order": 1 (default) = for
+    // launches of >= 2^23 points in total, where it takes 3 % off the commitment phase of a 2^24 step; below that the level-2 sort loses more to the
+    // histogram's atomics than the two saved launches give back (+0.7 % per 2^20 step; profiles/r05_msm_fused_order.txt); 2 = always (tests); 0 = never
+    const bool fused_order = (ws.fused_order == 2 || (ws.fused_order == 1 && (uint64_t)n * (uint64_t)K >= ((uint64_t)1 << 23))) && sg.tab_stride == 0 && sg.G == sg.W1;
     const SizeHist szh{fused_order ? ghist : nullptr, sg.bin_shift, (uint64_t)nbuckets};
     if (fused_order) HIP_TRY(hipMemsetAsync(ghist, 0, 2 * SIZE_BINS * 4, stream));
     { ProfScope ps("msm_sort", stream);

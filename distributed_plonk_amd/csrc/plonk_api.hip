@@ -246,7 +246,7 @@ extern "C" int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value) 
     // every knob lives in the context it was set on (another context, possibly driven from another host thread, is not affected)
     if (!strcmp(key, "ntt_max_log_r")) { ctx->tables.max_log_r = (int)value; return PLONK_OK; }
     if (!strcmp(key, "msm_batch_max")) { ctx->msm_ws.batch_max = (int)value; return PLONK_OK; }      // vectors per launch set of commit_many
-    if (!strcmp(key, "msm_fused_order")) { ctx->msm_ws.fused_order = value ? 1 : 0; return PLONK_OK; }   // default 1
+    if (!strcmp(key, "msm_fused_order")) { ctx->msm_ws.fused_order = value < 0 ? 0 : (value > 2 ? 2 : (int)value); return PLONK_OK; }   // 1 = large launches (default), 2 = always, 0 = never
     if (!strcmp(key, "msm_fused_y3")) { ctx->msm_ws.fused_y3 = value ? 1 : 0; return PLONK_OK; }      // default 1
     if (!strcmp(key, "msm_sort_stage_cap")) { ctx->msm_ws.sort_stage_cap = (int)std::max<int64_t>(0, value); return PLONK_OK; }   // tests: force the chunked level-2 sort
     if (!strcmp(key, "msm_acc_persist")) { ctx->msm_ws.acc_persist = (int)std::max<int64_t>(-65536, std::min<int64_t>(value, 8)); return PLONK_OK; }   // default 4; < 0: an absolute grid of -value workgroups (tests)

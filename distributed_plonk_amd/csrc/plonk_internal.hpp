@@ -168,7 +168,7 @@ struct MsmWorkspace {
     // per-context tuning knobs (plonk_set_option): tests and experiments only
     int slice_log = 26;       // "msm_slice_log": MSMs above 2^slice_log points run slice by slice (workspace sizing)
     int batch_max = 32;       // "msm_batch_max": scalar vectors per launch set of plonk_commit_many_dev (1 = one MSM at a time)
-    int fused_order = 1;      // "msm_fused_order": the bucket-size histogram taken inside the level-2 sort and scanned inside the placement (round 5); 0 = round 4's three launches
+    int fused_order = 1;      // "msm_fused_order": the bucket-size histogram taken inside the level-2 sort and scanned inside the placement (round 5): 1 = for launches of >= 2^23 points, 2 = always, 0 = never
     int fused_y3 = 1;         // "msm_fused_y3": Y3 of the mixed addition under one Montgomery reduction (ec_lazy.hpp); 0 = two products
     int sort_stage_cap = 0;   // "msm_sort_stage_cap": > 0 caps the LDS staging buffer of the level-2 sort (entries; tests force its chunked path), 0 = what the LDS budget leaves
     int reduce_grid = 0;      // "msm_reduce_grid": 1 = the window reduction as row / column tree sums + bit sums (msm_grid_sums_kernel) instead of the running-sum pyramid; experiment, not measured yet

@@ -325,7 +325,8 @@ int plonk_debug_field_op(plonk_ctx* ctx, int field, int op, const uint64_t* a, c
  * "msm_table_c" (0 or 4..21) / "msm_table_sets" / "msm_table_budget_mib" (the table's window width, bucket sets per scalar and memory budget;
  * 0 = the plan's choice), "msm_sort_stage_cap" (tests: caps the LDS staging buffer of the level-2 sort), "msm_reduce_grid" (default 0: the window
  * reduction as tree sums over the bucket grid instead of the running-sum pyramid — faster for one small MSM alone, not beside another context's
- * accumulation: profiles/r04_pin_nop_experiment.txt), "msm_fused_y3", "ntt_shoup" (both curves, default 1: precomputed-quotient butterflies in
+ * accumulation: profiles/r04_pin_nop_experiment.txt), "msm_fused_order" (the bucket-size histogram inside the level-2 sort: 1 = for launches of
+ * >= 2^23 points (default), 2 = always, 0 = never), "msm_fused_y3", "ntt_shoup" (both curves, default 1: precomputed-quotient butterflies in
  * the NTT passes; 0 = Montgomery butterflies), "check_bases" (default 1: plonk_init* verifies that every base is a curve point), "quotient_fuse" (6 = default: the compact kernel; 0-5, 7: other formulations).
  * INTEGRATION.md §6 has the table. */
 int plonk_set_option(plonk_ctx* ctx, const char* key, int64_t value);

@@ -45,7 +45,7 @@ def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
 
     def rank_main(comm, w):
         w.init(ck, n, 8 * n)                               # whole commit key on every rank
-        pv = ClassProver(w, log_n, comm)
+        pv = ClassProver(w, log_n, comm, cache_key_cosets=(log_n == 7))      # one size with this rank's key class evaluations resident across the two proofs
         try:
             pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
             out = None

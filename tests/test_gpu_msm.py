@@ -242,6 +242,45 @@ def test_persistent_accumulation_matches_plain_grid_and_oracle(gpu_workers, orac
 
 
 @pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_bucket_ordering_fused_into_the_sort_matches_the_three_launch_form(gpu_workers, oracle, curve, cid):
+    """`msm_fused_order` (round 5): the bucket-size histogram taken inside the level-2 sort — both partition kernels: the direct one (narrow
+    windows) and the LDS-staged one (2^8 and more buckets per partition), its chunked path included — and scanned inside the placement.  The
+    default switches it on from 2^23 points per launch only, so it is FORCED here (2) against the three-launch form (0) and the oracle, with
+    duplicated bases, an infinity base, a heavy bucket and a batched round."""
+    w = gpu_workers(curve)
+    n = 1 << 13
+    bases = oracle.gen_bases(cid, 33, 300, n)
+    b, inf = _bases_with_inf(oracle, cid, bases, [11])
+    w.init(b, 0, 0)
+    rnd = oracle.from_mont(cid, oracle.rand_fr(cid, 34, n))
+    same = np.repeat(rnd[:1], n, axis=0)
+    try:
+        for name, sc, window, cap in (("uniform", rnd, 0, 0), ("c5-direct-sort", rnd, 5, 0), ("c14-staged-sort", rnd, 14, 0), ("c14-chunked", rnd, 14, 1024),
+                                      ("all-equal", same, 0, 0)):
+            w.set_option("msm_window", window)
+            w.set_option("msm_sort_stage_cap", cap)
+            want = oracle.msm(cid, bases, sc, inf, threads=8)
+            for mode in (0, 2):
+                w.set_option("msm_fused_order", mode)
+                assert _affine_eq(w, oracle, cid, w.var_msm(MsmWorkload(0, n), sc), want), (name, mode)
+        w.set_option("msm_window", 0)
+        w.set_option("msm_sort_stage_cap", 0)
+        w.set_option("msm_fused_order", 2)
+        vecs = [oracle.rand_fr(cid, 50 + k, n) for k in range(3)]
+        bufs = [w.alloc(n * 32) for _ in vecs]
+        for d, v in zip(bufs, vecs):
+            d.upload(v)
+        for v, p in zip(vecs, w.commit_many_dev([(d.ptr, n) for d in bufs])):
+            assert _affine_eq(w, oracle, cid, p, oracle.msm(cid, bases, oracle.from_mont(cid, v), inf, threads=8))
+        for d in bufs:
+            d.free()
+    finally:
+        w.set_option("msm_window", 0)
+        w.set_option("msm_sort_stage_cap", 0)
+        w.set_option("msm_fused_order", 1)
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
 def test_grid_reduction_matches_pyramid_and_oracle(gpu_workers, oracle, curve, cid):
     """`msm_reduce_grid` (experiment, off by default): the window reduction V = sum_j (j+1) B_j as row / column tree sums of the H x L bucket
     grid plus bit sums of the <= 1024 row / column totals (msm_engine.hip, 5b) instead of the running-sum pyramid.  Every window width from
