@@ -305,6 +305,88 @@ class Fuzz:
                 b.free()
         return np.array_equal(got, want), dict(n=n)
 
+    def op_perm_product_ranges(self):
+        """the product vector assembled from G gate ranges (plonk_perm_product_range_dev; class_prover.py): uneven slices, slices of one gate,
+        every slice multiplied by the totals before it == the oracle's vector"""
+        n = int(self.rs.randint(2, 1 << min(self.max_log, 12)) + 1)
+        G = int(self.rs.randint(1, min(n, 9)))
+        wires = self.O.rand_fr(self.cid, self.seed(), 5 * n).reshape(5, n, 4)
+        id_perm = self.O.rand_fr(self.cid, self.seed(), 5 * n)
+        perm_idx = self.rs.permutation(5 * n).astype(np.uint64)
+        beta, gamma = self.O.rand_fr(self.cid, self.seed(), 2)
+        dw, di, dp = self.up(wires), self.up(id_perm), self.up(perm_idx)
+        want = self.O.perm_product(self.cid, wires, id_perm, perm_idx, beta, gamma)
+        cuts = sorted(set([0, n] + [int(x) for x in self.rs.randint(1, n, size=G - 1)])) if G > 1 else [0, n]
+        mul = lambda a, b: self.O.field_op(self.cid, 0, "mul", np.ascontiguousarray(a).reshape(-1, 4), np.ascontiguousarray(b).reshape(-1, 4))
+        pre = self.f.to_limbs(1)
+        ok = True
+        try:
+            for lo, hi in zip(cuts, cuts[1:]):
+                cnt, extra = hi - lo, (0 if hi == n else 1)
+                out = self.w.alloc((cnt + 1) * 32)
+                self.w.perm_product_range_dev([dw.ptr + i * n * 32 for i in range(5)], di.ptr, dp.ptr, beta, gamma, n, lo, cnt + extra, out.ptr)
+                loc = out.download((cnt + extra, 4))
+                out.free()
+                ok = ok and np.array_equal(mul(loc[:cnt], np.tile(pre, (cnt, 1))), want[lo:hi])
+                if extra:
+                    pre = mul(pre, loc[cnt])[0]
+        finally:
+            for b in (dw, di, dp):
+                b.free()
+        return ok, dict(n=n, cuts=cuts)
+
+    def op_class_ifft(self):
+        """a size-n iFFT by residue class on one context: G class evaluations (plonk_coset_eval_dev with a G-fold) + plonk_class_interleave_dev
+        (reverse, 1/n) == the oracle's domain.ifft; random class stride (several polynomials side by side)"""
+        G = int(2 ** self.rs.randint(0, 4))
+        log_n = int(self.rs.randint(max(1, int(np.log2(G)) + 1), min(self.max_log, 13) + 1))
+        n = 1 << log_n
+        L = n // G
+        K, k_sel = int(self.rs.randint(1, 4)), 0
+        k_sel = int(self.rs.randint(0, K))
+        ev = self.fr(n)
+        d_ev = self.up(ev)
+        d_all, d_out = self.w.alloc(G * K * L * 32), self.w.alloc(n * 32)
+        self.w.memset_dev(d_all.ptr, 0xA5, G * K * L * 32)
+        try:
+            for s_ in range(G):
+                shift = self.f.to_limbs(pow(self.f.root_of_unity(n), (n - s_) % n, self.f.p))
+                self.w.coset_eval_dev(d_ev.ptr, n, L, shift, d_all.ptr + ((s_ * K + k_sel) * L) * 32)
+            self.w.class_interleave_dev(d_all.ptr + k_sel * L * 32, G, L, True, self.f.to_limbs(self.f.inv(n)), d_out.ptr, in_stride=K * L)
+            got = d_out.download((n, 4))
+        finally:
+            for b in (d_ev, d_all, d_out):
+                b.free()
+        return np.array_equal(got, self.O.ntt(self.cid, ev, True, False)), dict(log_n=log_n, G=G, K=K, k=k_sel)
+
+    def op_init_refuses_bad_srs(self):
+        """plonk_init: a random corruption of a valid SRS (a flipped bit, swapped coordinates of one point, an unreduced limb) is refused with the
+        offender's index; the untouched SRS installs and commits like the oracle"""
+        from distributed_plonk_amd._ffi import MsmWorkload, PlonkError
+        n = int(self.rs.randint(1, 300))
+        bases = self.O.gen_bases(self.cid, self.seed(), min(n, 16), n)
+        half = bases.shape[1] // 2
+        bad = bases.copy()
+        i = int(self.rs.randint(0, n))
+        kind = int(self.rs.randint(0, 3))
+        if kind == 0:
+            bad[i, int(self.rs.randint(0, bases.shape[1]))] ^= np.uint64(1 << int(self.rs.randint(0, 60)))
+        elif kind == 1:
+            bad[i] = np.concatenate([bases[i, half:], bases[i, :half]])
+        else:
+            bad[i, half - 1] = np.uint64(0xFFFFFFFFFFFFFFFF)
+        refused = False
+        try:
+            self.w.init(bad, 0, 0)
+        except PlonkError as ex:
+            refused = ex.code == -1 and f"base {i} of" in str(ex)
+        self.w.init(bases, 0, 0)
+        self.n_bases = 0                                   # the shared SRS of the other operations is gone: they re-initialise
+        sc = self.O.from_mont(self.cid, self.O.rand_fr(self.cid, self.seed(), n))
+        got = self.w.g1_to_affine(self.w.var_msm(MsmWorkload(0, n), sc))
+        exp = self.O.jac_to_affine(self.cid, self.O.msm(self.cid, bases, sc, threads=4))
+        return refused and got[1] == exp[1] and np.array_equal(got[0], exp[0]), dict(n=n, i=i, kind=kind)
+
     def op_transpose(self):
         rows, cols = int(self.rs.randint(1, 200)), int(self.rs.randint(1, 200))
         v = self.fr(rows * cols)
@@ -520,7 +602,8 @@ class Fuzz:
             buf.free(); out.free()
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
-    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove", "msm_table"]
+    OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove", "msm_table",
+           "perm_product_ranges", "class_ifft", "init_refuses_bad_srs"]
 
     def close(self):
         self.w.close()
