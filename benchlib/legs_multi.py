@@ -365,6 +365,8 @@ def class_prover(b):
     t_cls = b.max_over_ranks(t_cls)
     rounds_ms = {k_: round(v_, 2) for k_, v_ in cp.timings.items()}
     bytes_out_per_proof = comm.bytes_out // 2 if sim else None
+    r12 = "replicated (PLONK_CLASS_REPLICATED_R12=1 or one rank)" if cp.replicated_r12 else "size-n iFFTs by residue class, grand product by gate range"
+    cp.close()                                   # its work buffers (~150 GB at 2^24 on ONE rank) must go before the variant allocates its own
     # the same proof with this rank's class evaluations of the 18 proving-key polynomials resident (9.7 GB per rank at 2^24 / 8 ranks): a labelled
     # variant, like the single-GPU prover's resident_key_cosets — the reference re-transforms the key every proof
     t_res, same = None, None
@@ -404,11 +406,10 @@ def class_prover(b):
            "simulated": bool(sim),
            **({"sim_exchange": {"mode": args.sim_exchange, "device_bytes_out_per_proof": bytes_out_per_proof,
                                 "xgmi_model_ms_per_proof_at_153_GBps_per_link": round(bytes_out_per_proof / (G_ - 1) / 153e9 * 1e3, 2)}} if sim else {}),
-           "rounds_1_2": "replicated (PLONK_CLASS_REPLICATED_R12=1)" if cp.replicated_r12 else "size-n iFFTs by residue class, grand product by gate range",
+           "rounds_1_2": r12,
            "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 3 all-gathers of class values (the size-n iFFTs of rounds 1, 2, 3), "
                                     "1 all-gather of the product vector, 5 all-gathers of partial commitment points (one per round), "
                                     "5 all-gathers of 32-byte partials (slice totals, evaluations, degree, two openings)",
            "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
-    cp.close()
     inst.close()
     return row
