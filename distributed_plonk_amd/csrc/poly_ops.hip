@@ -164,22 +164,23 @@ __global__ void __launch_bounds__(PO_LANES) scan_apply_kernel(const Fr* __restri
                                                               const PoCtx c, const Epi epi) {
     __shared__ uint32_t sh[PO_LANES][9];
     const uint64_t q0 = (uint64_t)blockIdx.x * PO_TILE + (uint64_t)threadIdx.x * PO_CH;
-    typename Op::V x[PO_CH];
+    // The lane's PO_CH elements are read TWICE (the second time from L1 / L2) instead of being kept in an array: with the pinned multiplier the
+    // loops below are not unrolled, and an array indexed by a loop counter lives in scratch memory — 304 B per lane, which the PMC counters of
+    // round 5 showed as 4-5x the algorithmic traffic of these kernels (profiles/r05_poly_rows.txt).
     typename Op::V acc = Op::ident(c);
-#pragma unroll
     for (int k = 0; k < PO_CH; k++) {
         const uint64_t q = q0 + k;
-        x[k] = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
-        acc = k == 0 ? x[0] : Op::comb(acc, x[k], c);
+        const typename Op::V xk = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
+        acc = k == 0 ? xk : Op::comb(acc, xk, c);
     }
     const typename Op::V ex = block_exclusive<Op, PO_LANES>(acc, sh, c, nullptr);
     typename Op::V run = Op::comb(Op::load(boff + blockIdx.x, c), ex, c);
-#pragma unroll
     for (int k = 0; k < PO_CH; k++) {
         const uint64_t q = q0 + k;
-        if (inclusive) run = Op::comb(run, x[k], c);
+        const typename Op::V xk = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
+        if (inclusive) run = Op::comb(run, xk, c);
         if (q < n) epi(run, phys_index(q, n, reverse), c);
-        if (!inclusive) run = Op::comb(run, x[k], c);
+        if (!inclusive) run = Op::comb(run, xk, c);
     }
 }
 
@@ -701,21 +702,20 @@ __global__ void __launch_bounds__(DV_LANES) poly_div_apply_kernel(const Fr* __re
         for (int i = 0; i < 8; i++) w[i] = v.l[i];
     }
     __syncthreads();
-    // this lane's DV_CH consecutive coefficients
-    F29 x[DV_CH];
-#pragma unroll
-    for (int i = 0; i < DV_CH; i++) {
+    // this lane's DV_CH consecutive coefficients are read from the LDS tile where they are used — twice — and never held in an array: the loops
+    // below are not unrolled (the pinned multiplier exceeds the unroll budget) and an indexed array would live in scratch memory (the first
+    // form of this kernel: 304 B of scratch per lane, 2.5x the algorithmic traffic in the PMC counters, 0.66 ms)
+    auto coeff = [&](int i) {
         const uint32_t* w = tile + dv_word(L * DV_CH + i);
         Fr v;
 #pragma unroll
         for (int k = 0; k < 8; k++) v.l[k] = w[k];
-        x[i] = f29_from_sat(v);
-    }
+        return f29_from_sat(v);
+    };
     const F29 z = load_f29(tab + DVT_Z);
     // lane aggregate sum_i x[i] z^i, scaled by z^(DV_CH*L)
-    F29 a = x[DV_CH - 1];
-#pragma unroll
-    for (int i = DV_CH - 2; i >= 0; i--) a = f29_add(f29_mul(a, z, fp), x[i]);
+    F29 a = coeff(DV_CH - 1);
+    for (int i = DV_CH - 2; i >= 0; i--) a = f29_add(f29_mul(a, z, fp), coeff(i));
     const Fr bl = f29_to_sat(f29_canon(f29_mul(a, load_f29(tab + L), fp), fp));
     // exclusive additive suffix scan over the lanes: S_L = sum_{L' > L} B_L'
     {
@@ -740,11 +740,9 @@ __global__ void __launch_bounds__(DV_LANES) poly_div_apply_kernel(const Fr* __re
     // + z^DV_TILE * X_t, then * z^-(DV_CH*(L+1)):  q at the first index above this lane's chunk
     u = f29_add(u, f29_mul(f29_from_sat(load_fr(carry + blockIdx.x)), load_f29(tab + DVT_ZT), fp));
     F29 q = f29_mul(u, load_f29(tab + DV_LANES + L), fp);
-    __syncthreads();                                                          // every lane has read its coefficients: the tile becomes the output
-    // the recurrence down the chunk: q_(j0 + L*DV_CH + i) = x[i] + z * q_(that + 1)
-#pragma unroll
+    // the recurrence down the chunk: q_(j0 + L*DV_CH + i) = x[i] + z * q_(that + 1); slot (L, i) of the tile is read, then overwritten, by this lane only
     for (int i = DV_CH - 1; i >= 0; i--) {
-        q = f29_add(f29_mul(q, z, fp), x[i]);                                  // < 2.4 p, limbs < 2^30
+        q = f29_add(f29_mul(q, z, fp), coeff(i));                              // < 2.4 p, limbs < 2^30
         F29 qn = q;
         f29_norm(qn);
         const Fr v = f29_to_sat(f29_canon_lazy(qn, fp));                       // canonical without a product
