@@ -289,6 +289,9 @@ def verify_multi(b):
     return mv
 
 
+CLASS_FFT_HELPER_DEFAULT = "0"        # set by the measurement of profiles/r05_sim8_measurements.txt
+
+
 class _SimComm:
     """rank 0 of `size` ranks with nobody else there (diagnostic timing only): host objects come back `size` times; device collectives are the
     bench's stand-ins (Bench.sim_alltoall / sim_allgather: the bytes they would move, copied device to device on the worker's stream; nothing
@@ -348,7 +351,11 @@ def class_prover(b):
         comm = LibComm(w, bootstrap=_boot)
     else:
         comm = TorchComm(w, None if b.emulated else b.dev)
-    cp = ClassProver(w, args.log_n, comm, commit_helper=b.workers[1], key_range=(klo, khi))
+    # the key's 18 class evaluations on a third context beside rounds 1-2 (ClassProver(fft_helper=...)): one of the step's transform contexts when the
+    # run has them (--overlap-phases), PLONK_CLASS_FFT_HELPER=0 / 1 overrides the default
+    want_helper = os.environ.get("PLONK_CLASS_FFT_HELPER", CLASS_FFT_HELPER_DEFAULT) == "1"
+    fft_helper = b.step_workers[0] if (want_helper and b.step_workers) else None
+    cp = ClassProver(w, args.log_n, comm, commit_helper=b.workers[1], key_range=(klo, khi), fft_helper=fft_helper)
     cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
     pub = inst.public_inputs()
     vk = cp.verifying_key()                                                               # 18 sharded commitments, once per key
@@ -407,6 +414,7 @@ def class_prover(b):
            **({"sim_exchange": {"mode": args.sim_exchange, "device_bytes_out_per_proof": bytes_out_per_proof,
                                 "xgmi_model_ms_per_proof_at_153_GBps_per_link": round(bytes_out_per_proof / (G_ - 1) / 153e9 * 1e3, 2)}} if sim else {}),
            "rounds_1_2": r12,
+           "key_class_evaluations": "on a third context beside rounds 1 and 2" if fft_helper is not None else "inside round 3",
            "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 3 all-gathers of class values (the size-n iFFTs of rounds 1, 2, 3), "
                                     "1 all-gather of the product vector, 5 all-gathers of partial commitment points (one per round), "
                                     "5 all-gathers of 32-byte partials (slice totals, evaluations, degree, two openings)",

@@ -184,11 +184,15 @@ class ClassProver(Prover):
     and this rank commits, for every polynomial, the coefficients with index in [lo, hi): the key is sharded G ways like the
     reference's (dispatcher2.rs:260-266), 64 / 96 B per point resident."""
 
-    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None, cache_key_cosets: bool = False):
+    def __init__(self, worker: PlonkWorker, log_n: int, comm, commit_helper: Optional[PlonkWorker] = None, key_range=None, cache_key_cosets: bool = False,
+                 fft_helper: Optional[PlonkWorker] = None):
         """cache_key_cosets: keep this rank's class evaluations of the 18 proving-key polynomials resident across proofs (18 * 8n/G * 32 B:
         9.7 GB per rank at 2^24 gates and 8 ranks) — 18 of the 25 class evaluations of round 3 depend on nothing a proof draws.  Same proof;
-        NOT the reference's work (it re-transforms the key every proof, dispatcher2.rs:387-404): a labelled variant, like Prover's."""
-        super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper)
+        NOT the reference's work (it re-transforms the key every proof, dispatcher2.rs:387-404): a labelled variant, like Prover's.
+        fft_helper: another context on this rank's GPU (`init`-ed for the same domains): those 18 class evaluations are issued on ITS stream by a
+        thread of their own at the start of the proof, beside rounds 1 and 2 (no collective involved), and round 3 joins them — Prover's
+        fft_helper for the class prover; the reference's work, same proof."""
+        super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper, fft_helper=fft_helper)
         self.cache_class_key = bool(cache_key_cosets)
         self._class_key = None
         self.key_range = None if key_range is None else (int(key_range[0]), int(key_range[1]))
@@ -207,6 +211,28 @@ class ClassProver(Prover):
         self.replicated_r12 = os.environ.get("PLONK_CLASS_REPLICATED_R12") == "1" or G == 1 or self.n < 8 * G
         self.shift_n = f.to_limbs(pow(f.root_of_unity(self.n), (self.n - self.s) % self.n, f.p))      # w_n^-s
         self.inv_n = f.to_limbs(f.inv(self.n))
+
+    # ---- the proving key's class evaluations beside rounds 1-2 (fft_helper)
+    def _key_ffts_start(self, alloc):
+        if self.fft_helper is None or self.cache_class_key:
+            return
+        mL, key, h, shift, n = self.m // self.G, self._key, self.fft_helper, self.shift, self.n
+        d_kc = self._work("class_key_cosets_helper", 18 * mL)
+        kc = [d_kc.ptr + j * mL * 32 for j in range(18)]
+        self.w.sync()                                   # the helper's stream reads the key polynomials this context's stream wrote
+        errs = []
+
+        def run():
+            try:
+                for j, src in enumerate(key["sel"] + key["sig"]):
+                    h.coset_eval_dev(src, n, mL, shift, kc[j])
+                h.sync()
+            except BaseException as ex:     # noqa: BLE001 - re-raised by _key_ffts_join
+                errs.append(ex)
+
+        th = threading.Thread(target=run)
+        th.start()
+        self._key_ffts = (th, kc, errs)
 
     # ---- rounds 1-3: the size-n iFFTs by residue class, the grand product by gate range (module docstring)
     def _interpolate_many(self, alloc, pairs):
@@ -408,8 +434,11 @@ class ClassProver(Prover):
                     w.coset_eval_dev(srcs[j][0], srcs[j][1], mL, self.shift, d_key.ptr + j * mL * 32)
                 self._class_key = (key, d_key)
             cls[:18] = [self._class_key[1].ptr + j * mL * 32 for j in range(18)]
+        joined = self._key_ffts is not None
+        if joined:
+            cls[:18] = self._key_ffts_join()
         for j, (ptr, ln) in enumerate(srcs):
-            if self.cache_class_key and j < 18:
+            if (self.cache_class_key or joined) and j < 18:
                 continue
             w.coset_eval_dev(ptr, ln, mL, self.shift, cls[j])             # this class's slice of the coset FFT of :387-429
         tick("round3_coset_ffts", t0)

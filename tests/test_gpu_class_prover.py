@@ -45,16 +45,23 @@ def test_class_prover_matches_oracle(oracle, curve, cid, log_n, G):
 
     def rank_main(comm, w):
         w.init(ck, n, 8 * n)                               # whole commit key on every rank
-        pv = ClassProver(w, log_n, comm, cache_key_cosets=(log_n == 7))      # one size with this rank's key class evaluations resident across the two proofs
+        from distributed_plonk_amd.worker import PlonkWorker
+        helper = PlonkWorker(me=comm.rank, device=0, curve=curve) if log_n == 10 else None     # one size with the key's class evaluations on a third context beside rounds 1-2
+        if helper is not None:
+            helper.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, comm, cache_key_cosets=(log_n == 7), fft_helper=helper)      # one size with them resident across the two proofs
         try:
             pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
             out = None
             assert not pv.replicated_r12                   # the size-n iFFTs by residue class, the grand product by gate range
             for _ in range(2):                             # second proof reuses the work buffers
                 out = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label], keep=True)
+            assert pv._key_ffts is None
             return out, dict(pv.timings)
         finally:
             pv.close()
+            if helper is not None:
+                helper.close()
 
     results = run_local_ranks(G, rank_main, curve=curve)
     want = P.prove_rounds(cid, log_n, ck, inf, circ, bl, ch, threads=8)
