@@ -289,7 +289,7 @@ def verify_multi(b):
     return mv
 
 
-CLASS_FFT_HELPER_DEFAULT = "0"        # set by the measurement of profiles/r05_sim8_measurements.txt
+CLASS_FFT_HELPER_DEFAULT = "1"        # rank 0 of 8 simulated, same lease: 123.0 / 124.1 -> 114.8 / 115.3 ms per proof (profiles/r05_sim8_measurements.txt)
 
 
 class _SimComm:
