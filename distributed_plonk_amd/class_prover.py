@@ -195,7 +195,6 @@ class ClassProver(Prover):
         super().__init__(worker, log_n, cache_key_cosets=False, commit_helper=commit_helper, fft_helper=fft_helper)
         self.cache_class_key = bool(cache_key_cosets)
         self._class_key = None
-        self._wire_ffts = None                # (thread, 5 device pointers, errors): the wires' class evaluations on the helper beside round 1's commitments and round 2
         self.key_range = None if key_range is None else (int(key_range[0]), int(key_range[1]))
         G = comm.size
         if G & (G - 1) or G > self.m // self.n:
@@ -234,39 +233,6 @@ class ClassProver(Prover):
         th = threading.Thread(target=run)
         th.start()
         self._key_ffts = (th, kc, errs)
-
-    def _wire_polys_ready(self, wire_polys):
-        """fft_helper: the five wire polynomials' class evaluations need no challenge — they follow the key's on the helper's stream, beside round 1's
-        commitments and round 2, instead of waiting for round 3.  The helper context is driven by ONE thread at a time: this one first joins the
-        thread that issues the key's evaluations."""
-        if self.fft_helper is None or self._key_ffts is None or os.environ.get("PLONK_CLASS_WIRE_HELPER") == "0":      # (the knob: A/B runs)
-            return
-        mL, h, shift = self.m // self.G, self.fft_helper, self.shift
-        d_wc = self._work("class_wire_cosets_helper", 5 * mL)
-        wc = [d_wc.ptr + j * mL * 32 for j in range(5)]
-        self.w.sync()                                   # the helper's stream reads what this context's stream has just written
-        prev, errs = self._key_ffts[0], []
-
-        def run():
-            try:
-                prev.join()
-                for j, (ptr, ln) in enumerate(wire_polys):
-                    h.coset_eval_dev(ptr, ln, mL, shift, wc[j])
-                h.sync()
-            except BaseException as ex:     # noqa: BLE001 - re-raised at the join
-                errs.append(ex)
-
-        th = threading.Thread(target=run)
-        th.start()
-        self._wire_ffts = (th, wc, errs)
-
-    def prove_dev(self, *a, **kw):
-        try:
-            return super().prove_dev(*a, **kw)
-        finally:
-            if self._wire_ffts is not None:             # an exception before round 3: no thread is left behind
-                self._wire_ffts[0].join()
-                self._wire_ffts = None
 
     # ---- rounds 1-3: the size-n iFFTs by residue class, the grand product by gate range (module docstring)
     def _interpolate_many(self, alloc, pairs):
@@ -471,16 +437,8 @@ class ClassProver(Prover):
         joined = self._key_ffts is not None
         if joined:
             cls[:18] = self._key_ffts_join()
-        wires_done = self._wire_ffts is not None
-        if wires_done:
-            th, wc, errs = self._wire_ffts
-            self._wire_ffts = None
-            th.join()
-            if errs:
-                raise errs[0]
-            cls[18:23] = wc
         for j, (ptr, ln) in enumerate(srcs):
-            if ((self.cache_class_key or joined) and j < 18) or (wires_done and 18 <= j < 23):
+            if (self.cache_class_key or joined) and j < 18:
                 continue
             w.coset_eval_dev(ptr, ln, mL, self.shift, cls[j])             # this class's slice of the coset FFT of :387-429
         tick("round3_coset_ffts", t0)

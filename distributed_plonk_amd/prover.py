@@ -219,9 +219,6 @@ class Prover:
             self.w.memcpy_d2d(d_tmp.ptr, src, n * 32)
             self.w.ntt_dev(d_tmp.ptr, dst, n, True, False)
 
-    def _wire_polys_ready(self, wire_polys):
-        """hook: the five blinded wire polynomials exist (round 1, before their commitments); ClassProver starts their class evaluations here"""
-
     def _perm_product(self, alloc, wev, d_id: int, d_idx: int, beta, gamma) -> int:
         """the product vector of dispatcher2.rs:329-344 -> device pointer to its n values"""
         d_prod = alloc(self.n)
@@ -440,7 +437,6 @@ class Prover:
         self._interpolate_many(alloc, [(wev[i], wp[i]) for i in range(5)])
         for i in range(5):
             w.blind_dev(wp[i], n, blinders["wires"][i])
-        self._wire_polys_ready([(wp[i], WP) for i in range(5)])
         proof["wires_poly_comms"] = self._commit_many([(wp[i], WP) for i in range(5)])
         tick("round1", t0)
         # ---- Round 2 (:325-357): permutation product polynomial
