@@ -376,3 +376,26 @@ def test_zero_padded_row_pass_matches_oracle(gpu_workers, oracle, curve, cid, lo
     finally:
         for w in workers[1:]:
             w.close()
+
+
+def test_exchange_standin_and_async_copy(gpu_workers):
+    """The diagnostic exchange of bench.py --simulate-ranks (plonk_exchange_standin: blocks 1 .. S-1 of `send` -> the same blocks of `recv`, device to
+    device on the given stream — the bytes that would cross the fabric; block 0, the rank's own, stays) and plonk_memcpy_d2d_async, both ordered on
+    the context's stream."""
+    import ctypes as C
+    from distributed_plonk_amd import _ffi
+    w = gpu_workers("bn254")
+    S, b = 4, 4096
+    src = np.arange(S * b // 8, dtype=np.uint64)
+    old = np.full(S * b // 8, 0xABCD, dtype=np.uint64)
+    d_s, d_r = w.alloc(S * b).upload(src), w.alloc(S * b).upload(old)
+    _ffi.check(w.lib.plonk_exchange_standin(None, d_s.ptr, d_r.ptr, b, S, w.stream_ptr()))
+    w.sync()
+    got = d_r.download((S * b // 8,))
+    assert np.array_equal(got[b // 8:], src[b // 8:]) and np.array_equal(got[:b // 8], old[:b // 8])
+    fn = C.cast(w.lib.plonk_exchange_standin, _ffi.EXCHANGE_FN)             # usable wherever a plonk_exchange_fn is taken (worker.fft2_prepare passes it through)
+    assert isinstance(fn, _ffi.EXCHANGE_FN) and fn(None, d_s.ptr, d_r.ptr, b, 1, w.stream_ptr()) == 0       # one rank: nothing moves
+    w.memcpy_d2d_async(d_r.ptr, d_s.ptr + b, b)
+    w.sync()
+    assert np.array_equal(d_r.download((b // 8,)), src[b // 8:2 * b // 8])
+    d_s.free(); d_r.free()
