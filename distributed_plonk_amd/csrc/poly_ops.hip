@@ -42,6 +42,7 @@ struct OpMul {               // values: rep-form field elements as F29, normalis
     typedef F29 V;
     static constexpr int WORDS = 9;
     static __device__ __forceinline__ V load(const Fr* p, const PoCtx&) { return f29_from_sat(load_fr(p)); }
+    static __device__ __forceinline__ V from_raw(const Fr& r) { return f29_from_sat(r); }
     static __device__ __forceinline__ void store(Fr* p, const V& v, const PoCtx& c) { store_fr(p, f29_to_sat(f29_canon(v, c.f29))); }
     static __device__ __forceinline__ V comb(const V& a, const V& b, const PoCtx& c) { return f29_mul(a, b, c.f29); }
     static __device__ __forceinline__ V ident(const PoCtx& c) { return params_one(c.f29); }
@@ -60,6 +61,7 @@ struct OpAdd {               // values: canonical Fr
     typedef Fr V;
     static constexpr int WORDS = 8;
     static __device__ __forceinline__ V load(const Fr* p, const PoCtx&) { return load_fr(p); }
+    static __device__ __forceinline__ V from_raw(const Fr& r) { return r; }
     static __device__ __forceinline__ void store(Fr* p, const V& v, const PoCtx&) { store_fr(p, v); }
     static __device__ __forceinline__ V comb(const V& a, const V& b, const PoCtx& c) { return fp_add(a, b, c.fp); }
     static __device__ __forceinline__ V ident(const PoCtx&) { return fp_zero<8>(); }
@@ -121,21 +123,41 @@ __device__ __forceinline__ typename Op::V block_exclusive(const typename Op::V& 
 // logical position q of a scan <-> physical index (suffix scans run over the reversed array)
 __device__ __forceinline__ uint64_t phys_index(uint64_t q, uint64_t n, bool reverse) { return reverse ? n - 1 - q : q; }
 
+// A lane of the scan kernels owns PO_CH CONSECUTIVE elements (the scan is serial in the index).  Their 2 * PO_CH 16-byte loads are issued UP FRONT, into
+// registers, through a compile-time unrolled loop: one after the other with a ~200-instruction product in between, every 64-byte sector was fetched once
+// per 16 bytes used (PMC, round 5: 4x the bytes these kernels need); and an array indexed by a run-time loop counter lives in scratch memory (the
+// pinned multiplier keeps hipcc from unrolling `#pragma unroll` loops around it), so the indices here are template constants.
+template <int K> struct StaticFor {
+    template <class F> static __device__ __forceinline__ void run(F&& f) { StaticFor<K - 1>::run(f); f(std::integral_constant<int, K - 1>()); }
+};
+template <> struct StaticFor<0> {
+    template <class F> static __device__ __forceinline__ void run(F&&) {}
+};
+struct LaneChunk {
+    Fr raw[PO_CH];
+    __device__ __forceinline__ void load(const Fr* in, uint64_t q0, uint64_t n, int reverse) {
+        StaticFor<PO_CH>::run([&](auto k) {
+            constexpr int K = decltype(k)::value;
+            const uint64_t q = q0 + K;
+            raw[K] = q < n ? load_fr(in + phys_index(q, n, reverse)) : fp_zero<8>();
+        });
+    }
+};
+
 template <class Op>
 __global__ void __launch_bounds__(PO_LANES) scan_totals_kernel(const Fr* __restrict__ in, Fr* __restrict__ btot, uint64_t n, int reverse, const PoCtx c) {
     __shared__ uint32_t sh[PO_LANES][9];
     const uint64_t q0 = (uint64_t)blockIdx.x * PO_TILE + (uint64_t)threadIdx.x * PO_CH;
+    LaneChunk ch;
+    ch.load(in, q0, n, reverse);
     typename Op::V acc = Op::ident(c);
-    bool first = true;
-#pragma unroll
-    for (int k = 0; k < PO_CH; k++) {
-        const uint64_t q = q0 + k;
-        if (q < n) {
-            const typename Op::V x = Op::load(in + phys_index(q, n, reverse), c);
-            acc = first ? x : Op::comb(acc, x, c);
-            first = false;
+    StaticFor<PO_CH>::run([&](auto k) {
+        constexpr int K = decltype(k)::value;
+        if (q0 + K < n) {
+            const typename Op::V x = Op::from_raw(ch.raw[K]);
+            acc = K == 0 ? x : Op::comb(acc, x, c);              // q0 < n whenever any element of the lane is valid: element 0 comes first
         }
-    }
+    });
     const typename Op::V tot = block_total<Op, PO_LANES>(acc, sh, c);
     if (threadIdx.x == 0) Op::store(btot + blockIdx.x, tot, c);
 }
@@ -164,24 +186,26 @@ __global__ void __launch_bounds__(PO_LANES) scan_apply_kernel(const Fr* __restri
                                                               const PoCtx c, const Epi epi) {
     __shared__ uint32_t sh[PO_LANES][9];
     const uint64_t q0 = (uint64_t)blockIdx.x * PO_TILE + (uint64_t)threadIdx.x * PO_CH;
-    // The lane's PO_CH elements are read TWICE (the second time from L1 / L2) instead of being kept in an array: with the pinned multiplier the
-    // loops below are not unrolled, and an array indexed by a loop counter lives in scratch memory — 304 B per lane, which the PMC counters of
-    // round 5 showed as 4-5x the algorithmic traffic of these kernels (profiles/r05_poly_rows.txt).
+    // the lane's PO_CH elements: loaded once, up front, kept in registers across both loops (LaneChunk above; profiles/r05_poly_rows.txt has the
+    // PMC history: a run-time indexed array in scratch memory, then elements read twice 16 bytes at a time — 4-5x the algorithmic traffic either way)
+    LaneChunk ch;
+    ch.load(in, q0, n, reverse);
     typename Op::V acc = Op::ident(c);
-    for (int k = 0; k < PO_CH; k++) {
-        const uint64_t q = q0 + k;
-        const typename Op::V xk = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
-        acc = k == 0 ? xk : Op::comb(acc, xk, c);
-    }
+    StaticFor<PO_CH>::run([&](auto k) {
+        constexpr int K = decltype(k)::value;
+        const typename Op::V xk = q0 + K < n ? Op::from_raw(ch.raw[K]) : Op::ident(c);
+        acc = K == 0 ? xk : Op::comb(acc, xk, c);
+    });
     const typename Op::V ex = block_exclusive<Op, PO_LANES>(acc, sh, c, nullptr);
     typename Op::V run = Op::comb(Op::load(boff + blockIdx.x, c), ex, c);
-    for (int k = 0; k < PO_CH; k++) {
-        const uint64_t q = q0 + k;
-        const typename Op::V xk = q < n ? Op::load(in + phys_index(q, n, reverse), c) : Op::ident(c);
+    StaticFor<PO_CH>::run([&](auto k) {
+        constexpr int K = decltype(k)::value;
+        const uint64_t q = q0 + K;
+        const typename Op::V xk = q < n ? Op::from_raw(ch.raw[K]) : Op::ident(c);
         if (inclusive) run = Op::comb(run, xk, c);
         if (q < n) epi(run, phys_index(q, n, reverse), c);
         if (!inclusive) run = Op::comb(run, xk, c);
-    }
+    });
 }
 
 template <class Op>
@@ -375,6 +399,7 @@ int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm
     Fr* kconst = (Fr*)s; s += 64;
     uint32_t* flag = (uint32_t*)s;
     HIP_TRY(hipMemsetAsync(flag, 0, 4, stream));
+    bool zero_den = false;                    // the product of all denominators vanished (found by the host-side inversion)
     const PoCtx c = make_ctx(T);
     PermParams q;
     memset(&q, 0, sizeof q);
@@ -395,12 +420,18 @@ int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm
         const uint64_t nb = tiles_of(n);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_totals_kernel<OpMul>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)B, btot, (uint64_t)n, 1, c);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_top_kernel<OpMul>), dim3(1), dim3(PO_TOP), 0, stream, (const Fr*)btot, boff, total, nb, c);
-        Fr pm2;
-        uint64_t br = 2;
-        for (int i = 0; i < 8; i++) { uint64_t t = (uint64_t)P.p[i] - br; pm2.l[i] = (uint32_t)t; br = (t >> 32) & 1; }
-        Fr r256;
-        for (int i = 0; i < 8; i++) r256.l[i] = P.one[i];
-        hipLaunchKernelGGL(fr_inv_kernel, dim3(1), dim3(64), 0, stream, (const Fr*)total, kconst, flag, c, f29_from_sat(pm2), f29_from_sat(r256));
+        // 1 / (product of all denominators): ONE inversion per call.  On the host (round 5): 32 bytes down, fp_inv, 32 bytes up — ~40 us of round trip
+        // against 0.41 ms of a single lane walking 520 dependent products (fr_inv_kernel, kept for reference).  `total` holds D * 2^261 as plain limbs;
+        // kconst = 2^256 / D = 2^517 / total: fp_inv reads `total` as the Montgomery form of total / 2^256 and returns 2^512 / total, then five doublings.
+        Fr h_total;
+        HIP_TRY(hipMemcpyAsync(&h_total, total, sizeof(Fr), hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        bool zero_total = fp_is_zero(h_total);
+        Fr h_k = zero_total ? fp_zero<8>() : fp_inv(h_total, P);
+        for (int i = 0; i < 5; i++) h_k = fp_add(h_k, h_k, P);
+        HIP_TRY(hipMemcpyAsync(kconst, &h_k, sizeof(Fr), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));                                 // h_k is a stack object
+        zero_den = zero_total;
         ProfScope ps("perm_scan_den_final", stream);
         hipLaunchKernelGGL(HIP_KERNEL_NAME(scan_apply_kernel<OpMul, EpiPermFinal>), dim3((uint32_t)nb), dim3(PO_LANES), 0, stream, (const Fr*)B, (const Fr*)boff,
                            (uint64_t)n, 1, 1, c, EpiPermFinal{PN, kconst, (Fr*)d_out});
@@ -410,6 +441,7 @@ int perm_product_run(NttTables& T, const void* const* wires, const void* id_perm
     uint32_t h_flag = 0;
     HIP_TRY(hipMemcpyAsync(&h_flag, flag, 4, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
+    if (zero_den) h_flag |= 1;
     if (h_flag & 2) return plonk_fail(PLONK_ERR_ARG, "perm_product: permutation index out of range (>= 5n)");
     if (h_flag & 1) return plonk_fail(PLONK_ERR_ARG, "perm_product: zero denominator (the reference panics on this division, dispatcher2.rs:343)");
     return PLONK_OK;
