@@ -256,11 +256,28 @@ class ClassProver(Prover):
         cnt = hi - lo
         last = hi == n                               # nobody multiplies by the last slice's total
         d_loc = alloc(cnt + 1)
-        w.perm_product_range_dev(wev, d_id, d_idx, beta, gamma, n, lo, cnt + (0 if last else 1), d_loc.ptr)
-        total = self.f.to_limbs(1) if last else w.read_bytes(d_loc.ptr + cnt * 32, 32).view(np.uint64).copy()
+        # A zero denominator or an out-of-range permutation index shows up only on the rank whose gate slice holds it (the reference panics,
+        # dispatcher2.rs:338-343).  Raising here, BEFORE the collective, would leave the other ranks waiting in it for ever: the failure travels
+        # as a status word beside the 32-byte slice total, and every rank raises the same error after the all-gather.
+        failure = None
+        try:
+            w.perm_product_range_dev(wev, d_id, d_idx, beta, gamma, n, lo, cnt + (0 if last else 1), d_loc.ptr)
+            total = self.f.to_limbs(1) if last else w.read_bytes(d_loc.ptr + cnt * 32, 32).view(np.uint64).copy()
+        except Exception as ex:     # noqa: BLE001 - re-raised below, on every rank
+            failure, total = ex, self.f.to_limbs(1)
+        word = np.zeros((1, 8), dtype=np.uint64)
+        word[0, :4] = np.asarray(total, dtype=np.uint64).reshape(-1)[:4]
+        word[0, 4] = 0 if failure is None else 1
+        gathered = [np.asarray(part, dtype=np.uint64).reshape(-1) for part in self.comm.all_gather_host(word)]
+        failed = [r for r, part in enumerate(gathered) if int(part[4]) != 0]
+        if failed:
+            if failure is not None:
+                raise failure
+            raise ZeroDivisionError(f"permutation product: rank(s) {failed} reported a zero denominator or an out-of-range permutation index "
+                                    f"in their gate range (the reference panics, dispatcher2.rs:338-343)")
         pre = 1
-        for part in self.comm.all_gather_host(np.ascontiguousarray(total, dtype=np.uint64).reshape(1, 4))[:s]:
-            pre = pre * f.from_limbs(np.asarray(part).reshape(-1)[:4]) % f.p
+        for part in gathered[:s]:
+            pre = pre * f.from_limbs(part[:4]) % f.p
         d_send = alloc(cnt)
         w.poly_lincomb_dev([(d_loc.ptr, cnt)], f.vec_to_limbs([pre]), d_send.ptr, cnt)
         d_prod = alloc(n)

@@ -136,6 +136,44 @@ def test_class_prover_with_transcript_and_bad_witness(oracle):
     assert _same_point(results[G - 1][0]["shifted_opening_proof"], want["shifted_opening_proof"])
 
 
+def test_a_failure_in_one_gate_range_is_raised_on_every_rank(oracle):
+    """an out-of-range permutation index lives in ONE rank's gate slice.  That rank must not raise before the
+    all-gather of the slice totals (its peers would wait in the collective for ever): the status travels with the totals and every rank
+    raises after it — no rank is left with a broken barrier or a hang."""
+    import threading
+    log_n, G = 6, 4
+    P, circ, ck, inf, bl, ch = _instance(oracle, 0, log_n, 750)
+    n = 1 << log_n
+    bad_idx = circ["perm_idx"].copy()
+    bad_idx[2] = 5 * n + 9                                   # wire 0, gate 2: rank 0's range only
+
+    def rank_main(comm, w):
+        w.init(ck, n, 8 * n)
+        pv = ClassProver(w, log_n, comm)
+        try:
+            pv.load_key(circ["selectors"], circ["sigmas"], circ["k"])
+            try:
+                pv.prove(circ["wires"], circ["id_perm"], bad_idx, circ["pub_input"], bl, lambda label, _: ch[label])
+            except threading.BrokenBarrierError:
+                raise
+            except Exception as ex:     # noqa: BLE001 - what the test is about
+                first = (type(ex).__name__, str(ex))
+            else:
+                first = None
+            # and the communicator is still usable: the good circuit proves right after
+            good = pv.prove(circ["wires"], circ["id_perm"], circ["perm_idx"], circ["pub_input"], bl, lambda label, _: ch[label])
+            return first, good
+        finally:
+            pv.close()
+
+    results = run_local_ranks(G, rank_main)
+    want = P.prove_rounds(0, log_n, ck, inf, circ, bl, ch, threads=8)
+    for r, (first, good) in enumerate(results):
+        assert first is not None, f"rank {r} did not see the failure of rank 0's gate range"
+        assert _same_point(good["opening_proof"], want["opening_proof"])
+    assert "rank(s) [0]" in results[1][0][1] and "rank(s) [0]" in results[G - 1][0][1]
+
+
 def test_class_prover_over_rccl_single_rank(gpu_workers, oracle):
     """The torch.distributed transport (nccl = RCCL) on the library's stream, world size 1: G = 1 is the degenerate class
     decomposition (one class = the whole coset), exercising all_to_all_single / all_gather_into_tensor / all_gather_object."""

@@ -1,5 +1,6 @@
-"""HIP path vs the committed golden fixtures (tests/golden/*.json, generated by tools/gen_golden.py from the
-pure-Python big-int statement) — and the arkworks in-memory SRS layout that `init` receives on the wire."""
+"""HIP path vs the committed golden fixtures (tests/golden/*.json from tools/gen_golden.py = the repo's own big-int statement;
+tests/golden/sympy_*.json from tools/gen_golden_sympy.py = THIRD-PARTY sympy transforms and group law; and sympy live) — and the
+arkworks in-memory SRS layout that `init` receives on the wire."""
 import numpy as np
 import pytest
 
@@ -119,3 +120,102 @@ def test_init_refuses_a_mislaid_srs(gpu_workers, oracle, curve, cid):
     got, gi = w.g1_to_affine(w.var_msm(MsmWorkload(0, n), sc))
     exp, ei = oracle.jac_to_affine(cid, oracle.msm(cid, bases, sc, threads=4))
     assert gi == ei and np.array_equal(got, exp)
+
+
+# ---- third-party expected values (tools/gen_golden_sympy.py): sympy's transform and group law, not this repository's restatement -----
+
+def _same_point(w, jac, P):
+    q = w.q64
+    xy, isinf = w.g1_to_affine(jac)
+    want, winf = G.point_limbs(P, q)
+    return (isinf and winf) or (not isinf and not winf and np.array_equal(xy, want))
+
+
+def _jac(w, oracle_one, P):
+    q = w.q64
+    xy, inf = G.point_limbs(P, q)
+    if inf:
+        return np.concatenate([oracle_one, oracle_one, np.zeros(q, dtype=np.uint64)])        # arkworks' zero (1, 1, 0)
+    return np.concatenate([xy, oracle_one])
+
+
+@pytest.mark.parametrize("curve", ["bn254", "bls12_381"])
+def test_sympy_generated_fixtures(gpu_workers, curve):
+    """The HIP path against tests/golden/sympy_*.json: every transform mode for 2 ... 2^6 points element by element, 2^7 ... 2^12 by
+    SHA-256 of the output bytes, the device group law (P + Q, P + P, P - P, identity) and MSMs with an infinity base, duplicated
+    bases, P / -P pairs, scalars 0 / 1 / r - 1 and the reference's tiled-bases shape (dispatcher.rs:190-200)."""
+    w = gpu_workers(curve)
+    doc = G.load_sympy(curve)
+    r, qmod, q = int(doc["fr_modulus"], 16), int(doc["fq_modulus"], 16), w.q64
+    for e in doc["ntt"]:
+        v = G.limbs(e["input_mont"])
+        for key, (inv, coset) in KEYS.items():
+            assert np.array_equal(w.ntt(v, inv, coset), G.limbs(e[key])), (e["log_n"], key)
+    for e in doc["ntt_digest"]:
+        v = G.mont_limbs(G.sympy_ntt_input(doc, e["log_n"]), r)
+        assert G.sha256_limbs(v) == e["input_sha256"]
+        for key, (inv, coset) in KEYS.items():
+            assert G.sha256_limbs(w.ntt(v, inv, coset)) == e[key + "_sha256"], (e["log_n"], key)
+    one = G.limbs([hex((1 << (64 * q)) % qmod)], q)[0]
+    for e in doc["group"]:
+        if e["op"] == "add":
+            assert _same_point(w, w.g1_add(_jac(w, one, e["a"]), _jac(w, one, e["b"])), e["out"]), e
+        elif int(e["k"], 16) < r:                                  # k * P as a one-term MSM (var_msm takes canonical scalars)
+            bases, inf = G.bases_from_golden({"bases_mont": [e["a"]]}, q)
+            w.init(bases, 0, 0)
+            assert _same_point(w, w.var_msm(MsmWorkload(0, 1), G.limbs([e["k"]])), e["out"]), e
+    for e in doc["msm"]:
+        bases, inf = G.bases_from_golden(e, q)
+        sc = G.limbs(e["scalars"])
+        w.init(bases, 0, 0)                                       # infinity = (0, 0) in the XY layout
+        assert _same_point(w, w.var_msm(MsmWorkload(0, len(sc)), sc), e["result_affine_mont"]), e["case"]
+        # sharded by index range like dispatcher.rs:218-238, partial points added on the device
+        acc = None
+        step = (len(sc) + 2) // 3
+        for s in range(0, len(sc), step):
+            part = w.var_msm(MsmWorkload(s, min(s + step, len(sc))), sc[s:s + step])
+            acc = part if acc is None else w.g1_add(acc, part)
+        assert _same_point(w, acc, e["result_affine_mont"]), (e["case"], "sharded")
+
+
+@pytest.mark.parametrize("curve,b", [("bn254", 3), ("bls12_381", 4)])
+def test_hip_equals_sympy_live(gpu_workers, curve, b):
+    """No oracle and no fixture in between: fresh inputs, sympy computes the expected transform and the expected MSM point here."""
+    sympy = pytest.importorskip("sympy")
+    import random
+    from sympy.discrete.transforms import intt, ntt
+    from sympy.ntheory import primitive_root
+    from sympy.ntheory.elliptic_curve import EllipticCurve
+    w = gpu_workers(curve)
+    doc = G.load_sympy(curve)
+    r, qmod, q = int(doc["fr_modulus"], 16), int(doc["fq_modulus"], 16), w.q64
+    g = primitive_root(r)
+    ginv = pow(g, r - 2, r)
+    rng = random.Random()                                          # unseeded on purpose; the inputs are printed on failure
+    for log_n in (1, 4, 9, 11, 13):
+        a = [rng.randrange(r) for _ in range(1 << log_n)]
+        v = G.mont_limbs(a, r)
+        want = {"fft": ntt(a, r), "ifft": intt(a, r), "coset_fft": ntt([x * pow(g, i, r) % r for i, x in enumerate(a)], r),
+                "coset_ifft": [x * pow(ginv, i, r) % r for i, x in enumerate(intt(a, r))]}
+        for key, (inv, coset) in KEYS.items():
+            assert np.array_equal(w.ntt(v, inv, coset), G.mont_limbs(want[key], r)), (log_n, key, a[:4])
+    E = EllipticCurve(0, b, modulus=qmod)
+    gen = E(1, 2) if curve == "bn254" else E(
+        0x17f1d3a73197d7942695638c4fa9ac0fc3688c4f9774b905a14e3a3f171bac586c55e83ff97a1aeffb3af00adb22c6bb,
+        0x08b3f481e3aaa0f1a09e30ed741d8ae4fcf5e095d5d00af600db18cb2c04b3edd03cc744a2888ae40caa232946c5e7e1)
+    n = 16
+    ks = [rng.randrange(1, r) for _ in range(n)]
+    pts = [k * gen for k in ks]
+    sc = [rng.randrange(r) for _ in range(n)]
+    acc = E(0, 1, 0)
+    for P, k in zip(pts, sc):
+        acc = acc + k * P
+    bases = np.zeros((n, 2 * q), dtype=np.uint64)
+    for i, P in enumerate(pts):
+        bases[i, :q] = G.mont_limbs([int(P.x / P.z)], qmod, q)[0]
+        bases[i, q:] = G.mont_limbs([int(P.y / P.z)], qmod, q)[0]
+    w.init(bases, 0, 0)
+    xy, isinf = w.g1_to_affine(w.var_msm(MsmWorkload(0, n), G.limbs([hex(k) for k in sc])))
+    assert not isinf, (ks, sc)
+    assert np.array_equal(xy[:q], G.mont_limbs([int(acc.x / acc.z)], qmod, q)[0]), (ks, sc)
+    assert np.array_equal(xy[q:], G.mont_limbs([int(acc.y / acc.z)], qmod, q)[0]), (ks, sc)
