@@ -9,8 +9,10 @@ the reference prover issues per proof (/root/reference/src/dispatcher2.rs:294-69
     1  coset-iNTT of size 8n       (quotient)
     13 KZG commitments             (into_repr + n-point MSM each)
 
-metric = constraints/sec = n / (time of one step); ms_per_step is the proof-equivalent hot-path time.  `proof_ms` beside it is a REAL
-proof of a satisfied 2^log_n-gate circuit (the five rounds of dispatcher2.rs:296-712), accepted by a verifier.
+Since round 6 the HEADLINE is the proof itself: a step of the timed region = ONE real five-round proof of a satisfied 2^log_n-gate circuit
+(dispatcher2.rs:192-713: 13 commitments, 7 NTT(n), 26 NTT(8n), grand product, quotient, evaluations, openings, merlin transcript), K of them
+between barriers, the last one accepted by a verifier after the timed region; metric = constraints/sec = n / (time of one proof).  The op mix
+above, on its own seeded inputs, is measured first as `op_mix` (the headline of rounds 1-5; `--headline op-mix` times only that).
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--log-n 24] [--curve bn254]
 
@@ -36,43 +38,6 @@ from benchlib import HBM_PEAK_GBS, N_MSM, N_NTT_BIG, N_NTT_SMALL, POLY_OP_COST, 
 from benchlib.cli import parse, plan  # noqa: E402
 
 
-def _single_gpu_legs(b, out, args):
-    """rank 0, N == 1, after the headline: checks against the oracle, the next rows, the verified proof"""
-    from benchlib import legs_single as L
-    if not args.no_verify:
-        ver = run_leg(None, "verify", None, lambda: L.verify_single(b))       # a failed check must be visible, never fatal to the measurement
-        out["verification"] = ver
-        out["verified"] = "error" not in ver and all(ver.values())
-    next_rows = {}
-    if args.next_rows == "all":
-        next_rows.update(run_leg(None, "quotient_row", None, lambda: L.quotient_row(b), error=lambda ex: {"error": str(ex)}))
-    if args.next_rows in ("all", "proof"):
-        full = args.next_rows == "all"
-        res = run_leg(None, "prover_rounds", None, lambda: L.prover_rounds(b, with_small_rows=full, with_variants=full), error=lambda ex: ({}, {"error": repr(ex)}))
-        next_rows.update(res[0])
-        next_rows["prover_rounds"] = res[1]
-    return next_rows or None
-
-
-def _proof_fields(out, next_rows, class_row):
-    """the REAL proof at top level (BASELINE's metric is "proof-gen ms"): the five rounds of dispatcher2.rs:296-712 on the 8n route
-    with the proving key NOT resident — the reference's work — on the satisfied synthetic circuit, verified; `value` stays on
-    the SURVEY §8d op mix for continuity with rounds 1-3.  Same-proof variants beside it, labelled."""
-    pr = (next_rows or {}).get("prover_rounds") or {}
-    if "ms" in pr:
-        out["proof_ms"] = pr["ms"]
-        out["proof_constraints_per_s"] = pr["constraints_per_s"]
-        out["prover_verified"] = pr.get("prover_verified")
-        names = {"resident_key_cosets": "8n_route_key_coset_vectors_resident_in_HBM", "six_cosets": "six_coset_quotient_key_not_resident",
-                 "six_cosets_resident_key": "six_coset_quotient_key_resident",
-                 "key_coset_ffts_beside_rounds_1_2": "8n_route_key_not_resident_key_coset_ffts_on_a_third_context_beside_rounds_1_2",
-                 "key_coset_ffts_inside_round_3": "8n_route_key_not_resident_key_coset_ffts_inside_round_3"}
-        out["proof_variants_ms"] = dict({"8n_route_key_not_resident (the reference's work; = proof_ms; key coset FFTs %s)" % pr.get("key_coset_ffts", "inside round 3"): pr["ms"]},
-                                        **{names[k_]: v_.get("ms") for k_, v_ in (pr.get("variants") or {}).items()})
-    if class_row and "ms" in class_row:
-        out["proof_ms_class_prover_all_ranks"] = class_row["ms"]
-
-
 def main():
     args = parse()
     if args.dry_run:
@@ -84,62 +49,8 @@ def main():
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    from benchlib import headline, legs_multi as M
-    from benchlib.run import Bench
-
-    b = Bench(args)
-    guard = ResultLine(json_fd, b.rank, None)
-    dt, phases_ms = headline.timed_steps(b, guard)
-    # ---- the result line exists from here on: the headline is measured, everything below only ADDS fields to it, each leg in its own
-    # try/except; on N > 1 (never run on more than one real GPU: gpurun grants one) also under a watchdog: should a leg hang in a
-    # collective, rank 0 still prints the headline (with `aborted_optional_leg` naming the leg) and every rank exits 0.
-    out = headline.result_line(b, dt, phases_ms)
-    guard.arm(None, 0)
-    guard.out = out
-    rank0 = b.rank == 0
-    LEG = float(os.environ.get("PLONK_BENCH_LEG_BUDGET_S", "300"))
-    multi, sim, nbig = b.multi, b.sim, b.nbig
-
-    other = None
-    if multi and not sim and nbig:
-        other = run_leg(guard, "other_scheme", LEG, lambda: M.other_scheme(b))
-        if rank0:
-            out["other_scheme"] = other
-    if multi and nbig and not args.no_poly_parallel:
-        pp = run_leg(guard, "polynomial_parallel", LEG, lambda: M.polynomial_parallel(b), error=lambda ex: {"scheme": "polynomial_parallel", "error": repr(ex)})
-        if rank0:
-            out["polynomial_parallel"] = pp
-            if not sim:
-                # the three ways to spread the step over the ranks, side by side (`value` is always the first: the reference's scheme)
-                out["schemes_ms_per_step"] = {b.scheme: out.get("ms_per_step"), **({other["scheme"]: other.get("ms_per_step")} if other and "scheme" in other else {}),
-                                              "polynomial_parallel": pp.get("ms_per_step")}
-    if multi and not sim and not args.no_verify:
-        mv = run_leg(guard, "verify_multi", LEG, lambda: M.verify_multi(b))
-        if rank0:
-            out["verification"] = mv
-            out["verified"] = bool(mv) and "error" not in mv and all(mv.values())
-
-    single = rank0 and b.world == 1 and not multi and not sim
-    next_rows = _single_gpu_legs(b, out, args) if single else None
-    class_row = None
-    if (args.class_prover or multi or sim) and not args.no_class_prover and nbig:
-        class_row = run_leg(guard, "class_prover", 2 * LEG, lambda: M.class_prover(b))   # every rank raises or none does (same sizes everywhere)
-    cpu = None
-    if single and not args.no_cpu_baseline:
-        from benchlib.cpu_baseline import cpu_baseline
-        cpu = run_leg(None, "cpu_baseline", None, lambda: cpu_baseline(b))
-    if rank0:
-        out["cpu_baseline"] = cpu
-        out["next_rows"] = dict(next_rows or {}, class_prover=class_row) if class_row else next_rows
-        _proof_fields(out, next_rows, class_row)
-    if b.world > 1:
-        guard.emit()                             # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
-        guard.arm("teardown", 120.0)
-    b.close()
-    if single and not args.no_other_configs and args.log_n == 24 and args.curve == "bn254" and not args.dense_coset:
-        from benchlib.other_configs import other_configs
-        out["other_configs"] = run_leg(None, "other_configs", None, lambda: other_configs(args), error=lambda ex: [{"error": repr(ex)}])
-    guard.emit()
+    from benchlib.program import run
+    run(args, json_fd)
 
 
 if __name__ == "__main__":

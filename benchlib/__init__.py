@@ -1,10 +1,11 @@
 """bench.py's parts (one function per leg, every optional leg in its own try/except):
 
+    program.py        the run, stage by stage: op-mix step, the proof loop that takes the headline over, the legs, the CPU baseline last
     cli.py            argument parsing, the no-GPU plan (--dry-run)
     run.py            Bench: process group, contexts, resident synthetic inputs, the proof-equivalent step
-    headline.py       the timed region, per-kernel HIP-event times, the roofline, the result line
-    legs_single.py    N == 1 legs after the headline: verification against the oracle, next rows, the verified proof
-    legs_multi.py     N > 1 legs after the headline: other scheme, polynomial-level parallelism, verification, class prover
+    headline.py       the timed regions (op-mix steps, proofs), per-kernel HIP-event times, the roofline, the result line
+    legs_single.py    N == 1: SingleProof (what the headline times) and the legs after it: verification against the oracle, next rows, variants
+    legs_multi.py     N > 1: ClassProof (what the headline times) and the legs: other scheme, polynomial-level parallelism, verification
     cpu_baseline.py   the oracle timed on the host cores (reported baseline)
     other_configs.py  BASELINE.json configs[1] / configs[3] as short sub-runs
     line.py           ResultLine (one JSON line + watchdog), run_leg

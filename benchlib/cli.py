@@ -19,6 +19,10 @@ def parse():
     ap.add_argument("--n-domain-only", action="store_true",
                     help="BASELINE.json configs[4] (2^28-gate BN254: 'HBM-resident witness' sizing stress): the 8n quotient domain of such a circuit "
                          "does not exist on BN254 (two-adicity 28), so only the n-domain part of the step runs - 7 iNTT(n) + 13 commitments(n)")
+    ap.add_argument("--headline", default="proof", choices=["proof", "op-mix"],
+                    help="what the K timed steps are.  'proof' (default): K real five-round proofs of a satisfied synthetic circuit (N == 1: prover.py; N > 1: "
+                         "the coset-class prover on all ranks), verified after the timed region; the op-mix step is then measured first, as a short run of its "
+                         "own (`op_mix`).  'op-mix': K op-mix steps only (the headline of rounds 1-5; what the PMC collection profiles)")
     ap.add_argument("--no-verify", action="store_true", help="skip the post-run result checks (`verified` becomes null)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--next-rows", default="all", choices=["all", "proof", "none"],
@@ -30,7 +34,11 @@ def parse():
     ap.add_argument("--cpu-sample-log-n", type=int, default=20, help="cpu_baseline: log2 of the first measured sample (every op of the step once)")
     ap.add_argument("--cpu-sample-log-n2", type=int, default=22,
                     help="cpu_baseline: log2 of the second, larger measured sample (the single-threaded transforms and the commitment once each, ~25 s); "
-                         "the two give the fitted exponent behind `value_at_bench_size`.  0 = one sample only")
+                         "the two give the fitted exponent that is reported beside the full-size measurement.  0 = one sample only")
+    ap.add_argument("--cpu-full-size", default="auto", choices=["auto", "on", "off"],
+                    help="cpu_baseline: ALSO run every op of the step once at the bench size itself (2^24: ~90 s of host time, 10 GiB of host memory), so "
+                         "that `cpu_baseline.value` is a MEASUREMENT at the GPU line's size (`extrapolated: false`) with the smaller samples kept beside it.  "
+                         "'auto' = on when the host has the memory for it; 'off' = rounds 4-5's fitted extrapolation")
     ap.add_argument("--no-poly-parallel", action="store_true",
                     help="N > 1: skip the polynomial-level-parallel leg (whole operations per rank, no data-path collective; SURVEY §8e's alternative)")
     ap.add_argument("--simulate-ranks", type=int, default=0,

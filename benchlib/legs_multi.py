@@ -1,6 +1,6 @@
 """Optional legs of an N > 1 run (and of its one-GPU diagnostics --multi-path / --simulate-ranks), all AFTER and OUTSIDE the timed region:
 the other distribution scheme, polynomial-level parallelism ("report both"), the verification of the distributed code path
-against single-rank recomputation, and the five prover rounds with the coset-class prover.  Every function returns the dict that goes into
+against single-rank recomputation — and ClassProof, the five prover rounds with the coset-class prover that the N > 1 headline times.  Every function returns the dict that goes into
 the line (every rank executes it: the legs contain collectives); bench.py stores it on rank 0."""
 import os
 import threading
@@ -318,106 +318,126 @@ class _SimComm:
         self.b.sim_allgather(self.w, d_send, d_recv, nbytes, force=self.fill)
 
 
-def class_prover(b):
-    """The five prover rounds on ALL ranks with the coset-class decomposition (class_prover.py): the same satisfied synthetic
-    instance on every rank (generated in HBM from the seed), the commit key sharded over the ranks (dispatcher2.rs:260-266), real
-    transcript on every rank, degree check on; rank 0 hands the proof to the trapdoor verifier.  Default for N > 1.
-    --simulate-ranks S: rank 0's share of an S-rank proof on ONE GPU with no-op collectives (garbage proof, compute time only)."""
-    from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
-    from distributed_plonk_amd.synthetic import SyntheticInstance
-    from distributed_plonk_amd.transcript import PlonkTranscript
-    args, np, dist, w, n, m, sim, world = b.args, b.np, b.dist, b.w, b.n, b.m, b.sim, b.world
-    b.release_step_buffers()
-    if world == 1 and not dist.is_initialized() and not sim:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29653")
-        dist.init_process_group(rank=0, world_size=1, **b.pg_kwargs)
-    fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-    TAU = TAU_SEED % fld.p
-    G_, r_ = (sim, 0) if sim else (world, b.rank)
-    inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, init_worker=False)
-    klo, khi = key_shard_range(inst.key_size, r_, G_)                                     # a rank KEEPS only its slice of the key
-    for x in b.workers[:2]:
-        x.init_dev(inst.d_ck.ptr + klo * 16 * b.q64, khi - klo, n, m)
-    consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-    bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-    if sim:
-        comm = _SimComm(G_, b, w)
-    elif b.transport == "rccl" and b.multi:
-        def _boot(obj):
-            out_ = [None] * world
-            dist.all_gather_object(out_, obj)
-            return out_
-        comm = LibComm(w, bootstrap=_boot)
-    else:
-        comm = TorchComm(w, None if b.emulated else b.dev)
-    # the key's 18 class evaluations on a third context beside rounds 1-2 (ClassProver(fft_helper=...)): one of the step's transform contexts when the
-    # run has them (--overlap-phases), PLONK_CLASS_FFT_HELPER=0 / 1 overrides the default
-    want_helper = os.environ.get("PLONK_CLASS_FFT_HELPER", CLASS_FFT_HELPER_DEFAULT) == "1"
-    fft_helper = b.step_workers[0] if (want_helper and b.step_workers) else None
-    cp = ClassProver(w, args.log_n, comm, commit_helper=b.workers[1], key_range=(klo, khi), fft_helper=fft_helper)
-    cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-    pub = inst.public_inputs()
-    vk = cp.verifying_key()                                                               # 18 sharded commitments, once per key
-    t_cls, proof_c = None, None
-    for it in range(2):
-        fs = cp.fiat_shamir(pub)
+class ClassProof:
+    """The run's REAL proof on ALL ranks (N > 1, and its one-GPU diagnostics): the five prover rounds with the coset-class decomposition
+    (class_prover.py) — the same satisfied synthetic instance on every rank (generated in HBM from the seed), the commit key sharded over the
+    ranks (dispatcher2.rs:260-266), real transcript on every rank, degree check on.  `prove()` is one proof; bench.py times W + K of them as the
+    headline of an N > 1 run and rank 0 hands the last one to the trapdoor verifier (`finish`).
+    --simulate-ranks S: rank 0's share of an S-rank proof on ONE GPU with stand-in collectives (garbage proof, one rank's time)."""
+
+    def __init__(self, b):
+        from distributed_plonk_amd.class_prover import ClassProver, LibComm, TorchComm, key_shard_range
+        from distributed_plonk_amd.synthetic import SyntheticInstance
+        args, np, dist, w, n, m, sim, world = b.args, b.np, b.dist, b.w, b.n, b.m, b.sim, b.world
+        self.b = b
+        b.release_step_buffers()
+        if world == 1 and not dist.is_initialized() and not sim:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29653")
+            dist.init_process_group(rank=0, world_size=1, **b.pg_kwargs)
+        fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
+        self.TAU = TAU_SEED % fld.p
+        self.G, r_ = (sim, 0) if sim else (world, b.rank)
+        self.inst = inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=self.TAU, init_worker=False)
+        self.key_range = klo, khi = key_shard_range(inst.key_size, r_, self.G)              # a rank KEEPS only its slice of the key
+        for x in b.workers[:2]:
+            x.init_dev(inst.d_ck.ptr + klo * 16 * b.q64, khi - klo, n, m)
+        consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
+        self.bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
         if sim:
-            comm.fill = it == 0
-        b.full_sync()
-        t0 = time.perf_counter()
-        proof_c = cp.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=not sim)
-        b.full_sync()
-        t_cls = (time.perf_counter() - t0) * 1e3
-    t_cls = b.max_over_ranks(t_cls)
-    rounds_ms = {k_: round(v_, 2) for k_, v_ in cp.timings.items()}
-    bytes_out_per_proof = comm.bytes_out // 2 if sim else None
-    r12 = "replicated (PLONK_CLASS_REPLICATED_R12=1 or one rank)" if cp.replicated_r12 else "size-n iFFTs by residue class, grand product by gate range"
-    cp.close()                                   # its work buffers (~150 GB at 2^24 on ONE rank) must go before the variant allocates its own
-    # the same proof with this rank's class evaluations of the 18 proving-key polynomials resident (9.7 GB per rank at 2^24 / 8 ranks): a labelled
-    # variant, like the single-GPU prover's resident_key_cosets — the reference re-transforms the key every proof
-    t_res, same = None, None
-    try:
-        cpr = ClassProver(w, args.log_n, comm, commit_helper=b.workers[1], key_range=(klo, khi), cache_key_cosets=True)
-        cpr.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-        cpr._key["vk"] = vk
-        pr = None
-        for it in range(2):
-            fsr = cpr.fiat_shamir(pub)
-            if sim:
-                comm.fill = it == 0
-            b.full_sync()
-            t0 = time.perf_counter()
-            pr = cpr.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fsr, check_degree=not sim)
-            b.full_sync()
-            t_res = (time.perf_counter() - t0) * 1e3
-        t_res = b.max_over_ranks(t_res)
-        same = None if sim else bool(all(np.array_equal(pr[k_][0], proof_c[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof")))     # (a simulated rank proves garbage)
-        cpr.close()
-    except Exception as ex:     # noqa: BLE001 - a variant is a side note of a side leg
-        t_res = None
-        same = repr(ex)
-    cverified = None
-    if b.rank == 0 and not sim and not args.no_verify:
+            self.comm = _SimComm(self.G, b, w)
+        elif b.transport == "rccl" and b.multi:
+            def _boot(obj):
+                out_ = [None] * world
+                dist.all_gather_object(out_, obj)
+                return out_
+            self.comm = LibComm(w, bootstrap=_boot)
+        else:
+            self.comm = TorchComm(w, None if b.emulated else b.dev)
+        # the key's 18 class evaluations on a third context beside rounds 1-2 (ClassProver(fft_helper=...)): one of the step's transform contexts when the
+        # run has them (--overlap-phases), PLONK_CLASS_FFT_HELPER=0 / 1 overrides the default
+        want_helper = os.environ.get("PLONK_CLASS_FFT_HELPER", CLASS_FFT_HELPER_DEFAULT) == "1"
+        self.fft_helper = b.step_workers[0] if (want_helper and b.step_workers) else None
+        self.cp = ClassProver(w, args.log_n, self.comm, commit_helper=b.workers[1], key_range=(klo, khi), fft_helper=self.fft_helper)
+        self.cp.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+        self.pub = inst.public_inputs()
+        self.vk = self.cp.verifying_key()                                                  # 18 sharded commitments, once per key
+        self.proof = None
+        self.n_proofs = 0
+        # set-up, never timed: the first proof allocates the work buffers; under --sim-exchange none it still moves the stand-in's bytes so that the
+        # receive buffers the later proofs reuse hold field elements and not the zeros of a fresh allocation (_SimComm.fill)
+        self.prove()
+        self.bytes_out_setup = self.comm.bytes_out if sim else 0
+
+    def prove(self):
+        cp, inst, b = self.cp, self.inst, self.b
+        fs = cp.fiat_shamir(self.pub)
+        if b.sim:
+            self.comm.fill = self.n_proofs == 0
+        self.proof = cp.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, self.bl, fs, check_degree=not b.sim)
+        self.n_proofs += 1
+        return cp.timings
+
+    @property
+    def overlapped(self):
+        return self.fft_helper is not None
+
+    def finish(self, proof_ms, rounds_ms):
+        """after the timed proofs: the resident-key variant, the verifier on rank 0 -> the row under next_rows.class_prover"""
+        from distributed_plonk_amd.class_prover import ClassProver
+        from distributed_plonk_amd.transcript import PlonkTranscript
+        b, cp, inst, comm = self.b, self.cp, self.inst, self.comm
+        args, np, n, sim = b.args, b.np, b.n, b.sim
+        G_ = self.G
+        bytes_out_per_proof = (comm.bytes_out - self.bytes_out_setup) // max(self.n_proofs - 1, 1) if sim else None
+        r12 = "replicated (PLONK_CLASS_REPLICATED_R12=1 or one rank)" if cp.replicated_r12 else "size-n iFFTs by residue class, grand product by gate range"
+        proof_c = self.proof
+        cp.close()                                   # its work buffers (~150 GB at 2^24 on ONE rank) must go before the variant allocates its own
+        # the same proof with this rank's class evaluations of the 18 proving-key polynomials resident (9.7 GB per rank at 2^24 / 8 ranks): a labelled
+        # variant, like the single-GPU prover's resident_key_cosets — the reference re-transforms the key every proof
+        t_res, same = None, None
         try:
-            from oracle import bigint_ref as B_, verifier_ref as V_
-            V_.verify(B_.CURVES[args.curve], vk, pub, proof_c, TAU, transcript=PlonkTranscript(args.curve))
-            cverified = True
-        except Exception as ex:     # noqa: BLE001 - a rejected proof is a result, not a crash
-            cverified = f"REJECTED: {ex!r}"
-    row = {"n": n, "ranks": G_, "ms": round(t_cls, 2), "constraints_per_s": round(n / t_cls * 1e3, 1),
-           "rounds_ms_rank0": rounds_ms,
-           "variant_resident_key_class_cosets": {"ms": None if t_res is None else round(t_res, 2), "same_proof": same,
-                                                 "note": "18 of the 25 class evaluations of round 3 kept in HBM across proofs; not the reference's work"},
-           "accepted_by_verifier": cverified,
-           "simulated": bool(sim),
-           **({"sim_exchange": {"mode": args.sim_exchange, "device_bytes_out_per_proof": bytes_out_per_proof,
-                                "xgmi_model_ms_per_proof_at_153_GBps_per_link": round(bytes_out_per_proof / (G_ - 1) / 153e9 * 1e3, 2)}} if sim else {}),
-           "rounds_1_2": r12,
-           "key_class_evaluations": "on a third context beside rounds 1 and 2" if fft_helper is not None else "inside round 3",
-           "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 3 all-gathers of class values (the size-n iFFTs of rounds 1, 2, 3), "
-                                    "1 all-gather of the product vector, 5 all-gathers of partial commitment points (one per round), "
-                                    "5 all-gathers of 32-byte partials (slice totals, evaluations, degree, two openings)",
-           "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
-    inst.close()
-    return row
+            cpr = ClassProver(b.w, args.log_n, comm, commit_helper=b.workers[1], key_range=self.key_range, cache_key_cosets=True)
+            cpr.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+            cpr._key["vk"] = self.vk
+            pr = None
+            for it in range(2):
+                fsr = cpr.fiat_shamir(self.pub)
+                if sim:
+                    comm.fill = it == 0
+                b.full_sync()
+                t0 = time.perf_counter()
+                pr = cpr.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, self.bl, fsr, check_degree=not sim)
+                b.full_sync()
+                t_res = (time.perf_counter() - t0) * 1e3
+            t_res = b.max_over_ranks(t_res)
+            same = None if sim else bool(all(np.array_equal(pr[k_][0], proof_c[k_][0]) for k_ in ("opening_proof", "shifted_opening_proof")))     # (a simulated rank proves garbage)
+            cpr.close()
+        except Exception as ex:     # noqa: BLE001 - a variant is a side note of a side leg
+            t_res = None
+            same = repr(ex)
+        cverified = None
+        if b.rank == 0 and not sim and not args.no_verify:
+            try:
+                from oracle import bigint_ref as B_, verifier_ref as V_
+                V_.verify(B_.CURVES[args.curve], self.vk, self.pub, proof_c, self.TAU, transcript=PlonkTranscript(args.curve))
+                cverified = True
+            except Exception as ex:     # noqa: BLE001 - a rejected proof is a result, not a crash
+                cverified = f"REJECTED: {ex!r}"
+        row = {"n": n, "ranks": G_, "ms": None if proof_ms is None else round(proof_ms, 2),
+               "constraints_per_s": None if proof_ms is None else round(n / proof_ms * 1e3, 1),
+               "rounds_ms_rank0": rounds_ms,
+               "variant_resident_key_class_cosets": {"ms": None if t_res is None else round(t_res, 2), "same_proof": same,
+                                                     "note": "18 of the 25 class evaluations of round 3 kept in HBM across proofs; not the reference's work"},
+               "accepted_by_verifier": cverified,
+               "simulated": bool(sim),
+               **({"sim_exchange": {"mode": args.sim_exchange, "device_bytes_out_per_proof": bytes_out_per_proof,
+                                    "xgmi_model_ms_per_proof_at_153_GBps_per_link": round(bytes_out_per_proof / (G_ - 1) / 153e9 * 1e3, 2)}} if sim else {}),
+               "rounds_1_2": r12,
+               "key_class_evaluations": "on a third context beside rounds 1 and 2" if self.fft_helper is not None else "inside round 3",
+               "collectives_per_proof": "1 all-to-all + 1 all-gather of quotient coefficients, 3 all-gathers of class values (the size-n iFFTs of rounds 1, 2, 3), "
+                                        "1 all-gather of the product vector, 5 all-gathers of partial commitment points (one per round), "
+                                        "5 all-gathers of 32-byte partials (slice totals + status, evaluations, degree, two openings)",
+               "reference": "dispatcher2.rs:296-712 via distributed_plonk_amd/class_prover.py"}
+        inst.close()
+        return row

@@ -1,5 +1,5 @@
-"""Optional legs of the single-GPU run (rank 0, N == 1), all AFTER and OUTSIDE the timed region: the oracle as CHECKER of what was just
-timed, the SURVEY §8f "next" rows measured on their own, and the five prover rounds on a satisfied circuit handed to a verifier."""
+"""The single-GPU run (rank 0, N == 1): the proof the headline times (SingleProof) and the legs AFTER and OUTSIDE the timed region — the oracle
+as CHECKER of what was just timed, the SURVEY §8f "next" rows measured on their own, the timed proof handed to a verifier, its variants."""
 import time
 
 from .common import HBM_PEAK_GBS
@@ -250,62 +250,94 @@ def _variants(b, inst, vk, pub, bl, proof, full=True):
     return variants
 
 
-def prover_rounds(b, with_small_rows=True, with_variants=True):
-    """next rows (ranks 2-3) + everything above chained as the reference's five prover rounds (dispatcher2.rs:296-712) on a SATISFIED
-    synthetic circuit generated in HBM, with the merlin transcript, the quotient-degree check ON, and the finished proof handed to a
-    verifier — the reference's own end-to-end test (dispatcher2.rs:1273-1295) at the run's size.  Reported under next_rows and as
-    top-level proof_ms; NOT part of `value`.  -> (small rows dict, prover_rounds dict)"""
-    from distributed_plonk_amd.prover import Prover
-    from distributed_plonk_amd.synthetic import SyntheticInstance
-    args, np, w, n, workers = b.args, b.np, b.w, b.n, b.workers
-    fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
-    TAU = TAU_SEED % fld.p      # the trapdoor this run publishes
-    t0 = time.perf_counter()
-    inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=TAU, helpers=workers[1:2])
-    for x in workers[:2]:
-        x.sync()
-    t_gen = (time.perf_counter() - t0) * 1e3
-    consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
-    bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
-    helper = _Helper(b, inst) if proof_helper_wanted(args) else None
-    pv = Prover(w, args.log_n, commit_helper=workers[1], fft_helper=helper.ctx if helper else None)
-    pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
-    pub = inst.public_inputs()
-    t0 = time.perf_counter()
-    vk = pv.verifying_key()                                           # preprocess: 18 commitments, once per key
-    t_vk = (time.perf_counter() - t0) * 1e3
-    proof = None
-    for it in range(2):
-        fs = pv.fiat_shamir(pub)
+class SingleProof:
+    """The run's REAL proof (N == 1): a random SATISFIED 2^log_n-gate TurboPlonk circuit generated in HBM, its proving key, a trapdoor SRS, and
+    the prover of distributed_plonk_amd/prover.py.  `prove()` is one pass of `Prover::prove` (dispatcher2.rs:296-712): transcript set-up with
+    the verifying key and the public inputs (:238-241), rounds 1-5 with the merlin challenges, quotient-degree check ON.  bench.py times W + K
+    of them as the headline and hands the last one to the verifier AFTER the timed region (`check`)."""
+
+    def __init__(self, b):
+        from distributed_plonk_amd.prover import Prover
+        from distributed_plonk_amd.synthetic import SyntheticInstance
+        args, np, w, workers = b.args, b.np, b.w, b.workers
+        self.b = b
+        fld = __import__("distributed_plonk_amd.fr", fromlist=["FIELDS"]).FIELDS[args.curve]
+        self.TAU = TAU_SEED % fld.p      # the trapdoor this run publishes
         t0 = time.perf_counter()
-        proof = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, bl, fs, check_degree=True)
-        t_prove = (time.perf_counter() - t0) * 1e3
-    rounds = {k_: round(v_, 2) for k_, v_ in pv.timings.items()}
-    pver = {}
-    if not args.no_verify:
+        self.inst = inst = SyntheticInstance(w, args.log_n, seed=0xC1AC, num_inputs=3, tau=self.TAU, helpers=workers[1:2])
+        for x in workers[:2]:
+            x.sync()
+        self.t_gen = (time.perf_counter() - t0) * 1e3
+        self.consts = consts = np.arange(64, dtype=np.uint64).reshape(16, 4) + 11
+        self.bl = {"wires": consts[5:15].reshape(5, 2, 4), "perm": consts[12:15]}
+        self.helper = _Helper(b, inst) if proof_helper_wanted(args) else None
+        self.pv = Prover(w, args.log_n, commit_helper=workers[1], fft_helper=self.helper.ctx if self.helper else None)
+        self.pv.load_key_dev(inst.sel_ptrs, inst.sig_ptrs, inst.k)
+        self.pub = inst.public_inputs()
+        t0 = time.perf_counter()
+        self.vk = self.pv.verifying_key()                                           # preprocess: 18 commitments, once per key
+        self.t_vk = (time.perf_counter() - t0) * 1e3
+        self.proof = self.fs = None
+        self.prove()                     # set-up, never timed: the first proof allocates the work buffers (hipMalloc of ~120 GiB at 2^24 takes seconds)
+
+    def prove(self):
+        pv, inst = self.pv, self.inst
+        self.fs = pv.fiat_shamir(self.pub)
+        self.proof = pv.prove_dev(inst.wev, inst.d_id.ptr, inst.d_idx.ptr, inst.d_pi.ptr, self.bl, self.fs, check_degree=True)
+        return pv.timings
+
+    @property
+    def overlapped(self):
+        return self.helper is not None
+
+    def check(self):
+        b = self.b
+        if b.args.no_verify:
+            return None, {}
         try:
-            pver = _check_proof(b, pv, inst, vk, pub, proof, fs, TAU)
+            pver = _check_proof(b, self.pv, self.inst, self.vk, self.pub, self.proof, self.fs, self.TAU)
         except Exception as ex:     # noqa: BLE001 - a failed check must be visible, never fatal
-            pver["error"] = repr(ex)
-    prover_verified = (bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s")) if not args.no_verify else None
-    small = _small_rows(b, inst, fs, consts) if with_small_rows else {}
-    pv.close()
-    if helper is not None:
-        helper.close()
+            pver = {"error": repr(ex)}
+        return bool(pver) and "error" not in pver and all(v_ for k_, v_ in pver.items() if k_ != "check_s"), pver
+
+    def close_prover(self):
+        if self.pv is not None:
+            self.pv.close()
+            self.pv = None
+        if self.helper is not None:
+            self.helper.close()
+            self.helper = None
+
+    def close(self):
+        self.close_prover()
+        if self.inst is not None:
+            self.inst.close()
+            self.inst = None
+
+
+def proof_rows(b, P, proof_ms, rounds_ms, with_small_rows=True, with_variants=True):
+    """After the timed proofs: the last proof handed to the verifier (the reference's own end-to-end test, dispatcher2.rs:1273-1295, at the run's
+    size), the O(n) rows measured on their own, the same-proof variants.  -> (small rows dict, prover_rounds dict)"""
+    n = b.n
+    prover_verified, pver = P.check()
+    small = _small_rows(b, P.inst, P.fs, P.consts) if with_small_rows else {}
+    helper_on = P.helper is not None
+    proof, inst, vk, pub, bl = P.proof, P.inst, P.vk, P.pub, P.bl
+    P.close_prover()                     # its work buffers go before the variants allocate theirs
     variants = _variants(b, inst, vk, pub, bl, proof, full=with_variants)
     row = {
-        "n": n, "ms": round(t_prove, 2), "constraints_per_s": round(n / t_prove * 1e3, 1),
-        "rounds_ms": rounds,
+        "n": n, "ms": None if proof_ms is None else round(proof_ms, 2), "constraints_per_s": None if proof_ms is None else round(n / proof_ms * 1e3, 1),
+        "rounds_ms": rounds_ms,
         "prover_verified": prover_verified, "prover_verification": pver,
-        "key_coset_ffts": "on a third context beside rounds 1 and 2" if helper is not None else "inside round 3",
-        "setup_ms": {"circuit_key_and_trapdoor_srs_generation": round(t_gen, 1), "verifying_key_18_commitments": round(t_vk, 1)},
+        "key_coset_ffts": "on a third context beside rounds 1 and 2" if helper_on else "inside round 3",
+        "setup_ms": {"circuit_key_and_trapdoor_srs_generation": round(P.t_gen, 1), "verifying_key_18_commitments": round(P.t_vk, 1)},
         "variants": variants,
         "reference": "dispatcher2.rs:296-712 (rounds 1-5: 13 commitments, 7 NTT(n), 26 NTT(8n), permutation product, quotient, "
                      "10 evaluations, linearisation, 2 openings), end-to-end test dispatcher2.rs:1273-1295",
         "note": "a random SATISFIED TurboPlonk circuit generated in HBM (plonk_synth_circuit: uniform witness and selectors, q_c solved per "
                 "gate, copy constraints = n cycles of length 5 between pseudo-random gates), commit key tau^i*G with a published trapdoor "
                 "(plonk_synth_srs), challenges from the merlin transcript (host Python, ~7 ms inside the timed proof), "
-                "WrongQuotientPolyDegree check ON.  Variants produce the same proof: resident_key_cosets skips the 18 selector/sigma coset "
-                "NTTs per proof (proving-key data); six_cosets interpolates the degree-(5n+7) quotient from 6n evaluations"}
-    inst.close()
+                "WrongQuotientPolyDegree check ON.  `ms` = the run's headline (the average of the timed proofs).  Variants produce the same proof: "
+                "resident_key_cosets skips the 18 selector/sigma coset NTTs per proof (proving-key data); six_cosets interpolates the degree-(5n+7) "
+                "quotient from 6n evaluations"}
     return small, row

@@ -240,8 +240,9 @@ class ClassProver(Prover):
             return super()._interpolate_many(alloc, pairs)
         w, n, G, s = self.w, self.n, self.G, self.s
         L, K = n // G, len(pairs)
-        d_mine = alloc(K * L)                        # [polynomial][L]: this class's values of every polynomial of the round
-        d_all = alloc(G * K * L)                     # [class][polynomial][L] after the all-gather
+        # named work buffers shared by the three calls of a proof (K = 5, 1, 1 polynomials: the first call sizes them), not numbered ones per call
+        d_mine = self._work("interp_mine", K * L)    # [polynomial][L]: this class's values of every polynomial of the round
+        d_all = self._work("interp_all", G * K * L)  # [class][polynomial][L] after the all-gather
         for k, (src, _) in enumerate(pairs):
             w.coset_eval_dev(src, n, L, self.shift_n, d_mine.ptr + k * L * 32)
         self.comm.all_gather_dev(d_mine.ptr, d_all.ptr, K * L * 32)

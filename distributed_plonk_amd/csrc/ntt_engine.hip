@@ -424,7 +424,7 @@ int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream) {
         const bool epi_ok = c.epi.kind == 0 || ((c.epi.kind == 3 || c.epi.kind == 4) && c.epi.bq == 1 && c.epi.b0 == 0 && c.epi.aq == 0 && c.epi.a0 == 0);
         if (interleaved || c.inverse || c.pro.kind || !epi_ok || c.in_len == 0 || c.in_len > NTT_MAX_FOLD * M || c.in_rows == 0 || Bt % c.in_rows ||
             (c.row_coset_const && c.epi.kind == 0))
-            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, 1 <= len <= 8M, batch = rows * classes");
+            return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation is forward, contiguous, 1 <= len <= %dM, batch = rows * classes", NTT_MAX_FOLD);
         if (NP > 1 && (c.work == nullptr || (const void*)c.work == (const void*)c.out || (const void*)c.work == (const void*)c.in))
             return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation needs a separate work buffer");
         if (NP == 1 && (const void*)c.in == (const void*)c.out) return plonk_fail(PLONK_ERR_ARG, "ntt_run: shared-input evaluation cannot run in place");

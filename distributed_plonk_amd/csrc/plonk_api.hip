@@ -5,6 +5,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <algorithm>
 #include <vector>
 
 #include "constants.h"
@@ -94,9 +95,10 @@ struct plonk_ctx {
 // state of the collective order check (comm_order_check, further down)
 namespace {
 struct DeviceCollectives {
-    plonk_ctx* control = nullptr;        // the context whose communicator carries the tags (the first created on this device)
+    plonk_ctx* control = nullptr;        // the context whose communicator carries the tags (the oldest LIVE communicator of this device)
+    std::vector<plonk_ctx*> live;        // contexts of this device that hold a communicator, in creation order (the control's successors)
     int created = 0;                     // communicators created so far = the next one's ordinal
-    uint64_t seq = 0;                    // collectives entered
+    uint64_t seq = 0;                    // CHECKED collectives entered (a tag was exchanged)
 };
 std::mutex g_coll_mu;
 DeviceCollectives g_coll[64];
@@ -663,13 +665,15 @@ static int comm_order_check(plonk_ctx* ctx, uint64_t kind, uint64_t bytes) {
         std::lock_guard<std::mutex> g(g_coll_mu);
         DeviceCollectives& d = g_coll[ctx->device];
         control = d.control;
+        if (!control || !control->comm) return plonk_fail(PLONK_ERR_STATE, "collective order check: no live communicator on device %d to carry the tags", ctx->device);
+        // communicators of different sizes: nothing to line up against — and nothing counted: ranks outside such a sub-communicator never see
+        // this collective, so counting it would leave their sequence numbers behind for every later checked collective
+        if (comm_world(ctx->comm) != comm_world(control->comm)) return PLONK_OK;
         tag[0] = ((uint64_t)(uint32_t)ctx->comm_ordinal << 8) | kind;
         tag[1] = bytes;
         tag[2] = d.seq++;
     }
-    if (!control || !control->comm) return plonk_fail(PLONK_ERR_STATE, "collective order check: the device's first communicator is gone");
     const int world = comm_world(control->comm);
-    if (comm_world(ctx->comm) != world) return PLONK_OK;          // communicators of different sizes: nothing to line up against
     std::vector<uint64_t> all((size_t)3 * world);
     int rc = comm_allgather_host(control->comm, tag, sizeof tag, all.data(), control->stream);
     if (rc) return rc;
@@ -692,15 +696,20 @@ extern "C" int plonk_comm_init(plonk_ctx* ctx, const void* id, int rank, int wor
         std::lock_guard<std::mutex> g(g_coll_mu);
         DeviceCollectives& d = g_coll[ctx->device];
         ctx->comm_ordinal = d.created++;
+        d.live.push_back(ctx);
         if (!d.control) d.control = ctx;
     }
     return rc;
 }
+// The control communicator is the OLDEST LIVE one of the device: when its context goes, the next in creation order takes over (every rank
+// creates and destroys its communicators in the same order, so the successor lines up as the first one did) instead of every later checked
+// collective failing with "the first communicator is gone" while other communicators are alive.
 static void comm_forget(plonk_ctx* ctx) {
     if (ctx->device < 0 || ctx->device >= 64) return;
     std::lock_guard<std::mutex> g(g_coll_mu);
     DeviceCollectives& d = g_coll[ctx->device];
-    if (d.control == ctx) d.control = nullptr;
+    d.live.erase(std::remove(d.live.begin(), d.live.end(), ctx), d.live.end());
+    if (d.control == ctx) d.control = d.live.empty() ? nullptr : d.live.front();
 }
 extern "C" int plonk_comm_destroy(plonk_ctx* ctx) {
     CHECK_CTX(ctx);
@@ -975,7 +984,11 @@ extern "C" int plonk_perm_product_range_dev(plonk_ctx* ctx, const void* const d_
         return plonk_fail(PLONK_ERR_ARG, "plonk_perm_product_range_dev: gates [%zu, %zu + %zu) of %zu", first, first, count, n);
     int rc = ensure_scratch2(ctx, perm_product_scratch_bytes(count));
     if (rc) return rc;
-    return perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, first, count, d_out, ctx->d_scratch2, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));          // plonk_last_kernel_ms, like the whole-vector entry point
+    rc = perm_product_run(ctx->tables, d_wires, d_id_perm, d_perm_idx, beta, gamma, n, first, count, d_out, ctx->d_scratch2, ctx->stream);
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    return rc;
 }
 extern "C" int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes, size_t size, size_t in_stride, int reverse, const uint64_t* scale,
                                           void* d_out) {

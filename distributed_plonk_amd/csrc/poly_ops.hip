@@ -593,6 +593,12 @@ int poly_lincomb_run(NttTables& T, size_t k, const void* const* polys, const siz
 #define DVT_ZL (2 * DV_LANES + 1)
 #define DVT_ZT (2 * DV_LANES + 2)
 #define DVT_N (2 * DV_LANES + 3)
+// The relations these kernels rely on (the constants DO get changed — the tile-shape A/B of round 5 — and a shape that breaks one of
+// them would give wrong openings with PLONK_OK):
+static_assert(PO_LANES == (1 << 8), "poly_eval: the lane-strided Horner multiplies by z^PO_LANES = host_rep_pow2k(point, 8)");
+static_assert((DV_CH & (DV_CH - 1)) == 0 && (DV_LANES & (DV_LANES - 1)) == 0, "poly_div: z^DV_CH, z^DV_LANES and z^DV_TILE are built by repeated squaring");
+static_assert(DV_LANES <= 1024, "poly_div_agg_kernel indexes the first level of the power table (1024 entries) with the lane number");
+static_assert(DV_TILE == DV_LANES * DV_CH && DV_TOP >= 2, "poly_div: a tile is DV_LANES lanes x DV_CH consecutive coefficients");
 static int build_div_tab(NttTables& T, const Fr& z_mont, const F29** out, hipStream_t stream) {
     const FrParams& P = T.fp;
     std::string key((const char*)z_mont.l, 32);

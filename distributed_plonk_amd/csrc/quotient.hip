@@ -699,6 +699,18 @@ int quotient_evals_run(NttTables& T, const plonk_quotient_inputs* in, size_t n, 
     q.pi = (const Fr*)in->pub_input;
     q.out = (Fr*)d_out;
     {
+        // No aliasing (plonk_hip.h): `out` must not overlap any input vector.  A lane reads z at its own index AND at the shifted index of
+        // z(wX) (another lane's output index), and the split form (quotient_fuse = 8) writes `out` in its first kernel before the second reads
+        // wires, sigmas and z — an aliased call would return PLONK_OK with a corrupted quotient.
+        const char* o0 = (const char*)d_out;
+        const char* o1 = o0 + (size_t)m_local * sizeof(Fr);
+        auto overlaps = [&](const void* p_) { const char* a = (const char*)p_; return a != nullptr && a < o1 && o0 < a + (size_t)m_local * sizeof(Fr); };
+        bool bad = overlaps(q.z) || overlaps(q.pi);
+        for (int j = 0; j < 13; j++) bad = bad || overlaps(q.sel[j]);
+        for (int j = 0; j < 5; j++) bad = bad || overlaps(q.sig[j]) || overlaps(q.wire[j]);
+        if (bad) return plonk_fail(PLONK_ERR_ARG, "quotient_evals: d_out overlaps an input vector (the output must be a buffer of its own)");
+    }
+    {
         ProfScope ps("quotient_evals_kernel", stream);
         const int fuse = (T.quotient_fuse >= 0 && T.quotient_fuse <= 8) ? T.quotient_fuse : 6;
         const dim3 grid((uint32_t)((m_local + 255) / 256));

@@ -214,7 +214,7 @@ class Prover:
         """domain.ifft of rounds 1-3 (dispatcher2.rs:300-309, 345-346, 426): pairs [(d_evals, d_coeffs)], n evaluations -> n coefficients
         each; the evaluations are not modified (ntt_dev consumes its input, hence the copy)."""
         n = self.n
-        d_tmp = alloc(n)
+        d_tmp = self._work("interp_tmp", n)              # ONE temporary for the three calls of a proof (rounds 1, 2, 3), not a numbered buffer per call
         for src, dst in pairs:
             self.w.memcpy_d2d(d_tmp.ptr, src, n * 32)
             self.w.ntt_dev(d_tmp.ptr, dst, n, True, False)

@@ -210,7 +210,9 @@ typedef struct {
 /* d_out[i] = 1/Z_H(x_i) * (gate(x_i) + alpha * perm(x_i)) + alpha^2/n * (z(x_i) - 1)/(x_i - 1), x_i = g * w_m^i, exactly as
  * the loop at dispatcher2.rs:435-504.  alpha, beta, gamma: transcript challenges; k: vk.k[0..5] — all Fr, Montgomery,
  * host pointers.  Uses the domains fixed by plonk_init.  The quotient's coefficient form is then
- * plonk_ntt_dev(d_out, ..., m, is_inv = 1, is_coset = 1) (dispatcher2.rs:507). */
+ * plonk_ntt_dev(d_out, ..., m, is_inv = 1, is_coset = 1) (dispatcher2.rs:507).
+ * NO ALIASING: d_out must not overlap any input vector (a lane reads `perm` at its own index and at the shifted index of z(wX), and the
+ * split formulation writes d_out before it reads wires, sigmas and perm) — an overlapping call is PLONK_ERR_ARG. */
 int plonk_quotient_evals_dev(plonk_ctx* ctx, const plonk_quotient_inputs* in, const uint64_t* alpha, const uint64_t* beta,
                              const uint64_t* gamma, const uint64_t* k, void* d_out);
 

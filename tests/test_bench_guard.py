@@ -187,13 +187,16 @@ def test_other_configs_fall_back_to_the_phase_after_phase_run(monkeypatch):
         calls.append((list(cmd), env.get("PLONK_BENCH_WATCHDOG"), env.get("PLONK_BENCH_PROOF_HELPER"), kw.get("timeout")))
         if "--overlap-phases" not in cmd:
             raise subprocess.CalledProcessError(4, cmd)
-        line = {"ms_per_step": 1.0, "value": 2.0, "steps": 3, "phases_ms": {"transforms": 1, "commitments": 2, "note": "x"}, "config": {"phase_overlap": False},
-                "roofline": {"kernel": "k", "frac": 0.1, "avg_launch_ms": 1}, "verified": True, "verification": {}, "proof_ms": 5, "prover_verified": True}
+        line = {"ms_per_step": 5.0, "value": 2.0, "steps": 3, "phases_ms": {"round1": 1, "round2": 2, "note": "x"}, "config": {"phase_overlap": False},
+                "headline": "K verified five-round proofs", "op_mix": {"ms_per_step": 1.0, "constraints_per_s": 9.0, "phases_ms": {"transforms": 1, "commitments": 2, "note": "x"}},
+                "roofline": {"kernel": "k", "frac": 0.1, "avg_launch_ms": 1}, "verified": True, "verification": {}, "proof_ms": 5.0, "prover_verified": True}
         return types.SimpleNamespace(stdout=json.dumps(line).encode())
 
     monkeypatch.setattr(oc.subprocess, "run", fake_run)
     res = oc.other_configs(types.SimpleNamespace(bases="distinct"))
     assert len(res) == 2 and all(r["phase_overlap"] is False and "CalledProcessError" in r["overlap_run_failed"] and r["verified"] for r in res), res
+    # round 6: the sub-run's headline is its proof (ms_per_step = proof_ms), the op-mix step rides beside it; an un-overlapped run quotes its own frac
+    assert all(r["ms_per_step"] == r["proof_ms"] == 5.0 and r["op_mix_ms_per_step"] == 1.0 and r["frac"] == 0.1 and "no context overlap" in r["frac_source"] for r in res), res
     assert [c[1:3] for c in calls] == [("1", None), (None, "0")] * 2
     assert all(20.0 <= c[3] <= 150.0 for c in calls) and oc.BUDGET_S <= 300
     assert all(c[0][-2:] == ["--overlap-phases", "off"] for c in calls[1::2])
@@ -244,29 +247,72 @@ def test_no_committed_result_line_claims_more_valu_issue_than_time():
     assert not bad, bad
 
 
-def test_cpu_baseline_reports_two_samples_a_fitted_exponent_and_the_bench_size_figure():
-    """`cpu_baseline.value` is the largest MEASURED sample, `samples` holds both, `fitted_exponent` is what they give and
-    `value_at_bench_size` (with `extrapolated: true`) is the figure that belongs beside the GPU line.  Tiny sizes here; the oracle is the timed thing."""
+def test_other_configs_quote_the_unoverlapped_fraction_only():
+    """a sub-run whose timed region overlaps contexts (2^20 / 2^22: --overlap-phases auto, Prover(fft_helper)) reports the roofline
+    fraction of its UN-OVERLAPPED op-mix pass; without such a pass no fraction is quoted at all — never the one from stretched launches."""
+    sys.path.insert(0, ROOT)
+    from benchlib.other_configs import entry_of
+    base = {"ms_per_step": 50.0, "value": 2.0e7, "steps": 3, "phases_ms": {"round1": 1.0, "note": "x"}, "config": {"phase_overlap": True}, "headline": "K proofs",
+            "op_mix": {"ms_per_step": 40.0, "constraints_per_s": 2.6e7, "phases_ms": {"transforms_with_commitments_beside_them": 39.0,
+                                                                                      "commitments_tail_after_the_last_transform": 1.0, "note": "x"}},
+            "roofline": {"kernel": "ntt_pass_kernel", "frac": 0.03, "avg_launch_ms": 0.5, "overlap_note": "stretched"}, "verified": True, "proof_ms": 50.0}
+    e = entry_of("c", dict(base, roofline_unoverlapped={"roofline": {"kernel": "ntt_pass_kernel", "frac": 0.055, "avg_launch_ms": 0.3}}))
+    assert e["frac"] == 0.055 and e["avg_launch_ms"] == 0.3 and e["frac_in_the_overlapped_timed_region"] == 0.03 and "roofline_unoverlapped" in e["frac_source"]
+    assert "commitments" not in e["op_mix_phases_ms"] and "commitments_tail_after_the_last_transform" in e["op_mix_phases_ms"]
+    e = entry_of("c", base)
+    assert e["frac"] is None and e["frac_in_the_overlapped_timed_region"] == 0.03 and "not quoted" in e["frac_source"]
+
+
+class _FakeClock:
+    """A deterministic clock for benchlib.cpu_baseline: every timed call takes exactly what the model says (the fitted exponent of
+    2^8 / 2^10 WALL-CLOCK samples failed one run in four on a loaded box).  Consecutive clock() pairs bracket, in order: [ntt_par, ntt8_par,] ntt, ntt8,
+    msm of each sample."""
+
+    def __init__(self, durations):
+        self.d, self.t, self.calls = list(durations), 0.0, 0
+
+    def __call__(self):
+        if self.calls % 2 == 1:
+            self.t += self.d[self.calls // 2]
+        self.calls += 1
+        return self.t
+
+
+def _cpu_args(**kw):
     import types
+    return types.SimpleNamespace(**dict(dict(curve="bn254", log_n=12, cpu_sample_log_n=8, cpu_sample_log_n2=10, cpu_full_size="auto"), **kw))
+
+
+def test_cpu_baseline_is_measured_at_the_bench_size_with_the_small_samples_beside_it():
+    """`cpu_baseline.value` is a MEASUREMENT at the GPU line's size (`extrapolated: false`), the two smaller samples and the
+    exponent they give stay beside it as a cross-check; with --cpu-full-size off (or no host memory) the figure is the fitted one, labelled.  The
+    oracle really runs (tiny sizes); the clock is injected, so every number below is exact and the test does not depend on the box's load."""
     import numpy as np
     sys.path.insert(0, ROOT)
     from benchlib.cpu_baseline import cpu_baseline
     from oracle import oracle as O
-    bases = O.gen_bases(O.BN254, 3, 64, 1 << 10)
-
-    def d2h(ctx, dst, src, nbytes):
-        import ctypes as C
-        C.memmove(dst, bases.ctypes.data, nbytes)
-        return 0
-
-    b = types.SimpleNamespace(args=types.SimpleNamespace(curve="bn254", log_n=12, cpu_sample_log_n=8, cpu_sample_log_n2=10), np=np, n=1 << 12, q64=4,
-                              w=types.SimpleNamespace(lib=types.SimpleNamespace(plonk_memcpy_d2h=d2h), ctx=None), bases=types.SimpleNamespace(ptr=0))
-    c = cpu_baseline(b)
-    assert c["kind"] == "port" and c["extrapolated"] is True and [s["log_n"] for s in c["samples"]] == [8, 10]
-    assert c["value"] == c["samples"][1]["constraints_per_s"] and "2^10" in c["sample"]
-    assert 0.3 < c["fitted_exponent"] < 2.5 and c["value_at_bench_size"] == c["extrapolated_to_bench_size"]["by_fitted_exponent"]["value"]
-    assert c["extrapolated_to_bench_size"]["by_operation_counts"]["value"] > 0
+    bases = O.gen_bases(O.BN254, 3, 64, 1 << 12)
+    # step time ~ n^1.1 exactly: sample s costs 2^(1.1 * log_n) * (7 * 1 + 26 * 8 + 13 * 4) time units of 1 us
+    unit = lambda ln: 1e-6 * 2.0 ** (1.1 * ln)
+    ops = lambda ln, par: ([0.5 * unit(ln), 4 * unit(ln)] if par else []) + [unit(ln), 8 * unit(ln), 4 * unit(ln)]
+    clk = _FakeClock(ops(8, True) + ops(10, False) + ops(12, False))
+    c = cpu_baseline(_cpu_args(), {}, bases, clock=clk)
+    assert clk.calls == 2 * (5 + 3 + 3)
+    assert c["kind"] == "port" and c["extrapolated"] is False and [s["log_n"] for s in c["samples"]] == [8, 10, 12]
+    step12 = unit(12) * (7 + 26 * 8 + 13 * 4)
+    assert c["value"] == c["value_at_bench_size"] == round(4096 / step12, 1) == c["samples"][2]["constraints_per_s"]
+    assert "the GPU line's own size" in c["sample"] and "2^12" in c["sample"]
+    assert c["fitted_exponent"] == 1.1
+    x = c["extrapolated_to_bench_size"]
+    assert abs(x["by_fitted_exponent"]["value"] / c["value"] - 1) < 1e-3 and "cross-check" in x["note"] and x["by_operation_counts"]["value"] > 0
+    # rounds 4-5's form on request: two samples, the fitted figure, labelled as an extrapolation
+    clk = _FakeClock(ops(8, True) + ops(10, False))
+    c = cpu_baseline(_cpu_args(cpu_full_size="off"), {}, bases, clock=clk)
+    assert c["extrapolated"] is True and [s["log_n"] for s in c["samples"]] == [8, 10] and c["value"] == c["samples"][1]["constraints_per_s"]
+    assert c["value_at_bench_size"] == c["extrapolated_to_bench_size"]["by_fitted_exponent"]["value"] and "EXTRAPOLATED" in c["extrapolated_to_bench_size"]["note"]
+    assert c["full_size_skipped"] == "--cpu-full-size off"
     # one sample only, at the bench size: nothing is extrapolated
-    b.args.cpu_sample_log_n2, b.args.log_n, b.n = 0, 8, 1 << 8
-    c = cpu_baseline(b)
+    clk = _FakeClock(ops(8, True))
+    c = cpu_baseline(_cpu_args(log_n=8, cpu_sample_log_n2=0), {}, bases[:256], clock=clk)
     assert c["extrapolated"] is False and c["value_at_bench_size"] == c["value"] and len(c["samples"]) == 1 and "extrapolated_to_bench_size" not in c
+    assert isinstance(np.asarray(bases), np.ndarray)

@@ -106,3 +106,31 @@ def test_quotient_coset_class_of_a_tiny_domain(gpu_workers, oracle, curve, cid, 
         assert np.array_equal(out.download((mL, 4)), want[s::G]), s
         buf.free()
     out.free()
+
+
+def test_output_overlapping_an_input_is_refused(gpu_workers):
+    """d_out aliasing an input would be silently wrong (z is read at a shifted index; the split form writes d_out before it reads
+    wires / sigmas / z) — plonk_hip.h states the no-alias rule and the entry point enforces it for every formulation."""
+    from distributed_plonk_amd._ffi import PlonkError
+    w = gpu_workers("bn254")
+    log_n = 5
+    n, m = 1 << log_n, 8 << log_n
+    w.init(None, n, m)
+    vecs = [w.alloc(m * 32) for _ in range(25)]
+    for j, buf in enumerate(vecs):
+        w.synth_fr(0x77 + j, buf.ptr, m)
+    ptr = [b.ptr for b in vecs]
+    ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 3
+    out = w.alloc(m * 32)
+    try:
+        for fuse in (6, 8):
+            w.set_option("quotient_fuse", fuse)
+            for bad in (ptr[23], ptr[18], ptr[13], ptr[0], ptr[24], ptr[23] + 32 * (m - 1)):          # z, a wire, a sigma, a selector, pi, one element of overlap
+                with pytest.raises(PlonkError) as e:
+                    w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], bad)
+                assert e.value.code == -1 and "overlaps an input" in str(e.value)
+            w.quotient_evals_dev(ptr[0:13], ptr[13:18], ptr[18:23], ptr[23], ptr[24], ch[0], ch[1], ch[2], ch[3:8], out.ptr)
+    finally:
+        w.set_option("quotient_fuse", 6)
+        for b in vecs + [out]:
+            b.free()

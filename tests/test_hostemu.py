@@ -156,6 +156,9 @@ def test_bench_program_multi_rank_control_flow(emu_env, world, extra):
     assert sum(sum(r.values()) for r in pp["operations_per_rank"]) == 7 + 26 + 13, pp
     cp = d["next_rows"]["class_prover"]
     assert cp["ranks"] == world and cp["accepted_by_verifier"] is True, cp
+    # round 6: the class prover's K proofs ARE the headline of an N > 1 run (accepted by the verifier, or the line falls back to the op-mix step)
+    assert d["headline"].startswith("K verified five-round proofs by the coset-class prover on all") and d["prover_verified"] is True, d["headline"]
+    assert "proof_headline_error" not in d and d["op_mix"] == {"emulated": True}
 
 
 @pytest.mark.parametrize("extra", [("--sim-exchange", "standin"), ("--sim-exchange", "none", "--scheme", "classes")])
@@ -177,6 +180,7 @@ def test_bench_program_simulated_ranks(emu_env, extra):
     cp = d["next_rows"]["class_prover"]
     assert cp["simulated"] is True and cp["ranks"] == 4 and cp["rounds_1_2"].startswith("size-n iFFTs by residue class"), cp
     assert (cp["sim_exchange"]["device_bytes_out_per_proof"] > 0) and "error" not in (d.get("polynomial_parallel") or {}), d
+    assert "SIMULATED ranks" in d["headline"] and "proof_headline_error" not in d, d["headline"]
 
 
 def test_bench_program_multi_rank_with_phases_overlapped(emu_env):
@@ -193,9 +197,9 @@ def test_bench_program_multi_rank_with_phases_overlapped(emu_env):
 
 @pytest.mark.parametrize("overlap", ["off", "auto"])
 def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
-    """`python bench.py` as the driver runs it at N = 1 (here: 2^7 gates on the emulation): the headline, the verification against the oracle, the
-    next rows and the verified proof all execute, and the line carries exactly the top-level fields the round-3 program printed (the refactoring
-    of bench.py into benchlib/ must not lose or rename one; an emulated line has no clock-derived field by construction).  "off": the step as the
+    """`python bench.py` as the driver runs it at N = 1 (here: 2^7 gates on the emulation): the op-mix step, its verification against the oracle, the
+    proof loop that takes the headline over (round 6), the next rows and the verifier all execute, and the line carries exactly these top-level
+    fields (the round-3 program's, plus `headline`, `op_mix`, `roofline_unoverlapped`; an emulated line has no clock-derived field by construction).  "off": the step as the
     2^24 line runs it, one phase after the other; "auto": at this size the transforms are issued while the commitment threads run (the
     configs[1] / configs[3] sub-runs)."""
     import json
@@ -205,10 +209,12 @@ def test_bench_program_single_rank_line_has_every_field(emu_env, overlap):
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert r.returncode == 0 and len(lines) == 1, (r.stdout + r.stderr)[-3000:]
     d = json.loads(lines[0])
-    assert set(d) == {"config", "cpu_baseline", "data", "dtype", "emulated", "higher_is_better", "kernels", "metric", "n_gpus", "next_rows", "other_scheme",
-                      "prover_verified", "roofline", "roofline_other", "scaling", "steps", "unit", "value", "verification", "verified", "vs_baseline", "warmup"}, sorted(d)
+    assert set(d) == {"config", "cpu_baseline", "data", "dtype", "emulated", "headline", "higher_is_better", "kernels", "metric", "n_gpus", "next_rows", "op_mix",
+                      "other_scheme", "prover_verified", "roofline", "roofline_other", "roofline_unoverlapped", "scaling", "steps", "unit", "value", "verification",
+                      "verified", "vs_baseline", "warmup"}, sorted(d)
     assert d["verified"] is True and all(d["verification"].values()), d["verification"]
-    assert d["prover_verified"] is True
+    assert d["prover_verified"] is True and d["headline"].startswith("K verified five-round proofs") and "proof_headline_error" not in d
+    assert d["roofline_unoverlapped"] == {"ran": True}       # this size overlaps contexts in the timed region (phases and / or the proof's third context)
     assert set(d["next_rows"]) == {"quotient_evals_kernel", "perm_product", "poly_eval", "poly_lincomb_20_terms", "poly_div_linear", "prover_rounds"}
     assert all(v.get("same_proof_as_the_verified_one") for v in d["next_rows"]["prover_rounds"]["variants"].values()), d["next_rows"]["prover_rounds"]["variants"]
     assert set(d["config"]) >= {"workload", "log_n", "curve", "bases", "scheme", "parallelism", "coset_inputs", "commit_batching", "phase_overlap"}

@@ -2,7 +2,7 @@
 # Round 5, eighth GPU call: (a) the WHOLE N > 1 code path through real RCCL communicators on a world of one rank, with the collective order check on
 # (verification leg, class prover with rounds 1-2 distributed through ncclAllGather, proof handed to the verifier); (b) rank 0 of 2 / 4 / 8 simulated:
 # the scaling picture one GPU can give; (c) configs[4]'s per-rank share (2^28 gates, n-domain only, rank 0 of 8).
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, fifth GPU call (a second lease for the split quotient kernel; the fused bucket ordering inside the step; the division after D2's diet)
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, fourth GPU call: the WHOLE -m gpu suite on the round's sources so far, the split quotient kernel against the compact one (alternating, one
 # process), and a kernel-level view of the rewritten division / evaluation.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

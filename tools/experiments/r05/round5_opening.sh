@@ -3,7 +3,7 @@
 # (profiles/README.md): the phases of a step overlapped at 2^20 / BLS12-381 2^22 / simulated 8 ranks, and
 # Prover(fft_helper=...) at the same sizes.  Every pair runs in ONE lease, alternating; only same-call pairs are comparable.
 #   gpurun --timeout 600 -- 'bash tools/round5_opening.sh'      -> gpurun_out/r05_opening.txt
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -2,7 +2,7 @@
 # Round 5, second GPU call: what the round built on the CPU, on the device.  (a) the new parity tests; (b) rank 0 of 8 simulated — the op-mix step
 # and the class prover's proof with rounds 1-2 distributed vs replicated, with and without the exchange stand-in; (c) Prover(fft_helper) at 2^24.
 #   gpurun --timeout 1500 -- 'bash tools/round5_second.sh'      -> gpurun_out/r05_second.txt + gpurun_out/r05_*.json
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 5, seventh GPU call: the ABI fuzzer with its three new operation kinds on the device, the permutation product kernel by kernel.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, sixth GPU call: the driver-style line once more now that profiles/pmc_current.json carries the shipped source hash (so `traffic` / `valu_issue` are
 # quoted), rank 0 of 8 simulated with the grid window reduction (small MSMs) against the pyramid, and kernel stats of the simulated rank.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

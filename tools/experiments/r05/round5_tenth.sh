@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5: ClassProver(fft_helper) — rank 0 of 8 simulated, the class prover's proof with the key's 18 class evaluations inside round 3 / on a third context
 # beside rounds 1-2, alternating, both exchange stand-ins.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R

@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 5, third GPU call: (a) the round's new parity tests on the device (summary to a file this time); (b) rank 0 of 8 simulated with VALID data in
 # every receive buffer (the second call's "no exchange" class-prover figures committed all-zero vectors: void); (c) the rewritten O(n) rows at 2^24.
-R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../../.." && pwd)}
 O=$R/gpurun_out
 mkdir -p $O
 cd $R
