@@ -82,8 +82,10 @@ def verify_single(b):
 def quotient_row(b):
     """next row, measured on its own, NOT part of `value`: quotient coset evaluations over 8n points"""
     np, w, m = b.np, b.w, b.m
-    vecs = [w.alloc(m * 32) for _ in range(25)]
+    vecs = []
     try:
+        for _ in range(25):              # inside the try: an allocation that fails half-way must not leak the buffers before it (100 GiB at 2^24)
+            vecs.append(w.alloc(m * 32))
         for j, buf in enumerate(vecs):
             w.synth_fr(0xABC + j, buf.ptr, m)
         ch = np.arange(32, dtype=np.uint64).reshape(8, 4) + 3
@@ -315,15 +317,21 @@ class SingleProof:
             self.inst = None
 
 
-def proof_rows(b, P, proof_ms, rounds_ms, with_small_rows=True, with_variants=True):
+def proof_rows(b, P, proof_ms, rounds_ms, with_small_rows=True, with_variants=True, with_quotient_row=False):
     """After the timed proofs: the last proof handed to the verifier (the reference's own end-to-end test, dispatcher2.rs:1273-1295, at the run's
-    size), the O(n) rows measured on their own, the same-proof variants.  -> (small rows dict, prover_rounds dict)"""
+    size), the O(n) rows measured on their own, the quotient kernel on its own, the same-proof variants.
+    -> (rows dict, prover_rounds dict)"""
     n = b.n
     prover_verified, pver = P.check()
     small = _small_rows(b, P.inst, P.fs, P.consts) if with_small_rows else {}
     helper_on = P.helper is not None
     proof, inst, vk, pub, bl = P.proof, P.inst, P.vk, P.pub, P.bl
-    P.close_prover()                     # its work buffers go before the variants allocate theirs
+    P.close_prover()                     # its work buffers (~125 GiB at 2^24) go before the quotient row (100 GiB) and the variants allocate theirs
+    if with_quotient_row:
+        try:
+            small.update(quotient_row(b))
+        except Exception as ex:     # noqa: BLE001 - a row of its own: its failure must not cost the proof's verdict
+            small["quotient_evals_kernel"] = {"error": str(ex)}
     variants = _variants(b, inst, vk, pub, bl, proof, full=with_variants)
     row = {
         "n": n, "ms": None if proof_ms is None else round(proof_ms, 2), "constraints_per_s": None if proof_ms is None else round(n / proof_ms * 1e3, 1),

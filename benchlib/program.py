@@ -13,11 +13,11 @@ def _single_gpu_legs(b, out, args, P, proof_ms, rounds_ms):
     """rank 0, N == 1, after the timed region: the next rows, the timed proof handed to the verifier, its variants"""
     from . import legs_single as L
     next_rows = {}
-    if args.next_rows == "all":
-        next_rows.update(run_leg(None, "quotient_row", None, lambda: L.quotient_row(b), error=lambda ex: {"error": str(ex)}))
+    if P is None and args.next_rows == "all":
+        next_rows.update(run_leg(None, "quotient_row", None, lambda: L.quotient_row(b), error=lambda ex: {"quotient_evals_kernel": {"error": str(ex)}}))
     if P is not None:
         full = args.next_rows == "all"
-        res = run_leg(None, "prover_rounds", None, lambda: L.proof_rows(b, P, proof_ms, rounds_ms, with_small_rows=full, with_variants=full),
+        res = run_leg(None, "prover_rounds", None, lambda: L.proof_rows(b, P, proof_ms, rounds_ms, with_small_rows=full, with_variants=full, with_quotient_row=full),
                       error=lambda ex: ({}, {"error": repr(ex)}))
         next_rows.update(res[0])
         next_rows["prover_rounds"] = res[1]

@@ -1,6 +1,7 @@
 """ctypes front-end of the C CPU oracle (TEST INFRASTRUCTURE ONLY — see oracle/plonk_oracle.c).
 
-PARITY UNPINNED (no reference golden vectors exist; see plonk_oracle.c header).
+PARITY UNPINNED (no reference golden vectors exist; see plonk_oracle.c header) — pinned instead to third-party sympy transforms and group
+law (tests/test_oracle_thirdparty.py, tests/golden/sympy_*.json) beside the repository's own big-integer statement.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module.
 All arrays are numpy uint64, little-endian limbs, layouts of /root/reference/src/utils.rs:27-43:

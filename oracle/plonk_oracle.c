@@ -12,7 +12,14 @@
  * algorithms and the reference's in-tree orchestration.  What pins it instead: exact integer math
  * (any correct implementation with the same p, R, omega, g is bit-identical on reduced residues and
  * on affine points), an independent pure-Python big-int statement (oracle/bigint_ref.py), O(N^2)
- * DFTs and double-and-add checks, and tests/golden/ vectors generated from bigint_ref.py.
+ * DFTs and double-and-add checks, tests/golden/ vectors generated from bigint_ref.py — and, since
+ * round 6, THIRD-PARTY code that this repository neither wrote nor ships: sympy's number-theoretic
+ * transform (sympy.discrete.transforms.ntt / intt; its primitive_root is arkworks' GENERATOR 5 / 7,
+ * hence the same omega) and sympy's elliptic-curve group law, run live against this file
+ * (tests/test_oracle_thirdparty.py: all four transform modes for 2 ... 2^10 points on both Fr, the
+ * 4-step and distributed decompositions, P + Q / 2P / P - P / k * P / MSMs on both curves) and
+ * committed as a second fixture set (tests/golden/sympy_*.json, tools/gen_golden_sympy.py) that the
+ * GPU golden test consumes.  Still "unpinned" by the task's definition: none of it is arkworks output.
  *
  * Restated reference functions (file:line under /root/reference/src):
  *   orc_ntt               ark-poly Radix2EvaluationDomain::{fft,ifft,coset_fft,coset_ifft}_in_place

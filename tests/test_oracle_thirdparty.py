@@ -170,3 +170,46 @@ def test_oracle_msm_equals_sympy_live(name, cid, cv, b):
     assert not inf
     assert np.array_equal(xy[:q64], G.mont_limbs([int(acc.x / acc.z)], q, q64)[0])
     assert np.array_equal(xy[q64:], G.mont_limbs([int(acc.y / acc.z)], q, q64)[0])
+
+
+@pytest.mark.parametrize("name,cid,cv,b", CURVES)
+def test_oracle_polynomial_rows_equal_sympy_galoistools(name, cid, cv, b):
+    """SURVEY §8f rank 3 (dispatcher2.rs:545-555, 566-633, 651-666) and the blinding of worker.rs:396-406: the oracle's Horner evaluation,
+    linear combination, division by (X - z) and (b_0 + b_1 X + ...)(X^n - 1) + p(X) against sympy's dense GF(p) polynomial arithmetic
+    (sympy.polys.galoistools: gf_eval, gf_div, gf_mul, gf_add — coefficients highest degree first)."""
+    from sympy.polys.domains import ZZ
+    from sympy.polys.galoistools import gf_add, gf_div, gf_eval, gf_mul, gf_mul_ground, gf_strip
+    r = cv.fr.p
+    rng = random.Random(4242 + cid)
+
+    def hi_first(c):            # our vectors are lowest degree first
+        return gf_strip([ZZ(x) for x in reversed(c)])
+
+    def lo_first(f, length):
+        out = [int(x) % r for x in reversed(f)]
+        return out + [0] * (length - len(out))
+
+    for n in (1, 2, 7, 64, 259):
+        c = [rng.randrange(r) for _ in range(n)]
+        z = rng.randrange(1, r)
+        C, Z = G.mont_limbs(c, r), G.mont_limbs([z], r)[0]
+        assert from_mont_ints(O.poly_eval(cid, C, Z).reshape(1, 4), r)[0] == int(gf_eval(hi_first(c), ZZ(z), r, ZZ)) % r, ("eval", n)
+        if n >= 2:
+            q, rem = gf_div(hi_first(c), [ZZ(1), ZZ(-z % r)], r, ZZ)
+            assert from_mont_ints(O.poly_div_linear(cid, C, Z), r) == lo_first(q, n - 1), ("div", n)
+            assert [int(x) % r for x in rem] in ([], [int(gf_eval(hi_first(c), ZZ(z), r, ZZ)) % r])        # remainder = p(z)
+    # linear combination of polynomials of different lengths
+    polys = [[rng.randrange(r) for _ in range(ln)] for ln in (5, 9, 1, 12)]
+    ks = [rng.randrange(r) for _ in polys]
+    acc = []
+    for p_, k_ in zip(polys, ks):
+        acc = gf_add(acc, gf_mul_ground(hi_first(p_), ZZ(k_), r, ZZ), r, ZZ)
+    got = O.poly_lincomb(cid, [G.mont_limbs(p_, r) for p_ in polys], G.mont_limbs(ks, r))
+    assert from_mont_ints(got, r) == lo_first(acc, 12)
+    # blinding: (b_0 + b_1 X [+ b_2 X^2]) * (X^n - 1) + p(X)
+    for n, kb in ((8, 2), (16, 3)):
+        p_ = [rng.randrange(r) for _ in range(n)]
+        bl = [rng.randrange(r) for _ in range(kb)]
+        zh = [ZZ(1)] + [ZZ(0)] * (n - 1) + [ZZ(r - 1)]
+        want = gf_add(gf_mul(hi_first(bl), zh, r, ZZ), hi_first(p_), r, ZZ)
+        assert from_mont_ints(O.blind(cid, G.mont_limbs(p_, r), n, G.mont_limbs(bl, r)), r) == lo_first(want, n + kb)

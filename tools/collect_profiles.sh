@@ -8,7 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 mkdir -p $O
-BENCH="python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-next-rows --no-other-configs --no-verify"
+# the PMC passes profile the op-mix step alone (--headline op-mix): the same kernels and launch shapes as inside a proof (99 pass launches and 7 batched
+# accumulations per step / proof), without the proof's set-up under the counters' serialisation; the stats pass runs the round-6 default (proofs timed)
+BENCH="python $R/bench.py --headline op-mix --steps 1 --warmup 1 --no-cpu-baseline --no-next-rows --no-other-configs --no-verify"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -o $TAG -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-next-rows --no-other-configs --no-verify > $O/${TAG}_bench_under_rocprof.json 2> $O/prof_stats.err
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o p -- $BENCH > /dev/null 2> $O/pmc_fetch.err
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/pmc_write -o p -- $BENCH > /dev/null 2> $O/pmc_write.err

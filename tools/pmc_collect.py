@@ -51,8 +51,8 @@ def main():
         kernels[name] = ent
     from distributed_plonk_amd.build import code_hashes
     out = {"source_hash": source_hash(), "code_hashes": code_hashes(), "config": f"2^{log_n}@{curve}@{world}", "kernels": kernels,
-           "how": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-next-rows "
-                  "--no-other-configs --no-verify ; averages per launch"}
+           "how": "rocprofv3 --kernel-trace --pmc <one counter group per run> -- python bench.py --headline op-mix --steps 1 --warmup 1 --no-cpu-baseline "
+                  "--no-next-rows --no-other-configs --no-verify ; averages per launch (the op-mix step: the kernels and launch shapes of a proof)"}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     print("wrote", out_path, len(kernels), "kernels, source hash", out["source_hash"])
 
