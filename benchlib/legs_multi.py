@@ -331,6 +331,8 @@ class ClassProof:
         args, np, dist, w, n, m, sim, world = b.args, b.np, b.dist, b.w, b.n, b.m, b.sim, b.world
         self.b = b
         b.release_step_buffers()
+        for x in set(b.workers) | set(b._extra_contexts()):      # the op-mix legs' caches (six pooled exchange buffers and the factor planes per context:
+            x.trim()                                             # ~100 GiB on the one GPU of a --multi-path run at 2^24) go before the proof's buffers come
         if world == 1 and not dist.is_initialized() and not sim:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29653")

@@ -83,6 +83,7 @@ SIGNATURES = {
     "plonk_fft1_dev_compact": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t]),
     "plonk_fft2_dev": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]),
     "plonk_transpose_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
+    "plonk_trim": (C.c_int, [C.c_void_p]),
     "plonk_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "plonk_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "plonk_memcpy_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

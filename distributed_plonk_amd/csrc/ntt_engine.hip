@@ -88,6 +88,26 @@ int ntt_tables_create(NttTables& T, int curve, hipStream_t stream) {
     return PLONK_OK;
 }
 
+// Everything a context can rebuild on demand: inter-pass / output-factor planes, coset row tables, the first-pass tables of class-decomposed
+// evaluations, the quotient kernel's 1/(x - 1) planes, power tables — not the root tables the domains were set up with.  -> bytes' worth of
+// entries released (the planes' share is T.plane_bytes; the rest is small).
+void ntt_tables_trim(NttTables& T) {
+    for (auto& kv : T.tw_lo_scaled) (void)hipFree(kv.second);
+    T.tw_lo_scaled.clear();
+    for (auto& kv : T.planes) (void)hipFree(kv.second);
+    T.planes.clear();
+    for (auto& kv : T.rowtabs) (void)hipFree(kv.second);
+    T.rowtabs.clear();
+    for (auto& kv : T.shift_sets) { (void)hipFree(kv.second.planes); (void)hipFree(kv.second.rowtabs); (void)hipFree(kv.second.foldc); }
+    T.shift_sets.clear();
+    T.plane_bytes = 0;
+    for (auto& kv : T.quot_inv_xm1) (void)hipFree(kv.second);
+    T.quot_inv_xm1.clear();
+    for (auto& kv : T.pow_tabs) (void)hipFree(kv.second);
+    T.pow_tabs.clear();
+    T.pow_order.clear();
+}
+
 void ntt_tables_destroy(NttTables& T) {
     for (int d = 0; d < 2; d++) {
         (void)hipFree(T.tw_shoup[d]); T.tw_shoup[d] = nullptr;

@@ -1051,7 +1051,31 @@ extern "C" int plonk_blind_dev(plonk_ctx* ctx, void* d_poly, size_t n, const uin
 extern "C" int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out) {
     CHECK_CTX(ctx);
     if (!out) return plonk_fail(PLONK_ERR_ARG, "plonk_dev_alloc: null");
-    HIP_TRY(hipMalloc(out, bytes ? bytes : 1));
+    const hipError_t e = hipMalloc(out, bytes ? bytes : 1);
+    if (e != hipSuccess) {              // an out-of-memory report that explains itself: what was asked for, what the device had left
+        (void)hipGetLastError();
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        return plonk_fail(PLONK_ERR_HIP, "plonk_dev_alloc: hipMalloc of %.2f GiB -> %s (device %d: %.1f GiB free of %.1f GiB)", (double)bytes / (double)(1ull << 30),
+                          hipGetErrorString(e), ctx->device, (double)free_b / (double)(1ull << 30), (double)total_b / (double)(1ull << 30));
+    }
+    return PLONK_OK;
+}
+// A worker lives across circuits (worker.rs:42-59: one State per process): what a context caches for the LAST problem size — the exchange buffers of
+// finished FFT tasks (up to six, 4 GiB each after a 2^27-point transform), NTT factor planes (up to tens of GiB), the MSM workspace, scratch — stays
+// allocated until the context dies.  plonk_trim gives all of it back; everything is rebuilt on demand by the next call that needs it.  The SRS, the
+// domains, open FFT tasks and the communicator are untouched.
+extern "C" int plonk_trim(plonk_ctx* ctx) {
+    CHECK_CTX(ctx);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (auto& pb : ctx->pool) (void)hipFree(pb.second);
+    ctx->pool.clear();
+    ntt_tables_trim(ctx->tables);
+    msm_ws_release(ctx->msm_ws);
+    if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+    if (ctx->d_scratch2) (void)hipFree(ctx->d_scratch2);
+    ctx->d_scratch = ctx->d_scratch2 = nullptr;
+    ctx->scratch_bytes = ctx->scratch2_bytes = 0;
     return PLONK_OK;
 }
 extern "C" int plonk_dev_free(plonk_ctx* ctx, void* p) {

@@ -154,6 +154,7 @@ struct NttCall {
 };
 
 int ntt_tables_create(NttTables& T, int curve, hipStream_t stream);
+void ntt_tables_trim(NttTables& T);      // release every table / plane that is rebuilt on demand (plonk_trim)
 void ntt_tables_destroy(NttTables& T);
 int ntt_run(NttTables& T, const NttCall& c, hipStream_t stream);
 bool ntt_single_pass_inplace_ok(const NttTables& T, const NttCall& c);

@@ -351,6 +351,11 @@ class PlonkWorker:
         check(self.lib.plonk_blind_dev(self.ctx, d_poly, n, _ptr(b), b.shape[0]))
 
     # ------------------------------------------------------------------ device memory, synthetic inputs, debug
+    def trim(self):
+        """plonk_trim: give back every cache this context can rebuild on demand (exchange buffers of finished FFT tasks, NTT factor planes,
+        MSM workspace, scratch) — a worker's State outlives a circuit (worker.rs:42-59)."""
+        check(self.lib.plonk_trim(self.ctx))
+
     def alloc(self, nbytes: int) -> DeviceBuffer:
         return DeviceBuffer(self, nbytes)
 

@@ -124,6 +124,8 @@ extern "C" {
     pub fn plonk_coset_interp_dev(ctx: *mut plonk_ctx, d_evals: *mut c_void, size: usize, shift: *const u64, scale: *const u64, i0: usize, count: usize, d_out: *mut c_void) -> c_int;
 
     // ---- device memory, synthetic inputs, knobs, timing
+    /// Release every cache the context can rebuild on demand (finished tasks' exchange buffers, NTT planes, MSM workspace, scratch).
+    pub fn plonk_trim(ctx: *mut plonk_ctx) -> c_int;
     pub fn plonk_dev_alloc(ctx: *mut plonk_ctx, bytes: usize, out: *mut *mut c_void) -> c_int;
     pub fn plonk_dev_free(ctx: *mut plonk_ctx, p: *mut c_void) -> c_int;
     pub fn plonk_memcpy_h2d(ctx: *mut plonk_ctx, d_dst: *mut c_void, h_src: *const c_void, bytes: usize) -> c_int;

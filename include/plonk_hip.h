@@ -283,6 +283,10 @@ int plonk_class_interleave_dev(plonk_ctx* ctx, const void* d_in, size_t classes,
                                void* d_out);
 
 /* ---- device memory + synthetic inputs (bench / tests; the reference uses thread_rng) ---------- */
+/* Give back every cache the context can rebuild on demand (exchange buffers of finished FFT tasks, NTT factor planes and tables derived per
+ * problem size, MSM workspace, scratch): a worker's State outlives a circuit (worker.rs:42-59) and would otherwise keep the last problem's
+ * tens of GiB.  The SRS, the domains, open FFT tasks and the communicator stay.  Synchronises the context's stream. */
+int plonk_trim(plonk_ctx* ctx);
 int plonk_dev_alloc(plonk_ctx* ctx, size_t bytes, void** out);
 int plonk_dev_free(plonk_ctx* ctx, void* p);
 int plonk_memcpy_h2d(plonk_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);

@@ -125,6 +125,7 @@ hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int dev);
 hipError_t hipMalloc(void** p, size_t bytes);
 template <typename T> static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }
 hipError_t hipFree(void* p);
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s = nullptr);
 hipError_t hipMemset(void* dst, int value, size_t bytes);

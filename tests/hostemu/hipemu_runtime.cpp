@@ -371,6 +371,7 @@ hipError_t hipMalloc(void** p, size_t bytes) {
     return hipSuccess;
 }
 hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes) { if (free_bytes) *free_bytes = 0; if (total_bytes) *total_bytes = 0; return hipSuccess; }   // not tracked
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind) { if (bytes) memmove(dst, src, bytes); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind k, hipStream_t) { return hipMemcpy(dst, src, bytes, k); }
 hipError_t hipMemset(void* dst, int value, size_t bytes) { if (bytes) memset(dst, value, bytes); return hipSuccess; }

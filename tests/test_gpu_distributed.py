@@ -399,3 +399,28 @@ def test_exchange_standin_and_async_copy(gpu_workers):
     w.sync()
     assert np.array_equal(d_r.download((b // 8,)), src[b // 8:2 * b // 8])
     d_s.free(); d_r.free()
+
+
+def test_trim_releases_the_caches_and_everything_still_works(gpu_workers, oracle):
+    """plonk_trim: the pooled exchange buffers of finished tasks, the NTT factor planes / class tables, the MSM workspace and the scratch of a
+    context go back to the device; the next calls rebuild what they need and give the same bits (a worker's State outlives a circuit,
+    worker.rs:42-59)."""
+    from distributed_plonk_amd.dispatcher import Dispatcher
+    from distributed_plonk_amd._ffi import MsmWorkload
+    w = gpu_workers("bn254")
+    n = 1 << 12
+    v = oracle.rand_fr(0, 91, n)
+    bases = oracle.gen_bases(0, 92, 64, n)
+    sc = oracle.from_mont(0, oracle.rand_fr(0, 93, n))
+    d = Dispatcher([w])
+    d.init(bases, n, 8 * n)
+    want_fft = oracle.ntt(0, v, True, True)
+    want_big = oracle.ntt(0, oracle.rand_fr(0, 94, 8 * n), False, True)
+    want_msm = oracle.jac_to_affine(0, oracle.msm(0, bases, sc, threads=4))
+    for _ in range(2):
+        assert np.array_equal(d.fft(v, is_quot=False, is_inv=True, is_coset=True), want_fft)
+        assert np.array_equal(w.ntt(oracle.rand_fr(0, 94, 8 * n), False, True), want_big)
+        got = w.g1_to_affine(w.var_msm(MsmWorkload(0, n), sc))
+        assert got[1] == want_msm[1] and np.array_equal(got[0], want_msm[0])
+        w.trim()
+        w.trim()                                    # idempotent
