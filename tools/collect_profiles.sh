@@ -18,6 +18,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES 
 cd $R
 python tools/pmc_collect.py $O/pmc_fetch $O/pmc_write $O/pmc_sq 24 bn254 1 $O/pmc_current.json
 find $O/prof_stats -name "*kernel_stats.csv" -exec cp {} $O/${TAG}_kernel_stats_2p24.csv \;
+# the same trace grouped by grid size: the n-point and 8n-point passes of ntt_pass_kernel separately (the stats file mixes them in the whole command's
+# ratio, one timed proof in 21 : 78 — tools/ktrace_by_grid.py)
+python tools/ktrace_by_grid.py $O/prof_stats ntt_pass msm_accumulate_kernel quotient_evals > $O/${TAG}_kernel_trace_by_grid_2p24.txt 2>&1
 # FETCH_SIZE calibration on known byte counts (wide stream vs the MSM's 72-byte gathers)
 if [ -x $R/tools/fetch_calib_bin ]; then
   (cd /tmp && rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_calib -o p -- $R/tools/fetch_calib_bin > $O/fetch_calib.out 2> $O/fetch_calib.err)
@@ -32,4 +35,4 @@ find $O/prof_msm_alone -name "*.csv" -delete 2>/dev/null
 find $O/prof_stats $O/pmc_fetch $O/pmc_write $O/pmc_sq $O/pmc_calib -name "*.csv" -delete 2>/dev/null
 ls -la $O/pmc_current.json $O/${TAG}_kernel_stats_2p24.csv
 head -5 $O/${TAG}_kernel_stats_2p24.csv | cut -c1-160
-echo "cp gpurun_out/pmc_current.json profiles/pmc_current.json; cp gpurun_out/pmc_current.json profiles/${TAG}_pmc_2p24.json; cp gpurun_out/${TAG}_kernel_stats_2p24.csv profiles/; cp gpurun_out/${TAG}_fetch_calibration.txt profiles/; cp gpurun_out/${TAG}_kernel_stats_msm_alone_2p24.csv profiles/"
+echo "cp gpurun_out/pmc_current.json profiles/pmc_current.json; cp gpurun_out/pmc_current.json profiles/${TAG}_pmc_2p24.json; cp gpurun_out/${TAG}_kernel_stats_2p24.csv gpurun_out/${TAG}_kernel_trace_by_grid_2p24.txt profiles/; cp gpurun_out/${TAG}_fetch_calibration.txt profiles/; cp gpurun_out/${TAG}_kernel_stats_msm_alone_2p24.csv profiles/"
