@@ -263,6 +263,10 @@ def promote_proof(b, out, dt, rounds_ms, kernels, steps, warmup, what, overlappe
                phases_ms=dict(rounds_ms, note="this rank's host clock per prover round (each ends in a stream synchronisation: its commitments feed the "
                                               "transcript), averaged over the timed proofs"),
                roofline=roofline, roofline_other=roofline_other, kernels=_fmt_kernels(kernels), headline=what, proof_ms=round(ms, 3))
+    if isinstance(out.get("config"), dict):
+        out["config"] = dict(out["config"], workload=(f"2^{b.args.log_n}-gate {b.args.curve} circuit, ONE verified five-round proof per step: 13 commit(n) + 7 NTT(n) + 26 NTT(8n) "
+                                                      f"+ permutation product + quotient evaluations + 10 evaluations + 2 openings + merlin transcript"),
+                             op_mix_workload=out["config"].get("workload"))
     if overlapped:
         for r_ in [roofline] + list(roofline_other or []):
             if r_:

@@ -156,8 +156,9 @@ def run(args, json_fd):
     if rank0:
         out["next_rows"] = dict(next_rows or {}, class_prover=class_row) if class_row else next_rows
         _proof_fields(out, next_rows, class_row)
-        if single and proof_headline and out.get("prover_verified") is not None:
-            out["verified"] = bool(out.get("verified")) and bool(out["prover_verified"])        # the headline is the proof: its verdict gates `verified`
+        if single and proof_headline and "op_mix" in out and not args.no_verify:
+            # the headline is the proof: its verdict gates `verified` — and a proof whose check did not run to a verdict is not a verified headline
+            out["verified"] = bool(out.get("verified")) and out.get("prover_verified") is True
     if b.world > 1:
         guard.emit()                             # N > 1: nothing is added after this point; tear-down (communicator destruction) must not cost the line
         guard.arm("teardown", 120.0)

@@ -241,7 +241,7 @@ def test_bench_program_proof_only_sub_run(emu_env):
 
 def test_differential_fuzz_slice(emu_env):
     """A fixed-seed slice of tools/fuzz_abi.py (random operations, shapes, flags and options against the oracle); long runs are a manual tool —
-    eighteen operations, from single kernels to whole proofs handed to the verifier; under AddressSanitizer it found the two defects recorded in DESIGN §5 and docs/HISTORY.md §0."""
+    nineteen operations, from single kernels to whole proofs handed to the verifier; under AddressSanitizer it found the two defects recorded in DESIGN §5 and docs/HISTORY.md §0."""
     r = subprocess.run([sys.executable, "tools/fuzz_abi.py", "--seconds", "500", "--max-ops", "60", "--seed", "5", "--max-log", "10"], cwd=ROOT, env=emu_env,
                        capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "fuzz ok: 60 operations" in r.stdout, (r.stdout + r.stderr)[-2000:]

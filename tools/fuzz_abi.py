@@ -387,6 +387,15 @@ class Fuzz:
         exp = self.O.jac_to_affine(self.cid, self.O.msm(self.cid, bases, sc, threads=4))
         return refused and got[1] == exp[1] and np.array_equal(got[0], exp[0]), dict(n=n, i=i, kind=kind)
 
+    def op_trim(self):
+        """plonk_trim between two operations: every rebuildable cache of the context (pooled exchange buffers, factor planes and class tables, MSM
+        workspace, scratch) goes back to the device; the transform right after it and everything the fuzzer draws next must rebuild what it needs."""
+        self.w.trim()
+        log_n = int(self.rs.randint(1, min(self.max_log, 11) + 1))
+        v = self.fr(1 << log_n)
+        inv, coset = bool(self.rs.randint(0, 2)), bool(self.rs.randint(0, 2))
+        return np.array_equal(self.w.ntt(v, inv, coset), self.O.ntt(self.cid, v, inv, coset, threads=4)), dict(log_n=log_n, inv=inv, coset=coset)
+
     def op_transpose(self):
         rows, cols = int(self.rs.randint(1, 200)), int(self.rs.randint(1, 200))
         v = self.fr(rows * cols)
@@ -603,7 +612,7 @@ class Fuzz:
         return np.array_equal(got, want[off::G] if G > 1 else want), dict(log_n=log_n, variant=variant, G=G, off=off)
 
     OPS = ["ntt", "coset_eval_interp", "msm", "commit_many", "poly", "lincomb", "perm_product", "transpose", "distributed_fft", "quotient", "compact_rows_fft", "round1", "prove_verify", "class_prove", "msm_table",
-           "perm_product_ranges", "class_ifft", "init_refuses_bad_srs"]
+           "perm_product_ranges", "class_ifft", "init_refuses_bad_srs", "trim"]
 
     def close(self):
         self.w.close()
