@@ -125,6 +125,22 @@ def test_compiled_cpp_host_program(emu_env, tmp_path):
     assert res.returncode == 0 and "host_check ok" in res.stdout, (res.stdout + res.stderr)[-2000:]
 
 
+def test_compiled_cpp_prover_program(emu_env, tmp_path):
+    """tests/host_cpp/prover_check.cpp — the five rounds of `Prover::prove` with their merlin transcript as compiled C++ on the bare C ABI
+    (host/plonk_prover.hpp), against the (emulated) library: verifying key, challenges, proof and serialization checked against the oracle's
+    rounds and the Python transcript (tests/test_host_cpp.py: check_cpp_prover); both curves on the GPU."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_host_cpp import _build_prover, check_cpp_prover
+    from oracle import oracle as O
+    O.lib()
+    exe = _build_prover(tmp_path)
+    shadow = tmp_path / "emu"
+    shadow.mkdir()
+    os.symlink(emu_env["PLONK_HIP_LIB"], shadow / "libplonk_hip.so")            # DT_RUNPATH yields to LD_LIBRARY_PATH
+    env = dict(emu_env, LD_LIBRARY_PATH=str(shadow) + os.pathsep + emu_env.get("LD_LIBRARY_PATH", ""))
+    check_cpp_prover(tmp_path, exe, "bn254", 0, 5, seed=1300, env=env)
+
+
 def _bench_dry_run(env, world, port, extra=()):
     """`bench.py --gpus N` exactly as the driver launches it (torch.distributed.run, one rank per device), against the emulation at a tiny size:
     a DRY RUN of the program's control flow.  The line it prints says `emulated`, has no value and no clock-derived field."""
