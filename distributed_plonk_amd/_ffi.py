@@ -73,6 +73,7 @@ SIGNATURES = {
     "plonk_commit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "plonk_g1_add": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]),
     "plonk_g1_to_affine": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
+    "plonk_keccak_f1600": (C.c_int, [C.c_void_p]),
     "plonk_transpose": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t]),
     "plonk_ntt_dev": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int]),
     "plonk_msm_dev": (C.c_int, [C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]),

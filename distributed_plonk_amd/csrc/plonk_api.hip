@@ -475,6 +475,43 @@ extern "C" int plonk_g1_add(int curve, const uint64_t* a, const uint64_t* b, uin
     if (!a || !b || !out) return plonk_fail(PLONK_ERR_ARG, "plonk_g1_add: null");
     return msm_jac_add_host(curve, (const uint32_t*)a, (const uint32_t*)b, (uint32_t*)out);
 }
+// Keccak-f[1600] on a 200-byte state (lane (x, y) at byte offset 8 * (x + 5 y), little-endian): the permutation under merlin's STROBE-128, i.e.
+// under the reference's Fiat-Shamir transcript (dispatcher2.rs:44-154).  Host-only and tiny, like the point helpers above: a proof's transcript is
+// ~25 permutations — 7-15 ms of a host interpreter's time per proof (5 % of an 8-rank proof), microseconds here.
+extern "C" int plonk_keccak_f1600(uint8_t* state200) {
+    if (!state200) return plonk_fail(PLONK_ERR_ARG, "plonk_keccak_f1600: null");
+    static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
+                                    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
+                                    0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
+                                    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                                    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int ROT[5][5] = {{0, 36, 3, 41, 18}, {1, 44, 10, 45, 2}, {62, 6, 43, 15, 61}, {28, 55, 25, 21, 56}, {27, 20, 39, 8, 14}};      // [x][y]
+    auto rol = [](uint64_t v, int r) { r &= 63; return r ? (v << r) | (v >> (64 - r)) : v; };
+    uint64_t a[5][5];
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++) {
+            uint64_t v = 0;
+            for (int b = 7; b >= 0; b--) v = (v << 8) | state200[8 * (x + 5 * y) + b];
+            a[x][y] = v;
+        }
+    for (int rnd = 0; rnd < 24; rnd++) {
+        uint64_t c[5], d[5], bb[5][5];
+        for (int x = 0; x < 5; x++) c[x] = a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4];
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) a[x][y] ^= d[x];
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) bb[y][(2 * x + 3 * y) % 5] = rol(a[x][y], ROT[x][y]);
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) a[x][y] = bb[x][y] ^ (~bb[(x + 1) % 5][y] & bb[(x + 2) % 5][y]);
+        a[0][0] ^= RC[rnd];
+    }
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++)
+            for (int b = 0; b < 8; b++) state200[8 * (x + 5 * y) + b] = (uint8_t)(a[x][y] >> (8 * b));
+    return PLONK_OK;
+}
+
 extern "C" int plonk_g1_to_affine(int curve, const uint64_t* jac, uint64_t* out_xy, int* is_infinity) {
     if (!jac || !out_xy || !is_infinity) return plonk_fail(PLONK_ERR_ARG, "plonk_g1_to_affine: null");
     return msm_jac_to_affine_host(curve, (const uint32_t*)jac, (uint32_t*)out_xy, is_infinity);

@@ -9,7 +9,8 @@ What it mirrors: `FakeStandardTranscript` (/root/reference/src/dispatcher2.rs:44
   * usize         8 bytes little-endian (`to_le_bytes` on a 64-bit target)
 Challenges: 64 transcript bytes reduced mod r (`from_le_bytes_mod_order`, :150).
 
-Tiny compute (a few hundred Keccak permutations per proof), so plain Python.  Pinned by known answers in
+Tiny compute (~25 Keccak permutations per proof): plain Python, with the permutation itself through the library's host-side
+`plonk_keccak_f1600` when it is loadable (the interpreter needs 0.3-0.7 ms per permutation: 5 % of an 8-rank proof).  Pinned by known answers in
 tests/test_transcript.py: the permutation against hashlib's SHA3-256/SHAKE128 through a sponge built on it, STROBE +
 Merlin framing against the Merlin project's published "test protocol" vector.  The reference itself holds no vectors.
 """
@@ -53,6 +54,31 @@ def keccak_f1600(state: bytearray) -> None:
             state[8 * (x + 5 * y):8 * (x + 5 * y) + 8] = a[x][y].to_bytes(8, "little")
 
 
+_keccak_py = keccak_f1600          # the pure-Python statement above: pinned by tests/test_transcript.py, and what runs when no library is loadable
+_native = None                      # None: not looked up yet; False: unavailable
+
+
+def _keccak_fast(state: bytearray) -> None:
+    """The same permutation through libplonk_hip.so's host-side `plonk_keccak_f1600` when the library is loadable (it is wherever a prover runs):
+    a proof's transcript is ~25 permutations — 7-15 ms per proof in the interpreter (5 % of an 8-rank proof), microseconds natively.
+    tests/test_transcript.py checks the two against each other and against hashlib."""
+    global _native
+    if _native is None:
+        try:
+            import ctypes as C
+            from . import _ffi
+            fn = _ffi.lib().plonk_keccak_f1600
+            _native = (fn, C.c_uint8 * 200)
+        except Exception:       # noqa: BLE001 - no library (a transcript-only use on a machine without the build): the interpreter does it
+            _native = False
+    if _native:
+        fn, arr_t = _native
+        if fn(arr_t.from_buffer(state)) != 0:
+            raise RuntimeError("plonk_keccak_f1600 failed")
+    else:
+        _keccak_py(state)
+
+
 # --------------------------------------------------------------------------------------------- STROBE-128 (the subset Merlin uses)
 _STROBE_R = 166
 _FLAG_I, _FLAG_A, _FLAG_C, _FLAG_T, _FLAG_M, _FLAG_K = 1, 2, 4, 8, 16, 32
@@ -63,7 +89,7 @@ class Strobe128:
         st = bytearray(200)
         st[0:6] = bytes([1, _STROBE_R + 2, 1, 0, 1, 96])
         st[6:18] = b"STROBEv1.0.2"
-        keccak_f1600(st)
+        _keccak_fast(st)
         self.state, self.pos, self.pos_begin, self.cur_flags = st, 0, 0, 0
         self.meta_ad(protocol_label, False)
 
@@ -83,7 +109,7 @@ class Strobe128:
         self.state[self.pos] ^= self.pos_begin
         self.state[self.pos + 1] ^= 0x04
         self.state[_STROBE_R + 1] ^= 0x80
-        keccak_f1600(self.state)
+        _keccak_fast(self.state)
         self.pos = self.pos_begin = 0
 
     def _absorb(self, data: bytes):

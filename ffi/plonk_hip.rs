@@ -95,6 +95,8 @@ extern "C" {
     pub fn plonk_ntt(ctx: *mut plonk_ctx, v: *mut u64, n: usize, is_inv: c_int, is_coset: c_int) -> c_int; // dispatcher.rs:594,632,667; dispatcher2.rs:507
     pub fn plonk_commit(ctx: *mut plonk_ctx, coeffs_mont: *const u64, n_coeffs: usize, out_jacobian: *mut u64) -> c_int; // worker.rs:117-123
     pub fn plonk_g1_add(curve: c_int, a_jac: *const u64, b_jac: *const u64, out_jac: *mut u64) -> c_int; // dispatcher.rs:236-238
+    /// Keccak-f[1600] in place on a 200-byte state (merlin's permutation; a Rust host keeps using the merlin crate).
+    pub fn plonk_keccak_f1600(state200: *mut u8) -> c_int;
     pub fn plonk_g1_to_affine(curve: c_int, jac: *const u64, out_xy: *mut u64, is_infinity: *mut c_int) -> c_int; // dispatcher2.rs:892
     pub fn plonk_transpose(ctx: *mut plonk_ctx, v: *mut u64, rows: usize, cols: usize) -> c_int; // transpose.rs:413
 

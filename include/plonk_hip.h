@@ -163,6 +163,10 @@ int plonk_commit(plonk_ctx* ctx, const uint64_t* coeffs_mont, size_t n_coeffs, u
  * `Commitment(commitment.into())` (dispatcher2.rs:892).  Host-side, tiny. */
 int plonk_g1_add(int curve, const uint64_t* a_jac, const uint64_t* b_jac, uint64_t* out_jac);
 int plonk_g1_to_affine(int curve, const uint64_t* jac, uint64_t* out_xy, int* is_infinity);
+/* Keccak-f[1600] in place on a 200-byte state (lane (x, y) at byte 8 * (x + 5 y), little-endian): the permutation under merlin / STROBE-128,
+ * i.e. under the reference's Fiat-Shamir transcript (dispatcher2.rs:44-154; merlin 3.0.0, Cargo.toml:40).  Host-side, tiny: a host whose language
+ * has no fast Keccak (the Python mirror) runs its transcript's ~25 permutations per proof through this. */
+int plonk_keccak_f1600(uint8_t* state200);
 /* ip_transpose, transpose.rs:413 (rows x cols -> cols x rows of Fr), host buffer. */
 int plonk_transpose(plonk_ctx* ctx, uint64_t* v, size_t rows, size_t cols);
 

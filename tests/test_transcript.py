@@ -31,6 +31,29 @@ def test_keccak_permutation_against_hashlib():
         assert _sponge(msg, 168, 0x1F, 400) == hashlib.shake_128(msg).digest(400)
 
 
+def test_native_keccak_equals_the_python_statement_and_is_what_the_transcript_runs():
+    """libplonk_hip.so's host-side plonk_keccak_f1600 (what STROBE runs when the library is loadable: ~25 permutations per proof, 7-15 ms in the
+    interpreter) against the pure-Python permutation that the hashlib test above pins, on random states; and Merlin's published vector both ways."""
+    import ctypes as C
+    from distributed_plonk_amd import _ffi
+    fn = _ffi.lib().plonk_keccak_f1600
+    rs = np.random.RandomState(7)
+    for _ in range(20):
+        a = bytearray(rs.randint(0, 256, 200).astype(np.uint8).tobytes())
+        b = bytearray(a)
+        T.keccak_f1600(a)
+        assert fn((C.c_uint8 * 200).from_buffer(b)) == 0 and a == b
+    assert fn(None) != 0
+    want = "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    for native in (None, False):                    # None: look the library up (native); False: the interpreter's permutation
+        T._native = native
+        t = T.MerlinTranscript(b"test protocol")
+        t.append_message(b"some label", b"some data")
+        assert t.challenge_bytes(b"challenge", 32).hex() == want
+        assert bool(T._native) == (native is None)
+    T._native = None
+
+
 def test_merlin_published_vector():
     """merlin's `equivalence_simple` inputs; the challenge value is the one the Merlin ports (Go, Python, JS) pin."""
     t = T.MerlinTranscript(b"test protocol")
