@@ -300,11 +300,13 @@ def _exchange_of_proofs(b, kernels, steps):
 
 
 def unoverlapped_roofline(b, steps=2):
-    """Runs whose timed region overlaps contexts (N == 1 up to 2^22 gates: --overlap-phases auto, Prover(fft_helper)) stretch every launch by the
-    kernels beside it, so their `roofline.frac` cannot be compared with the 2^24 line's.  Two op-mix steps with the phases
-    one after the other give the un-overlapped launch durations; -> the roofline entries from those."""
-    saved = b.overlap
-    b.overlap = False
+    """Runs whose timed region overlaps contexts (N == 1 up to 2^22 gates: --overlap-phases auto, Prover(fft_helper); every N > 1 / simulated run: two
+    transform lanes, commitments beside them, the class prover's third context) stretch every launch by the kernels beside it, so their `roofline.frac`
+    is a wall-clock figure, not a kernel property (0.019 on a simulated rank whose kernels do 1/8 of the work in 1/8 of the
+    time).  Two op-mix steps with ONE transform lane and the phases one after the other give the un-overlapped launch durations; -> the roofline entries
+    from those.  Every rank executes it (N > 1: the steps contain the exchanges)."""
+    saved = (b.overlap, b.overlap_multi, b.n_lanes)
+    b.overlap, b.overlap_multi, b.n_lanes = False, False, 1
     try:
         b.step()
         b.full_sync()
@@ -314,10 +316,14 @@ def unoverlapped_roofline(b, steps=2):
         for _ in range(steps):
             b.step()
         b.full_sync()
-        ms = (time.perf_counter() - t0) / steps * 1e3
+        ms = b.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
         b.w.profile_enable(False)
-        dom, other = rooflines(b, kernel_times(b), ms, steps)
+        kern = kernel_times(b)
+        if b.rank != 0:
+            return None
+        dom, other = rooflines(b, kern, ms, steps)
         return {"steps": steps, "op_mix_ms_per_step_phases_apart": round(ms, 3), "roofline": dom, "roofline_other": other,
-                "note": "op-mix steps with the transforms and the commitments one after the other: launch durations without another context's kernels beside them"}
+                "note": "op-mix steps on ONE transform lane with the transforms and the commitments one after the other: launch durations without another "
+                        "context's kernels beside them" + (" (a simulated rank: 1/S of the work per launch)" if b.sim else "")}
     finally:
-        b.overlap = saved
+        b.overlap, b.overlap_multi, b.n_lanes = saved

@@ -123,6 +123,13 @@ def run(args, json_fd):
             out["verification"] = mv
             out["verified"] = bool(mv) and "error" not in mv and all(mv.values())
 
+    if (multi or sim) and nbig and b.scheme == "reference2d":
+        # per-launch durations of an N > 1 / simulated run are wall times under two transform lanes + commitments (+ the class prover's third context):
+        # two op-mix steps on ONE lane, phases apart, give the kernel's own fraction at the per-rank launch size
+        un = run_leg(guard, "roofline_unoverlapped", LEG, lambda: headline.unoverlapped_roofline(b))
+        if rank0:
+            out["roofline_unoverlapped"] = ({"ran": "error" not in (un or {}), **({"error": un["error"]} if "error" in (un or {}) else {})} if b.emulated else un)
+
     next_rows = _single_gpu_legs(b, out, args, P, proof_ms, rounds_ms) if (single and rank0) else None
     class_row = None
     if with_class:
