@@ -257,10 +257,15 @@ def test_other_configs_quote_the_unoverlapped_fraction_only():
                                                                                       "commitments_tail_after_the_last_transform": 1.0, "note": "x"}},
             "roofline": {"kernel": "ntt_pass_kernel", "frac": 0.03, "avg_launch_ms": 0.5, "overlap_note": "stretched"}, "verified": True, "proof_ms": 50.0}
     e = entry_of("c", dict(base, roofline_unoverlapped={"roofline": {"kernel": "ntt_pass_kernel", "frac": 0.055, "avg_launch_ms": 0.3}}))
-    assert e["frac"] == 0.055 and e["avg_launch_ms"] == 0.3 and e["frac_in_the_overlapped_timed_region"] == 0.03 and "roofline_unoverlapped" in e["frac_source"]
+    assert e["frac"] == 0.055 and e["avg_launch_ms"] == 0.3 and e["frac_in_the_overlapped_timed_region"] == {"kernel": "ntt_pass_kernel", "frac": 0.03}
+    assert "roofline_unoverlapped" in e["frac_source"] and e["dominant_kernel"] == "ntt_pass_kernel"
+    # the fraction quoted is ntt_pass_kernel's even where another kernel dominates the un-overlapped pass (BLS12-381: the accumulation); all of them sit beside it
+    e2 = entry_of("c", dict(base, roofline_unoverlapped={"roofline": {"kernel": "msm_accumulate_kernel", "frac": 0.007, "avg_launch_ms": 18.0},
+                                                         "roofline_other": [{"kernel": "ntt_pass_kernel", "frac": 0.05, "avg_launch_ms": 0.9}]}))
+    assert e2["frac"] == 0.05 and e2["dominant_kernel"] == "ntt_pass_kernel" and e2["frac_by_kernel_unoverlapped"]["msm_accumulate_kernel"]["frac"] == 0.007
     assert "commitments" not in e["op_mix_phases_ms"] and "commitments_tail_after_the_last_transform" in e["op_mix_phases_ms"]
     e = entry_of("c", base)
-    assert e["frac"] is None and e["frac_in_the_overlapped_timed_region"] == 0.03 and "not quoted" in e["frac_source"]
+    assert e["frac"] is None and e["frac_in_the_overlapped_timed_region"]["frac"] == 0.03 and "not quoted" in e["frac_source"]
 
 
 class _FakeClock:
