@@ -128,7 +128,7 @@ def test_compiled_cpp_host_program(emu_env, tmp_path):
 def test_compiled_cpp_prover_program(emu_env, tmp_path):
     """tests/host_cpp/prover_check.cpp — the five rounds of `Prover::prove` with their merlin transcript as compiled C++ on the bare C ABI
     (host/plonk_prover.hpp), against the (emulated) library: verifying key, challenges, proof and serialization checked against the oracle's
-    rounds and the Python transcript (tests/test_host_cpp.py: check_cpp_prover); both curves on the GPU."""
+    rounds and the Python transcript (tests/test_host_cpp.py: check_cpp_prover), both curves (larger sizes on the GPU)."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from test_host_cpp import _build_prover, check_cpp_prover
     from oracle import oracle as O
@@ -139,6 +139,7 @@ def test_compiled_cpp_prover_program(emu_env, tmp_path):
     os.symlink(emu_env["PLONK_HIP_LIB"], shadow / "libplonk_hip.so")            # DT_RUNPATH yields to LD_LIBRARY_PATH
     env = dict(emu_env, LD_LIBRARY_PATH=str(shadow) + os.pathsep + emu_env.get("LD_LIBRARY_PATH", ""))
     check_cpp_prover(tmp_path, exe, "bn254", 0, 5, seed=1300, env=env)
+    check_cpp_prover(tmp_path, exe, "bls12_381", 1, 4, seed=1301, env=env)          # the six-limb Fq path of the point encodings
 
 
 def _bench_dry_run(env, world, port, extra=()):
