@@ -213,3 +213,31 @@ def test_oracle_polynomial_rows_equal_sympy_galoistools(name, cid, cv, b):
         zh = [ZZ(1)] + [ZZ(0)] * (n - 1) + [ZZ(r - 1)]
         want = gf_add(gf_mul(hi_first(bl), zh, r, ZZ), hi_first(p_), r, ZZ)
         assert from_mont_ints(O.blind(cid, G.mont_limbs(p_, r), n, G.mont_limbs(bl, r)), r) == lo_first(want, n + kb)
+
+
+@pytest.mark.parametrize("name,cid,cv,b", CURVES)
+def test_committed_sympy_fixture_is_what_the_generator_writes(name, cid, cv, b):
+    """The fixture the GPU golden test consumes IS sympy's output: the generator's own functions, run here on the smaller entries, reproduce the
+    committed file (a hand-edited or stale tests/golden/sympy_*.json fails) — transforms up to 2^5 points in full, the 2^7-point digests."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("gen_golden_sympy", os.path.join(root, "tools", "gen_golden_sympy.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    doc = G.load_sympy(name)
+    r = cv.fr.p
+    R = pow(2, 256, r)
+    assert gen.CURVES[name]["r"] == r and doc["ntt_seed"] == gen.NTT_SEED
+    for e in doc["ntt"]:
+        if e["log_n"] > 5:
+            continue
+        a = gen.ntt_input(r, e["log_n"])
+        modes, _ = gen.four_modes(a, r, primitive_root(r))
+        assert e["input_mont"] == [hex(x * R % r) for x in a]
+        for k, v in modes.items():
+            assert e[k] == [hex(int(x) * R % r) for x in v], (e["log_n"], k)
+    e = next(x for x in doc["ntt_digest"] if x["log_n"] == 7)
+    a = gen.ntt_input(r, 7)
+    modes, _ = gen.four_modes(a, r, primitive_root(r))
+    assert e["input_sha256"] == gen.digest(a, R, r) and all(e[k + "_sha256"] == gen.digest(v, R, r) for k, v in modes.items())
