@@ -1007,15 +1007,31 @@ int blind_run(NttTables& T, void* d_poly, size_t n, const uint64_t* blinders, si
 // ---------------------------------------------------------------------------------------------- degree (DensePolynomial trimming)
 // index of the highest non-zero coefficient + 1 (0 for the zero polynomial): what DensePolynomial::from_coefficients_vec
 // leaves after trimming, used for the WrongQuotientPolyDegree check of dispatcher2.rs:511-518
+// One workgroup scans DEG_CH * 256 consecutive coefficients (coalesced: lane-strided), folds its highest non-zero index in LDS and issues ONE atomicMax — and only if
+// it found one.  (Until round 6 every non-zero coefficient issued its own atomicMax on the one result word: 84 M serialised atomics for the degree-(5n + 7) quotient of a
+// 2^24-gate circuit, 14 - 16 ms of round 3 — tools/commit_round_probe.py found it as the gap between round 3's commitment phase and the same commitments alone.)
+#define DEG_CH 8
 __global__ void __launch_bounds__(256) poly_degree_kernel(const Fr* __restrict__ poly, uint64_t len, unsigned long long* __restrict__ top) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= len) return;
-    if (!fp_is_zero(load_fr(poly + i))) atomicMax(top, (unsigned long long)(i + 1));
+    __shared__ unsigned long long best[256];
+    const uint64_t base = (uint64_t)blockIdx.x * (256 * DEG_CH);
+    unsigned long long cand = 0;
+#pragma unroll
+    for (int k = 0; k < DEG_CH; k++) {
+        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        if (i < len && !fp_is_zero(load_fr(poly + i))) cand = (unsigned long long)(i + 1);      // i grows with k: the last hit is this lane's highest
+    }
+    best[threadIdx.x] = cand;
+    __syncthreads();
+    for (int d = 128; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d && best[threadIdx.x + d] > best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + d];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && best[0] != 0) atomicMax(top, best[0]);
 }
 int poly_degree_run(const void* d_poly, size_t len, int64_t* degree, void* scratch, hipStream_t stream) {
     unsigned long long* top = (unsigned long long*)scratch;
     HIP_TRY(hipMemsetAsync(top, 0, 8, stream));
-    if (len) hipLaunchKernelGGL(poly_degree_kernel, dim3((uint32_t)((len + 255) / 256)), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, top);
+    if (len) hipLaunchKernelGGL(poly_degree_kernel, dim3((uint32_t)((len + 256 * DEG_CH - 1) / (256 * DEG_CH))), dim3(256), 0, stream, (const Fr*)d_poly, (uint64_t)len, top);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return plonk_fail(PLONK_ERR_HIP, "poly_degree launch: %s", hipGetErrorString(e));
     unsigned long long h = 0;

@@ -249,3 +249,31 @@ def test_poly_lincomb_and_blind(gpu_workers, oracle, curve, cid):
         d.free()
     for b in bufs + [out]:
         b.free()
+
+
+@pytest.mark.parametrize("curve,cid", [("bn254", 0), ("bls12_381", 1)])
+def test_poly_degree(gpu_workers, oracle, curve, cid):
+    """plonk_poly_degree_dev = DensePolynomial::degree() after trimming (the WrongQuotientPolyDegree check, dispatcher2.rs:511-518): the index of the
+    highest non-zero coefficient, -1 for the zero polynomial — for lengths around the kernel's 2048-coefficient workgroup chunk, a single non-zero
+    at either end, trailing zeros, and a 2^20 + 5 vector whose top sits in the last partial chunk."""
+    w = gpu_workers(curve)
+    rs = np.random.RandomState(11 + cid)
+    for length in (1, 2, 255, 256, 257, 2047, 2048, 2049, 5000, (1 << 20) + 5):
+        v = oracle.rand_fr(cid, 300 + length % 97, length)
+        cases = []
+        for top in sorted({0, length - 1, int(rs.randint(0, length)), max(0, length - 2048), max(0, length - 2049)}):
+            a = v.copy()
+            a[top + 1:] = 0
+            if not a[top].any():
+                a[top, 0] = 1
+            cases.append((a, top))
+        z = np.zeros_like(v)
+        cases.append((z, -1))
+        one = z.copy()
+        one[0, 3] = 1                      # only the top limb of coefficient 0 is set
+        cases.append((one, 0))
+        buf = w.alloc(length * 32)
+        for a, want in cases:
+            buf.upload(a)
+            assert w.poly_degree_dev(buf.ptr, length) == want, (length, want)
+        buf.free()
