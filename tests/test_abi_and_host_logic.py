@@ -171,3 +171,49 @@ def test_kernel_machine_code_hashes():
         assert written["unit_of:ntt_pass_kernel"] == "ntt_engine" and written["unit_of:msm_accumulate_kernel"] == "msm_engine" and "host:plonk_api" in written
     db = json.load(open(os.path.join(ROOT, "profiles", "pmc_current.json")))
     assert {k_ for k_ in db.get("code_hashes", {}) if ":" not in k_} <= set(hashes)
+
+
+@pytest.mark.parametrize("curve", [0, 1])
+def test_host_side_point_functions_match_the_oracle(curve):
+    """plonk_g1_add / plonk_g1_to_affine (the dispatcher's reduce and `Commitment(commitment.into())`, dispatcher.rs:236-238, dispatcher2.rs:892) are
+    host code of the REAL library — since round 6 on the 64-bit-limb host statement of the Montgomery product (csrc/fp.hpp, hipcc host pass only) that
+    also runs the MSM's host fold.  No GPU needed: random sums, P + P, P - P, the identity on either side, against the oracle bit for bit."""
+    import ctypes as C
+    import numpy as np
+    from distributed_plonk_amd import _ffi
+    from oracle import oracle as O
+    lib = _ffi.lib()
+    Q = O.FQ_LIMBS[curve]
+    one = O.field_const(curve, 1, 1)[:Q]
+    bases = O.gen_bases(curve, 99, 24, 24)
+    jac = lambda xy: np.concatenate([xy, one]).astype(np.uint64)
+    zero = np.concatenate([one, one, np.zeros(Q, dtype=np.uint64)])
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+
+    def add(a, b):
+        out = np.zeros(3 * Q, dtype=np.uint64)
+        assert lib.plonk_g1_add(curve, p(np.ascontiguousarray(a)), p(np.ascontiguousarray(b)), p(out)) == 0
+        return out
+
+    def affine(j):
+        xy, inf = np.zeros(2 * Q, dtype=np.uint64), C.c_int(0)
+        assert lib.plonk_g1_to_affine(curve, p(np.ascontiguousarray(j)), p(xy), C.byref(inf)) == 0
+        return xy, bool(inf.value)
+
+    def same(j, want_jac):
+        (a, ai), (b, bi) = affine(j), O.jac_to_affine(curve, want_jac)
+        return ai == bi and np.array_equal(a, b)
+
+    acc_l, acc_o = zero.copy(), zero.copy()
+    for i in range(24):
+        acc_l, acc_o = add(acc_l, jac(bases[i])), O.jac_add(curve, acc_o, jac(bases[i]))
+        assert same(acc_l, acc_o), i
+    dbl = add(jac(bases[3]), jac(bases[3]))
+    assert same(dbl, O.jac_add(curve, jac(bases[3]), jac(bases[3])))
+    neg = bases[5].copy()
+    qmod = int.from_bytes(O.field_const(curve, 1, 0)[:Q].tobytes(), "little")
+    y = int.from_bytes(neg[Q:].tobytes(), "little")
+    neg[Q:] = np.frombuffer(((qmod - y) % qmod).to_bytes(8 * Q, "little"), dtype=np.uint64)
+    assert affine(add(jac(bases[5]), jac(neg)))[1] is True                       # P - P
+    assert same(add(zero, jac(bases[7])), jac(bases[7])) and same(add(jac(bases[7]), zero), jac(bases[7]))
+    assert same(add(acc_l, acc_l), O.jac_add(curve, acc_o, acc_o))               # doubling of a non-normalised point
