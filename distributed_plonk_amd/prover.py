@@ -433,7 +433,8 @@ class Prover:
         WP = n + 2
         d_wp = alloc(5 * WP)
         wp = [d_wp.ptr + i * WP * 32 for i in range(5)]
-        w.memset_dev(d_wp.ptr, 0, 5 * WP * 32)
+        for i in range(5):                                            # the interpolation writes coefficients 0 .. n-1; only the two above them must be zero
+            w.memset_dev(wp[i] + n * 32, 0, (WP - n) * 32)            # before the blinding adds into them (a whole-vector memset was 2.5 GiB per 2^24 proof)
         self._interpolate_many(alloc, [(wev[i], wp[i]) for i in range(5)])
         for i in range(5):
             w.blind_dev(wp[i], n, blinders["wires"][i])
@@ -446,7 +447,7 @@ class Prover:
         dbg_prod = self._download(d_prod_ptr, n) if keep else None
         PP = n + 3
         d_pp = alloc(PP)
-        w.memset_dev(d_pp.ptr, 0, PP * 32)
+        w.memset_dev(d_pp.ptr + n * 32, 0, (PP - n) * 32)
         self._interpolate_many(alloc, [(d_prod_ptr, d_pp.ptr)])
         w.blind_dev(d_pp.ptr, n, blinders["perm"])
         proof["prod_perm_poly_comm"] = self._commit(d_pp.ptr, PP)

@@ -453,8 +453,8 @@ class Prover {
         const size_t WP = n + 2;
         void* d_wp = scope.alloc(5 * WP);
         void* d_tmp = scope.alloc(n);
-        check(plonk_memset_dev(ctx_, d_wp, 0, 5 * WP * 32));
         for (int i = 0; i < 5; i++) {
+            check(plonk_memset_dev(ctx_, at(d_wp, i * WP + n), 0, (WP - n) * 32));          // the interpolation writes coefficients 0 .. n-1
             interpolate(d_tmp, wev[i], at(d_wp, i * WP));
             check(plonk_blind_dev(ctx_, at(d_wp, i * WP), n, wire_blinders + 8 * i, 2));
         }
@@ -471,7 +471,7 @@ class Prover {
         check(plonk_perm_product_dev(ctx_, wev, d_id, d_idx, beta.data(), gamma.data(), n, d_prod));
         const size_t PP = n + 3;
         void* d_pp = scope.alloc(PP);
-        check(plonk_memset_dev(ctx_, d_pp, 0, PP * 32));
+        check(plonk_memset_dev(ctx_, at(d_pp, n), 0, (PP - n) * 32));
         interpolate(d_tmp, d_prod, d_pp);
         check(plonk_blind_dev(ctx_, d_pp, n, perm_blinders, 3));
         proof.prod_perm_poly_comm = commit(d_pp, PP);
